@@ -1,0 +1,203 @@
+/*
+ * snapmi.h -- C ABI of libsnapmi.so, the MI355X (gfx950) Snappy raw block codec.
+ *
+ * This is the drop-in boundary for the hot path of BurntSushi/rust-snappy:
+ *   snap::raw::Encoder::compress   (reference src/compress.rs:99-154)
+ *   snap::raw::Decoder::decompress (reference src/decompress.rs:75-95)
+ * and the functions beside them.  Three groups of entry points:
+ *
+ *  1. The libsnappy C API (snappy-c.h) -- exactly the symbols the reference's
+ *     own native seam binds (snappy-cpp/src/lib.rs:66-88, linked by
+ *     snappy-cpp/build.rs:2 as dylib=snappy).  Pointing that link line at
+ *     libsnapmi.so makes the reference's `--features cpp` tests and benches
+ *     run against the GPU codec unchanged.
+ *  2. Scalar mirrors of snap::raw::* that carry the full snap::Error
+ *     (variant + fields, reference src/error.rs:72-180) across the ABI.
+ *  3. The batched, device-resident API the Rust shim / a GPU pipeline calls:
+ *     arrays of independent raw streams in HBM in, arrays of compressed
+ *     streams in HBM out.  This is the form that is benchmarked.
+ *
+ * Plain pointers and sizes only; no C++ or torch types.  All functions are
+ * blocking unless stated otherwise.  Every compute entry point runs HIP
+ * kernels on the GPU; there is no CPU fallback -- without a usable device
+ * they fail with SNAPMI_E_DEVICE.
+ */
+#ifndef SNAPMI_H
+#define SNAPMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ */
+/* 1. libsnappy C API (snappy-c.h:46-122; bound by the reference at     */
+/*    snappy-cpp/src/lib.rs:66-88).  Host pointers.                     */
+/* ------------------------------------------------------------------ */
+typedef enum {
+    SNAPPY_OK = 0,
+    SNAPPY_INVALID_INPUT = 1,
+    SNAPPY_BUFFER_TOO_SMALL = 2
+} snappy_status;
+
+/* replaces snappy_compress (snappy-cpp/src/lib.rs:67-72).
+ * *compressed_length: in = capacity, out = bytes written. */
+snappy_status snappy_compress(const char *input, size_t input_length,
+                              char *compressed, size_t *compressed_length);
+/* replaces snappy_uncompress (snappy-cpp/src/lib.rs:74-79) */
+snappy_status snappy_uncompress(const char *compressed,
+                                size_t compressed_length, char *uncompressed,
+                                size_t *uncompressed_length);
+/* replaces snappy_max_compressed_length (snappy-cpp/src/lib.rs:81) */
+size_t snappy_max_compressed_length(size_t source_length);
+/* replaces snappy_uncompressed_length (snappy-cpp/src/lib.rs:83-87) */
+snappy_status snappy_uncompressed_length(const char *compressed,
+                                         size_t compressed_length,
+                                         size_t *result);
+/* snappy-c.h:120-122; not bound by the reference, kept for completeness */
+snappy_status snappy_validate_compressed_buffer(const char *compressed,
+                                                size_t compressed_length);
+
+/* ------------------------------------------------------------------ */
+/* Errors: snap::Error (reference src/error.rs:72-180), same order.     */
+/* ------------------------------------------------------------------ */
+enum snapmi_kind {
+    SNAPMI_OK = 0,
+    SNAPMI_TOO_BIG = 1,                  /* a=given        b=max            */
+    SNAPMI_BUFFER_TOO_SMALL = 2,         /* a=given        b=min            */
+    SNAPMI_EMPTY = 3,
+    SNAPMI_HEADER = 4,
+    SNAPMI_HEADER_MISMATCH = 5,          /* a=expected_len b=got_len        */
+    SNAPMI_LITERAL = 6,                  /* a=len  b=src_len  c=dst_len     */
+    SNAPMI_COPY_READ = 7,                /* a=len  b=src_len                */
+    SNAPMI_COPY_WRITE = 8,               /* a=len  b=dst_len                */
+    SNAPMI_OFFSET = 9,                   /* a=offset  b=dst_pos             */
+    SNAPMI_STREAM_HEADER = 10,           /* a=byte                          */
+    SNAPMI_STREAM_HEADER_MISMATCH = 11,  /* a=first 6 body bytes, LE packed */
+    SNAPMI_UNSUPPORTED_CHUNK_TYPE = 12,  /* a=byte                          */
+    SNAPMI_UNSUPPORTED_CHUNK_LENGTH = 13,/* a=len  b=header (0/1)           */
+    SNAPMI_CHECKSUM = 14,                /* a=expected  b=got               */
+    /* not snap::Error variants: */
+    SNAPMI_E_UNEXPECTED_EOF = 64, /* io::ErrorKind::UnexpectedEof (frame)   */
+    SNAPMI_E_DEVICE = 100,  /* no GPU / HIP call failed; see last_error     */
+    SNAPMI_E_ARGUMENT = 101 /* NULL pointer, bad context                    */
+};
+
+typedef struct snapmi_error {
+    int32_t kind; /* enum snapmi_kind */
+    uint32_t reserved;
+    uint64_t a, b, c;
+} snapmi_error;
+
+/* ------------------------------------------------------------------ */
+/* Context: one HIP device + stream + device scratch.  Maps to          */
+/* snap::raw::Encoder (exclusive &mut self, owns its scratch table --   */
+/* reference src/compress.rs:67-70): one context per thread.            */
+/* ------------------------------------------------------------------ */
+typedef struct snapmi_ctx snapmi_ctx;
+
+/* device: HIP ordinal.  hip_stream: a hipStream_t the kernels are
+ * launched on, or NULL for a stream owned by the context. */
+int snapmi_ctx_create(int device, void *hip_stream, snapmi_ctx **out);
+void snapmi_ctx_destroy(snapmi_ctx *ctx);
+/* Message for the last SNAPMI_E_DEVICE / SNAPMI_E_ARGUMENT on this ctx. */
+const char *snapmi_last_error(const snapmi_ctx *ctx);
+/* hipStream_t the context launches on (for event timing by the caller). */
+void *snapmi_ctx_stream(const snapmi_ctx *ctx);
+/* "snapmi <version> gfx950" */
+const char *snapmi_version(void);
+
+/* ------------------------------------------------------------------ */
+/* 2. Scalar mirrors of snap::raw (host buffers; H2D + kernels + D2H).  */
+/*    Return enum snapmi_kind; *err (may be NULL) gets the fields.      */
+/* ------------------------------------------------------------------ */
+/* snap::raw::max_compress_len, reference src/compress.rs:42-53
+ * (0 when the input or the bound exceeds 2^32-1). */
+size_t snapmi_max_compress_len(size_t input_len);
+/* snap::raw::decompress_len, reference src/decompress.rs:30-35.
+ * Pure header parse on the host. */
+int snapmi_decompress_len(const uint8_t *input, size_t input_len,
+                          size_t *result, snapmi_error *err);
+/* snap::raw::Encoder::compress, reference src/compress.rs:99-154 */
+int snapmi_raw_compress(snapmi_ctx *ctx, const uint8_t *input,
+                        size_t input_len, uint8_t *output, size_t output_cap,
+                        size_t *written, snapmi_error *err);
+/* snap::raw::Decoder::decompress, reference src/decompress.rs:75-95 */
+int snapmi_raw_decompress(snapmi_ctx *ctx, const uint8_t *input,
+                          size_t input_len, uint8_t *output,
+                          size_t output_cap, size_t *written,
+                          snapmi_error *err);
+
+/* ------------------------------------------------------------------ */
+/* 3. Batched device-resident API.  Every d_* pointer is device memory  */
+/*    on the context's device; stream i is an independent raw stream    */
+/*    (its own varint header), exactly one Encoder::compress /          */
+/*    Decoder::decompress call of the reference.                        */
+/*    Asynchronous: work is enqueued on the context's stream; results   */
+/*    are valid after snapmi_ctx_synchronize (or a caller-side wait on  */
+/*    that stream).  Return value reports enqueue-time failures only;   */
+/*    per-stream results land in d_out_lens / d_errs.                   */
+/* ------------------------------------------------------------------ */
+
+/*
+ * Compress n streams.
+ *   d_in_ptrs[i], d_in_lens[i] : input bytes of stream i
+ *   h_in_lens                  : host copy of d_in_lens (needed to size the
+ *                                launch); NULL = fetched with a blocking D2H
+ *   d_out_ptrs[i], d_out_caps[i]: output buffer; capacity must be >=
+ *                                snapmi_max_compress_len(len) or stream i
+ *                                fails with BufferTooSmall (reference
+ *                                src/compress.rs:111-116); d_out_caps NULL =
+ *                                capacities are not checked
+ *   d_out_lens[i]              : bytes written (0 on error)
+ *   d_errs[i]                  : per-stream snapmi_error (may be NULL)
+ */
+int snapmi_compress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
+                          const uint64_t *d_in_lens,
+                          const uint64_t *h_in_lens, void *const *d_out_ptrs,
+                          const uint64_t *d_out_caps, uint64_t *d_out_lens,
+                          snapmi_error *d_errs, size_t n);
+
+/*
+ * Decompress n streams.  d_out_caps[i] is the capacity of d_out_ptrs[i]
+ * (reference: output.len(), src/decompress.rs:84-89); d_out_lens[i] gets the
+ * decompressed length on success, 0 on error.
+ */
+int snapmi_decompress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
+                            const uint64_t *d_in_lens,
+                            void *const *d_out_ptrs,
+                            const uint64_t *d_out_caps, uint64_t *d_out_lens,
+                            snapmi_error *d_errs, size_t n);
+
+/* decompress_len for n streams on the device (reference
+ * src/decompress.rs:30-35): d_out_lens[i] = header value, d_errs[i] as the
+ * reference would return. */
+int snapmi_decompress_len_batch(snapmi_ctx *ctx,
+                                const void *const *d_in_ptrs,
+                                const uint64_t *d_in_lens,
+                                uint64_t *d_out_lens, snapmi_error *d_errs,
+                                size_t n);
+
+/* Wait for everything enqueued on the context's stream. */
+int snapmi_ctx_synchronize(snapmi_ctx *ctx);
+
+/*
+ * Timing of the last batch call, measured with HIP events recorded on the
+ * context's stream around each kernel group.  Valid after synchronize.
+ * Times in milliseconds; a group that did not run reports 0.
+ */
+typedef struct snapmi_timing {
+    float plan_ms;     /* descriptor scan / block table kernels            */
+    float codec_ms;    /* the dominant kernel: compress or decompress      */
+    float compact_ms;  /* compress only: gather of blocks 1.. into place   */
+    float total_ms;    /* first event to last event                        */
+    uint64_t codec_launches; /* launches of the dominant kernel            */
+} snapmi_timing;
+int snapmi_last_timing(snapmi_ctx *ctx, snapmi_timing *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNAPMI_H */

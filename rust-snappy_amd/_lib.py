@@ -1,0 +1,75 @@
+"""ctypes binding of libsnapmi.so (include/snapmi.h).
+
+The shared library is the product: HIP kernels for gfx950 behind a C ABI.
+This module only declares signatures.  It never falls back to a CPU codec:
+if the library is missing, importing the package fails loudly.
+"""
+import ctypes as C
+import os
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = PKG_DIR / "libsnapmi.so"
+
+
+class SnapmiError(C.Structure):
+    """snapmi_error: (kind, a, b, c) -- snap::Error variant + fields."""
+    _fields_ = [("kind", C.c_int32), ("reserved", C.c_uint32),
+                ("a", C.c_uint64), ("b", C.c_uint64), ("c", C.c_uint64)]
+
+
+class SnapmiTiming(C.Structure):
+    _fields_ = [("plan_ms", C.c_float), ("codec_ms", C.c_float),
+                ("compact_ms", C.c_float), ("total_ms", C.c_float),
+                ("codec_launches", C.c_uint64)]
+
+
+# every symbol include/snapmi.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+_SZ = C.c_size_t
+_SZP = C.POINTER(C.c_size_t)
+_ERRP = C.POINTER(SnapmiError)
+SYMBOLS = [
+    ("snappy_compress", C.c_int, [C.c_char_p, _SZ, _P, _SZP]),
+    ("snappy_uncompress", C.c_int, [C.c_char_p, _SZ, _P, _SZP]),
+    ("snappy_max_compressed_length", _SZ, [_SZ]),
+    ("snappy_uncompressed_length", C.c_int, [C.c_char_p, _SZ, _SZP]),
+    ("snappy_validate_compressed_buffer", C.c_int, [C.c_char_p, _SZ]),
+    ("snapmi_ctx_create", C.c_int, [C.c_int, _P, C.POINTER(_P)]),
+    ("snapmi_ctx_destroy", None, [_P]),
+    ("snapmi_last_error", C.c_char_p, [_P]),
+    ("snapmi_ctx_stream", _P, [_P]),
+    ("snapmi_version", C.c_char_p, []),
+    ("snapmi_max_compress_len", _SZ, [_SZ]),
+    ("snapmi_decompress_len", C.c_int, [C.c_char_p, _SZ, _SZP, _ERRP]),
+    ("snapmi_raw_compress", C.c_int,
+     [_P, C.c_char_p, _SZ, _P, _SZ, _SZP, _ERRP]),
+    ("snapmi_raw_decompress", C.c_int,
+     [_P, C.c_char_p, _SZ, _P, _SZ, _SZP, _ERRP]),
+    ("snapmi_compress_batch", C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _SZ]),
+    ("snapmi_decompress_batch", C.c_int, [_P, _P, _P, _P, _P, _P, _P, _SZ]),
+    ("snapmi_decompress_len_batch", C.c_int, [_P, _P, _P, _P, _P, _SZ]),
+    ("snapmi_ctx_synchronize", C.c_int, [_P]),
+    ("snapmi_last_timing", C.c_int, [_P, C.POINTER(SnapmiTiming)]),
+]
+
+_lib = None
+
+
+def load():
+    """Load libsnapmi.so; raise if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(str(LIB_PATH), mode=getattr(os, "RTLD_LOCAL", 0))
+    for name, res, args in SYMBOLS:
+        f = getattr(L, name)  # AttributeError if the ABI lost a symbol
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L

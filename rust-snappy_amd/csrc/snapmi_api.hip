@@ -1,0 +1,616 @@
+// snapmi_api.hip -- host side of the C ABI declared in include/snapmi.h.
+//
+// Nothing here computes Snappy on the CPU: the only host-side arithmetic is
+// the header varint parse (decompress_len) and max_compress_len, which the
+// reference also treats as free-standing helpers (src/compress.rs:42-53,
+// src/decompress.rs:30-35).  Every compress/decompress entry point launches
+// the HIP kernels and fails with SNAPMI_E_DEVICE when there is no GPU.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "snapmi.h"
+#include "snapmi_device.hpp"
+#include "snapmi_kernels.hpp"
+
+using namespace snapmi;
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+} // namespace
+
+struct snapmi_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    std::string last_error;
+    // grow-only device scratch
+    DevBuf blk_first, slot_first, blk_size, blk_off, slots;
+    // staging for the host-pointer (scalar) entry points
+    DevBuf st_in, st_out, st_desc;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool timing_valid = false;
+    bool timing_is_compress = false;
+    uint64_t codec_launches = 0;
+};
+
+namespace {
+
+int fail_ctx(snapmi_ctx *ctx, int kind, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->last_error = buf;
+    return kind;
+}
+
+#define HIP_TRY(ctx, expr)                                                    \
+    do {                                                                      \
+        hipError_t _e = (expr);                                               \
+        if (_e != hipSuccess)                                                 \
+            return fail_ctx((ctx), SNAPMI_E_DEVICE, "%s failed: %s", #expr,   \
+                            hipGetErrorString(_e));                           \
+    } while (0)
+
+int reserve(snapmi_ctx *ctx, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap)
+        return SNAPMI_OK;
+    if (b.p) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes + bytes / 8 + 256;
+    HIP_TRY(ctx, hipMalloc(&b.p, want));
+    b.cap = want;
+    return SNAPMI_OK;
+}
+
+void set_err(snapmi_error *e, int kind, uint64_t a = 0, uint64_t b = 0,
+             uint64_t c = 0)
+{
+    if (e) {
+        e->kind = kind;
+        e->reserved = 0;
+        e->a = a;
+        e->b = b;
+        e->c = c;
+    }
+}
+
+// reference bytes::read_varu64, src/bytes.rs:73-90
+size_t host_varint(const uint8_t *p, size_t n, uint64_t *value)
+{
+    uint64_t acc = 0;
+    unsigned shift = 0;
+    for (size_t i = 0; i < n; i++) {
+        uint8_t b = p[i];
+        if (shift >= 64)
+            return 0;
+        if (b < 0x80) {
+            *value = acc | ((uint64_t)b << shift);
+            return i + 1;
+        }
+        acc |= (uint64_t)(b & 0x7F) << shift;
+        shift += 7;
+    }
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *snapmi_version(void) { return "snapmi 0.1.0 gfx950"; }
+
+int snapmi_ctx_create(int device, void *hip_stream, snapmi_ctx **out)
+{
+    if (!out)
+        return SNAPMI_E_ARGUMENT;
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0 || device < 0 || device >= count) {
+        fprintf(stderr,
+                "snapmi: no usable HIP device (requested %d, %d visible: "
+                "%s); the codec has no CPU fallback\n",
+                device, count, hipGetErrorString(e));
+        return SNAPMI_E_DEVICE;
+    }
+    if (hipSetDevice(device) != hipSuccess)
+        return SNAPMI_E_DEVICE;
+    snapmi_ctx *ctx = new (std::nothrow) snapmi_ctx();
+    if (!ctx)
+        return SNAPMI_E_DEVICE;
+    ctx->device = device;
+    if (hip_stream) {
+        ctx->stream = (hipStream_t)hip_stream;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) !=
+            hipSuccess) {
+            delete ctx;
+            return SNAPMI_E_DEVICE;
+        }
+        ctx->owns_stream = true;
+    }
+    for (auto &ev : ctx->ev) {
+        if (hipEventCreate(&ev) != hipSuccess) {
+            snapmi_ctx_destroy(ctx);
+            return SNAPMI_E_DEVICE;
+        }
+    }
+    *out = ctx;
+    return SNAPMI_OK;
+}
+
+void snapmi_ctx_destroy(snapmi_ctx *ctx)
+{
+    if (!ctx)
+        return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream)
+        (void)hipStreamSynchronize(ctx->stream);
+    for (DevBuf *b : {&ctx->blk_first, &ctx->slot_first, &ctx->blk_size,
+                      &ctx->blk_off, &ctx->slots, &ctx->st_in, &ctx->st_out,
+                      &ctx->st_desc})
+        if (b->p)
+            (void)hipFree(b->p);
+    for (auto &ev : ctx->ev)
+        if (ev)
+            (void)hipEventDestroy(ev);
+    if (ctx->owns_stream && ctx->stream)
+        (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *snapmi_last_error(const snapmi_ctx *ctx)
+{
+    return ctx ? ctx->last_error.c_str() : "null context";
+}
+
+void *snapmi_ctx_stream(const snapmi_ctx *ctx)
+{
+    return ctx ? (void *)ctx->stream : nullptr;
+}
+
+int snapmi_ctx_synchronize(snapmi_ctx *ctx)
+{
+    if (!ctx)
+        return SNAPMI_E_ARGUMENT;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SNAPMI_OK;
+}
+
+size_t snapmi_max_compress_len(size_t input_len)
+{
+    return (size_t)max_compress_len_u64(input_len);
+}
+
+int snapmi_decompress_len(const uint8_t *input, size_t input_len,
+                          size_t *result, snapmi_error *err)
+{
+    if (!result || (!input && input_len))
+        return SNAPMI_E_ARGUMENT;
+    *result = 0;
+    set_err(err, SNAPMI_OK);
+    if (input_len == 0)
+        return SNAPMI_OK;
+    uint64_t v = 0;
+    if (host_varint(input, input_len, &v) == 0) {
+        set_err(err, SNAPMI_HEADER);
+        return SNAPMI_HEADER;
+    }
+    if (v > kMaxInput) {
+        set_err(err, SNAPMI_TOO_BIG, v, kMaxInput);
+        return SNAPMI_TOO_BIG;
+    }
+    *result = (size_t)v;
+    return SNAPMI_OK;
+}
+
+// ----------------------------------------------------------------------
+// batched device-resident API
+// ----------------------------------------------------------------------
+int snapmi_compress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
+                          const uint64_t *d_in_lens,
+                          const uint64_t *h_in_lens, void *const *d_out_ptrs,
+                          const uint64_t *d_out_caps, uint64_t *d_out_lens,
+                          snapmi_error *d_errs, size_t n)
+{
+    if (!ctx)
+        return SNAPMI_E_ARGUMENT;
+    if (n == 0)
+        return SNAPMI_OK;
+    if (!d_in_ptrs || !d_in_lens || !d_out_ptrs || !d_out_lens ||
+        n > 0x7FFFFFFFu)
+        return fail_ctx(ctx, SNAPMI_E_ARGUMENT, "compress_batch: bad args");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    std::vector<uint64_t> fetched;
+    if (!h_in_lens) {
+        fetched.resize(n);
+        HIP_TRY(ctx, hipMemcpyAsync(fetched.data(), d_in_lens,
+                                    n * sizeof(uint64_t),
+                                    hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        h_in_lens = fetched.data();
+    }
+    uint64_t blocks = 0, slots = 0;
+    for (size_t i = 0; i < n; i++) {
+        const uint64_t len = h_in_lens[i];
+        if (len == 0 || max_compress_len_u64(len) == 0)
+            continue;
+        const uint64_t nb = (len + kMaxBlock - 1) / kMaxBlock;
+        blocks += nb;
+        slots += nb - 1;
+    }
+    if (blocks > 0x7FFFFFFFu)
+        return fail_ctx(ctx, SNAPMI_E_ARGUMENT,
+                        "compress_batch: %llu blocks in one batch",
+                        (unsigned long long)blocks);
+
+    int rc;
+    if ((rc = reserve(ctx, ctx->blk_first, (n + 1) * sizeof(uint32_t))) ||
+        (rc = reserve(ctx, ctx->slot_first, (n + 1) * sizeof(uint32_t))) ||
+        (rc = reserve(ctx, ctx->blk_size, (blocks + 1) * sizeof(uint32_t))) ||
+        (rc = reserve(ctx, ctx->blk_off, (blocks + 2) * sizeof(uint64_t))) ||
+        (rc = reserve(ctx, ctx->slots, (slots + 1) * (size_t)kSlotBytes)))
+        return rc;
+
+    CompressArgs a;
+    a.in_ptrs = d_in_ptrs;
+    a.in_lens = d_in_lens;
+    a.out_ptrs = d_out_ptrs;
+    a.out_caps = d_out_caps;
+    a.out_lens = d_out_lens;
+    a.errs = d_errs;
+    a.blk_first = (uint32_t *)ctx->blk_first.p;
+    a.slot_first = (uint32_t *)ctx->slot_first.p;
+    a.blk_size = (uint32_t *)ctx->blk_size.p;
+    a.blk_off = (uint64_t *)ctx->blk_off.p;
+    a.scratch = (uint8_t *)ctx->slots.p;
+    a.n_streams = (uint32_t)n;
+    a.host_blocks = (uint32_t)blocks;
+    a.host_slots = (uint32_t)slots;
+
+    hipStream_t s = ctx->stream;
+    ctx->timing_valid = false;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], s));
+    hipLaunchKernelGGL(k_plan_compress, dim3(1), dim3(1024), 0, s, a);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], s));
+    if (blocks)
+        hipLaunchKernelGGL(k_compress_blocks, dim3((uint32_t)blocks),
+                           dim3(64), 0, s, a);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], s));
+    if (blocks) {
+        hipLaunchKernelGGL(k_scan_sizes, dim3(1), dim3(1024), 0, s, a);
+        hipLaunchKernelGGL(k_compact, dim3((uint32_t)blocks), dim3(256), 0,
+                           s, a);
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[3], s));
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->timing_valid = true;
+    ctx->timing_is_compress = true;
+    ctx->codec_launches = blocks ? 1 : 0;
+    return SNAPMI_OK;
+}
+
+int snapmi_decompress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
+                            const uint64_t *d_in_lens,
+                            void *const *d_out_ptrs,
+                            const uint64_t *d_out_caps, uint64_t *d_out_lens,
+                            snapmi_error *d_errs, size_t n)
+{
+    if (!ctx)
+        return SNAPMI_E_ARGUMENT;
+    if (n == 0)
+        return SNAPMI_OK;
+    if (!d_in_ptrs || !d_in_lens || !d_out_ptrs || !d_out_caps ||
+        !d_out_lens || n > 0x7FFFFFFFu)
+        return fail_ctx(ctx, SNAPMI_E_ARGUMENT, "decompress_batch: bad args");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DecompressArgs a;
+    a.in_ptrs = d_in_ptrs;
+    a.in_lens = d_in_lens;
+    a.out_ptrs = d_out_ptrs;
+    a.out_caps = d_out_caps;
+    a.out_lens = d_out_lens;
+    a.errs = d_errs;
+    a.n_streams = (uint32_t)n;
+    hipStream_t s = ctx->stream;
+    ctx->timing_valid = false;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], s));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], s));
+    hipLaunchKernelGGL(k_decompress_streams, dim3((uint32_t)n), dim3(64), 0,
+                       s, a);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], s));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[3], s));
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->timing_valid = true;
+    ctx->timing_is_compress = false;
+    ctx->codec_launches = 1;
+    return SNAPMI_OK;
+}
+
+int snapmi_decompress_len_batch(snapmi_ctx *ctx,
+                                const void *const *d_in_ptrs,
+                                const uint64_t *d_in_lens,
+                                uint64_t *d_out_lens, snapmi_error *d_errs,
+                                size_t n)
+{
+    if (!ctx)
+        return SNAPMI_E_ARGUMENT;
+    if (n == 0)
+        return SNAPMI_OK;
+    if (!d_in_ptrs || !d_in_lens || !d_out_lens || n > 0x7FFFFFFFu)
+        return fail_ctx(ctx, SNAPMI_E_ARGUMENT,
+                        "decompress_len_batch: bad args");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DecompressArgs a;
+    a.in_ptrs = d_in_ptrs;
+    a.in_lens = d_in_lens;
+    a.out_ptrs = nullptr;
+    a.out_caps = nullptr;
+    a.out_lens = d_out_lens;
+    a.errs = d_errs;
+    a.n_streams = (uint32_t)n;
+    hipLaunchKernelGGL(k_decompress_len, dim3((uint32_t)((n + 255) / 256)),
+                       dim3(256), 0, ctx->stream, a);
+    HIP_TRY(ctx, hipGetLastError());
+    return SNAPMI_OK;
+}
+
+int snapmi_last_timing(snapmi_ctx *ctx, snapmi_timing *out)
+{
+    if (!ctx || !out)
+        return SNAPMI_E_ARGUMENT;
+    memset(out, 0, sizeof *out);
+    if (!ctx->timing_valid)
+        return fail_ctx(ctx, SNAPMI_E_ARGUMENT, "no batch has been timed");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev[3]));
+    HIP_TRY(ctx, hipEventElapsedTime(&out->plan_ms, ctx->ev[0], ctx->ev[1]));
+    HIP_TRY(ctx, hipEventElapsedTime(&out->codec_ms, ctx->ev[1], ctx->ev[2]));
+    HIP_TRY(ctx,
+            hipEventElapsedTime(&out->compact_ms, ctx->ev[2], ctx->ev[3]));
+    HIP_TRY(ctx, hipEventElapsedTime(&out->total_ms, ctx->ev[0], ctx->ev[3]));
+    out->codec_launches = ctx->codec_launches;
+    return SNAPMI_OK;
+}
+
+// ----------------------------------------------------------------------
+// scalar mirrors (host buffers): stage through device memory, batch of 1
+// ----------------------------------------------------------------------
+namespace {
+
+struct OneDesc {
+    const void *in_ptr;
+    uint64_t in_len;
+    void *out_ptr;
+    uint64_t out_cap;
+    uint64_t out_len;
+    uint64_t pad;
+    snapmi_error err;
+};
+
+int run_one(snapmi_ctx *ctx, bool compress, const uint8_t *input,
+            size_t input_len, uint8_t *output, size_t output_cap,
+            size_t *written, snapmi_error *err)
+{
+    if (!ctx || !written || (!input && input_len) || (!output && output_cap))
+        return SNAPMI_E_ARGUMENT;
+    *written = 0;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc;
+    // Device output buffer: what the kernels may write.  For compression the
+    // reference demands max_compress_len (checked on the device as well).
+    size_t dev_out = output_cap;
+    if (!compress) {
+        size_t dl = 0;
+        snapmi_error he;
+        if (input_len && snapmi_decompress_len(input, input_len, &dl, &he) ==
+                             SNAPMI_OK &&
+            dl < dev_out)
+            dev_out = dl;
+    } else {
+        size_t need = snapmi_max_compress_len(input_len);
+        if (need && need < dev_out)
+            dev_out = need;
+    }
+    if ((rc = reserve(ctx, ctx->st_in, input_len + 16)) ||
+        (rc = reserve(ctx, ctx->st_out, dev_out + 64)) ||
+        (rc = reserve(ctx, ctx->st_desc, sizeof(OneDesc))))
+        return rc;
+    OneDesc h;
+    memset(&h, 0, sizeof h);
+    h.in_ptr = ctx->st_in.p;
+    h.in_len = input_len;
+    h.out_ptr = ctx->st_out.p;
+    h.out_cap = output_cap; // the caller's capacity is what is validated
+    hipStream_t s = ctx->stream;
+    if (input_len)
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->st_in.p, input, input_len,
+                                    hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->st_desc.p, &h, sizeof h,
+                                hipMemcpyHostToDevice, s));
+    OneDesc *d = (OneDesc *)ctx->st_desc.p;
+    if (compress) {
+        uint64_t hl = input_len;
+        rc = snapmi_compress_batch(ctx, &d->in_ptr, &d->in_len, &hl,
+                                   &d->out_ptr, &d->out_cap, &d->out_len,
+                                   &d->err, 1);
+    } else {
+        rc = snapmi_decompress_batch(ctx, &d->in_ptr, &d->in_len, &d->out_ptr,
+                                     &d->out_cap, &d->out_len, &d->err, 1);
+    }
+    if (rc)
+        return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(&h, ctx->st_desc.p, sizeof h,
+                                hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    if (err)
+        *err = h.err;
+    if (h.err.kind != SNAPMI_OK)
+        return h.err.kind;
+    if (h.out_len > output_cap)
+        return fail_ctx(ctx, SNAPMI_E_DEVICE, "device wrote %llu > cap %zu",
+                        (unsigned long long)h.out_len, output_cap);
+    if (h.out_len)
+        HIP_TRY(ctx, hipMemcpy(output, ctx->st_out.p, h.out_len,
+                               hipMemcpyDeviceToHost));
+    *written = (size_t)h.out_len;
+    return SNAPMI_OK;
+}
+
+} // namespace
+
+int snapmi_raw_compress(snapmi_ctx *ctx, const uint8_t *input,
+                        size_t input_len, uint8_t *output, size_t output_cap,
+                        size_t *written, snapmi_error *err)
+{
+    return run_one(ctx, true, input, input_len, output, output_cap, written,
+                   err);
+}
+
+int snapmi_raw_decompress(snapmi_ctx *ctx, const uint8_t *input,
+                          size_t input_len, uint8_t *output,
+                          size_t output_cap, size_t *written,
+                          snapmi_error *err)
+{
+    return run_one(ctx, false, input, input_len, output, output_cap, written,
+                   err);
+}
+
+// ----------------------------------------------------------------------
+// libsnappy C API (snappy-c.h), as bound by the reference's snappy-cpp
+// crate.  A process-wide context on device SNAPMI_DEVICE (default 0),
+// serialised by a mutex: the C API is stateless and re-entrant.
+// ----------------------------------------------------------------------
+namespace {
+std::mutex g_mu;
+snapmi_ctx *g_ctx = nullptr;
+
+snapmi_ctx *global_ctx()
+{
+    if (!g_ctx) {
+        int dev = 0;
+        if (const char *e = getenv("SNAPMI_DEVICE"))
+            dev = atoi(e);
+        if (snapmi_ctx_create(dev, nullptr, &g_ctx) != SNAPMI_OK)
+            g_ctx = nullptr;
+    }
+    return g_ctx;
+}
+} // namespace
+
+size_t snappy_max_compressed_length(size_t source_length)
+{
+    return 32 + source_length + source_length / 6;
+}
+
+snappy_status snappy_uncompressed_length(const char *compressed,
+                                         size_t compressed_length,
+                                         size_t *result)
+{
+    // libsnappy reads a varint32: at most 5 bytes, value < 2^32.
+    uint64_t v = 0;
+    size_t n = compressed_length < 5 ? compressed_length : 5;
+    size_t h = host_varint((const uint8_t *)compressed, n, &v);
+    if (h == 0 || v > kMaxInput)
+        return SNAPPY_INVALID_INPUT;
+    *result = (size_t)v;
+    return SNAPPY_OK;
+}
+
+snappy_status snappy_compress(const char *input, size_t input_length,
+                              char *compressed, size_t *compressed_length)
+{
+    if (!compressed_length)
+        return SNAPPY_INVALID_INPUT;
+    if (*compressed_length < snappy_max_compressed_length(input_length))
+        return SNAPPY_BUFFER_TOO_SMALL;
+    std::lock_guard<std::mutex> lock(g_mu);
+    snapmi_ctx *ctx = global_ctx();
+    if (!ctx)
+        return (snappy_status)SNAPMI_E_DEVICE; // loud: not a snappy status
+    size_t written = 0;
+    snapmi_error err;
+    int rc = snapmi_raw_compress(ctx, (const uint8_t *)input, input_length,
+                                 (uint8_t *)compressed, *compressed_length,
+                                 &written, &err);
+    if (rc == SNAPMI_BUFFER_TOO_SMALL)
+        return SNAPPY_BUFFER_TOO_SMALL;
+    if (rc >= SNAPMI_E_DEVICE) {
+        fprintf(stderr, "snapmi: snappy_compress: %s\n",
+                snapmi_last_error(ctx));
+        return (snappy_status)rc;
+    }
+    if (rc != SNAPMI_OK)
+        return SNAPPY_INVALID_INPUT;
+    *compressed_length = written;
+    return SNAPPY_OK;
+}
+
+snappy_status snappy_uncompress(const char *compressed,
+                                size_t compressed_length, char *uncompressed,
+                                size_t *uncompressed_length)
+{
+    if (!uncompressed_length)
+        return SNAPPY_INVALID_INPUT;
+    size_t need = 0;
+    if (snappy_uncompressed_length(compressed, compressed_length, &need) !=
+        SNAPPY_OK)
+        return SNAPPY_INVALID_INPUT;
+    if (*uncompressed_length < need)
+        return SNAPPY_BUFFER_TOO_SMALL;
+    std::lock_guard<std::mutex> lock(g_mu);
+    snapmi_ctx *ctx = global_ctx();
+    if (!ctx)
+        return (snappy_status)SNAPMI_E_DEVICE;
+    size_t written = 0;
+    snapmi_error err;
+    int rc = snapmi_raw_decompress(ctx, (const uint8_t *)compressed,
+                                   compressed_length, (uint8_t *)uncompressed,
+                                   *uncompressed_length, &written, &err);
+    if (rc >= SNAPMI_E_DEVICE) {
+        fprintf(stderr, "snapmi: snappy_uncompress: %s\n",
+                snapmi_last_error(ctx));
+        return (snappy_status)rc;
+    }
+    if (rc != SNAPMI_OK)
+        return SNAPPY_INVALID_INPUT;
+    *uncompressed_length = written;
+    return SNAPPY_OK;
+}
+
+snappy_status snappy_validate_compressed_buffer(const char *compressed,
+                                                size_t compressed_length)
+{
+    size_t need = 0;
+    if (snappy_uncompressed_length(compressed, compressed_length, &need) !=
+        SNAPPY_OK)
+        return SNAPPY_INVALID_INPUT;
+    std::vector<char> tmp(need ? need : 1);
+    size_t n = need;
+    return snappy_uncompress(compressed, compressed_length, tmp.data(), &n);
+}
+
+} // extern "C"

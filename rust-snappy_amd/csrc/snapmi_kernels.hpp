@@ -1,0 +1,49 @@
+// snapmi_kernels.hpp -- kernel argument blocks and kernel declarations shared
+// between the .hip translation units and the host API.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "snapmi.h"
+
+namespace snapmi {
+
+// Batch of raw streams to compress.  All pointers are device memory.
+struct CompressArgs {
+    const void *const *in_ptrs; // [n] stream i input
+    const uint64_t *in_lens;    // [n]
+    void *const *out_ptrs;      // [n] stream i output
+    const uint64_t *out_caps;   // [n] or nullptr
+    uint64_t *out_lens;         // [n]
+    snapmi_error *errs;         // [n] or nullptr
+    uint32_t *blk_first;        // [n+1] first global block index of stream i
+    uint32_t *slot_first;       // [n+1] first scratch slot of stream i
+    uint32_t *blk_size;         // [blocks] compressed bytes of each block
+    uint64_t *blk_off;          // [blocks+1] exclusive scan of blk_size
+    uint8_t *scratch;           // [slots * kSlotBytes]
+    uint32_t n_streams;
+    uint32_t host_blocks; // launch geometry computed from the host lengths
+    uint32_t host_slots;
+};
+
+// Batch of raw streams to decompress.
+struct DecompressArgs {
+    const void *const *in_ptrs;
+    const uint64_t *in_lens;
+    void *const *out_ptrs;    // nullptr for "lengths only"
+    const uint64_t *out_caps; // [n] or nullptr when out_ptrs is nullptr
+    uint64_t *out_lens;
+    snapmi_error *errs; // [n] or nullptr
+    uint32_t n_streams;
+};
+
+__global__ void k_plan_compress(CompressArgs a);
+__global__ void k_compress_blocks(CompressArgs a);
+__global__ void k_scan_sizes(CompressArgs a);
+__global__ void k_compact(CompressArgs a);
+
+__global__ void k_decompress_streams(DecompressArgs a);
+__global__ void k_decompress_len(DecompressArgs a);
+
+} // namespace snapmi

@@ -1,0 +1,203 @@
+"""snap::raw -- host-side mirror of the reference's raw block API
+(src/raw.rs:13-14) on top of the C ABI of libsnapmi.so.
+
+  max_compress_len(n)            reference src/compress.rs:42-53
+  decompress_len(buf)            reference src/decompress.rs:30-35
+  Encoder().compress / compress_vec   reference src/compress.rs:99-169
+  Decoder().decompress / decompress_vec  reference src/decompress.rs:75-110
+
+plus the batched, device-resident form (`compress_batch`, `decompress_batch`)
+that takes torch CUDA tensors -- torch is only the owner of device memory.
+All compute happens in the HIP kernels; without a GPU these raise
+`DeviceError`.
+"""
+import ctypes as C
+
+from . import _lib
+from .error import DeviceError, Error
+
+MAX_INPUT_SIZE = 0xFFFFFFFF  # reference src/lib.rs:93
+MAX_BLOCK_SIZE = 1 << 16     # reference src/lib.rs:97
+
+
+def _raise(ctx, rc, err=None):
+    if rc >= 100:
+        msg = None
+        if ctx is not None and ctx._h:
+            msg = _lib.load().snapmi_last_error(ctx._h).decode()
+        raise DeviceError(rc, message=msg or "no usable HIP device")
+    if err is not None and err.kind == rc:
+        raise Error(rc, err.a, err.b, err.c)
+    raise Error(rc)
+
+
+class Context:
+    """snapmi_ctx: one HIP device + stream + device scratch."""
+
+    def __init__(self, device=0, stream=None):
+        self._h = None
+        L = _lib.load()
+        h = C.c_void_p()
+        rc = L.snapmi_ctx_create(int(device), stream, C.byref(h))
+        if rc != 0:
+            raise DeviceError(rc, message=f"snapmi_ctx_create({device}) failed"
+                              ": no usable HIP device (no CPU fallback)")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if self._h:
+            _lib.load().snapmi_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def stream(self):
+        return _lib.load().snapmi_ctx_stream(self._h)
+
+    def synchronize(self):
+        rc = _lib.load().snapmi_ctx_synchronize(self._h)
+        if rc:
+            _raise(self, rc)
+
+    def last_timing(self):
+        t = _lib.SnapmiTiming()
+        rc = _lib.load().snapmi_last_timing(self._h, C.byref(t))
+        if rc:
+            _raise(self, rc)
+        return {"plan_ms": t.plan_ms, "codec_ms": t.codec_ms,
+                "compact_ms": t.compact_ms, "total_ms": t.total_ms,
+                "codec_launches": t.codec_launches}
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+def max_compress_len(input_len):
+    return _lib.load().snapmi_max_compress_len(int(input_len))
+
+
+def decompress_len(data):
+    data = bytes(data)
+    n = C.c_size_t(0)
+    err = _lib.SnapmiError()
+    rc = _lib.load().snapmi_decompress_len(data, len(data), C.byref(n),
+                                           C.byref(err))
+    if rc:
+        _raise(None, rc, err)
+    return n.value
+
+
+class Encoder:
+    """snap::raw::Encoder.  Owns a context (device scratch + stream), like the
+    reference's encoder owns its hash tables; reuse it."""
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx or default_context()
+
+    def compress(self, data, output):
+        """Compress into the writable buffer `output`; returns bytes written.
+        `output` must hold max_compress_len(len(data)) bytes."""
+        data = bytes(data)
+        out = (C.c_char * len(output)).from_buffer(output)
+        n = C.c_size_t(0)
+        err = _lib.SnapmiError()
+        rc = _lib.load().snapmi_raw_compress(self.ctx._h, data, len(data),
+                                             out, len(output), C.byref(n),
+                                             C.byref(err))
+        if rc:
+            _raise(self.ctx, rc, err)
+        return n.value
+
+    def compress_vec(self, data):
+        cap = max_compress_len(len(data))
+        if cap == 0:
+            raise Error(1, len(data), MAX_INPUT_SIZE)
+        buf = bytearray(cap)
+        n = self.compress(data, buf)
+        return bytes(buf[:n])
+
+
+class Decoder:
+    """snap::raw::Decoder (stateless in the reference)."""
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx or default_context()
+
+    def decompress(self, data, output):
+        data = bytes(data)
+        out = (C.c_char * max(len(output), 1)).from_buffer(
+            output if len(output) else bytearray(1))
+        n = C.c_size_t(0)
+        err = _lib.SnapmiError()
+        rc = _lib.load().snapmi_raw_decompress(self.ctx._h, data, len(data),
+                                               out, len(output), C.byref(n),
+                                               C.byref(err))
+        if rc:
+            _raise(self.ctx, rc, err)
+        return n.value
+
+    def decompress_vec(self, data):
+        buf = bytearray(decompress_len(data))
+        n = self.decompress(data, buf)
+        return bytes(buf[:n])
+
+
+# ---------------------------------------------------------------------
+# batched, device-resident (torch tensors own the HBM)
+# ---------------------------------------------------------------------
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def compress_batch(ctx, in_ptrs, in_lens, out_ptrs, out_caps, out_lens,
+                   errs=None, host_in_lens=None):
+    """snapmi_compress_batch.  in_ptrs/out_ptrs: int64 CUDA tensors of device
+    addresses; in_lens/out_caps/out_lens: uint64-as-int64 CUDA tensors;
+    errs: optional uint8 CUDA tensor of 32*n bytes; host_in_lens: optional
+    CPU int64 tensor (or None -> fetched from the device)."""
+    n = in_ptrs.numel()
+    h = None
+    if host_in_lens is not None:
+        h = C.c_void_p(host_in_lens.data_ptr())
+    rc = _lib.load().snapmi_compress_batch(
+        ctx._h, _ptr(in_ptrs), _ptr(in_lens), h, _ptr(out_ptrs),
+        _ptr(out_caps), _ptr(out_lens), _ptr(errs), n)
+    if rc:
+        _raise(ctx, rc)
+
+
+def decompress_batch(ctx, in_ptrs, in_lens, out_ptrs, out_caps, out_lens,
+                     errs=None):
+    n = in_ptrs.numel()
+    rc = _lib.load().snapmi_decompress_batch(
+        ctx._h, _ptr(in_ptrs), _ptr(in_lens), _ptr(out_ptrs), _ptr(out_caps),
+        _ptr(out_lens), _ptr(errs), n)
+    if rc:
+        _raise(ctx, rc)
+
+
+def decompress_len_batch(ctx, in_ptrs, in_lens, out_lens, errs=None):
+    n = in_ptrs.numel()
+    rc = _lib.load().snapmi_decompress_len_batch(
+        ctx._h, _ptr(in_ptrs), _ptr(in_lens), _ptr(out_lens), _ptr(errs), n)
+    if rc:
+        _raise(ctx, rc)

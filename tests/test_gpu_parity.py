@@ -1,0 +1,251 @@
+"""GPU suite: the HIP path, called through the C ABI, against the oracle.
+
+Bit-exact is the bar: compressed bytes equal the oracle's bytes, decompressed
+bytes equal the original, error variants and field values equal the
+reference's (test/tests.rs:345-466)."""
+import hashlib
+import random
+
+import numpy as np
+import pytest
+
+import kats
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_compress(ctx, streams):
+    from rust_snappy_amd import batch
+    src = batch.StreamBatch.from_bytes(streams)
+    dst, lens, errs = batch.compress(ctx, src)
+    out = []
+    for i in range(len(streams)):
+        assert errs[i][0] == 0, (i, errs[i])
+        out.append(dst.stream_bytes(i, lens[i]))
+    return out
+
+
+def gpu_decompress(ctx, comps, caps=None):
+    from rust_snappy_amd import batch
+    src = batch.StreamBatch.from_bytes(comps)
+    dst, lens, errs = batch.decompress(ctx, src, caps)
+    return [dst.stream_bytes(i, lens[i]) for i in range(len(comps))], errs
+
+
+def random_inputs(seed, count):
+    rng = random.Random(seed)
+    out = []
+    for _ in range(count):
+        alpha = rng.choice([1, 2, 3, 4, 16, 256])
+        n = rng.choice([0, 1, 2, 15, 16, 17, 18, 63, 64, 65, 255, 256, 257,
+                        1000, 5000, 65535, 65536, 65537, 70000,
+                        rng.randrange(0, 200000)])
+        out.append(bytes(rng.choices(range(alpha), k=n)))
+    return out
+
+
+def test_compress_corpus_bit_exact(ctx):
+    rnd = O.corpus_round()
+    got = gpu_compress(ctx, [d for _, d in rnd])
+    for (bench_id, data), c in zip(rnd, got):
+        n_in, n_out, sha = kats.CORPUS_SHA256[bench_id]
+        assert len(c) == n_out, bench_id
+        assert hashlib.sha256(c).hexdigest() == sha, bench_id
+
+
+def test_compress_golden_and_kats(ctx):
+    txt = (O.CORPUS / "Mark.Twain-Tom.Sawyer.txt").read_bytes()
+    snp = (O.CORPUS / "Mark.Twain-Tom.Sawyer.txt.rawsnappy").read_bytes()
+    ins = [txt, b"a" * 120, b"", b"\x00", kats.RANDOM1, kats.RANDOM2,
+           kats.RANDOM3, kats.RANDOM4]
+    got = gpu_compress(ctx, ins)
+    assert got[0] == snp                       # test/tests.rs:200-205
+    assert got[1].hex() == "780061fe0100da0100"
+    assert got[2] == b"\x00"
+    for d, c in zip(ins, got):
+        assert c == O.compress(d)
+
+
+def test_compress_structured_bit_exact(ctx):
+    ins = kats.small_copy_inputs() + kats.small_regular_inputs()
+    got = gpu_compress(ctx, ins)
+    for d, c in zip(ins, got):
+        assert c == O.compress(d), len(d)
+
+
+def test_compress_random_bit_exact(ctx):
+    ins = random_inputs(7, 600)
+    got = gpu_compress(ctx, ins)
+    for d, c in zip(ins, got):
+        assert c == O.compress(d), (len(d), d[:16])
+
+
+def test_compress_block_edges(ctx):
+    rng = random.Random(3)
+    base = (O.CORPUS / "alice29.txt").read_bytes()
+    ins = []
+    for n in [1, 14, 15, 16, 17, 18, 31, 32, 33, 255, 256, 257, 511, 512,
+              8191, 8192, 8193, 16383, 16384, 16385, 65535, 65536, 65537,
+              65536 + 16, 65536 + 17, 131071, 131072, 131073]:
+        ins.append(base[:n])
+        ins.append(bytes([rng.randrange(2) for _ in range(n)]))
+        ins.append(b"\x00" * n)
+    got = gpu_compress(ctx, ins)
+    for d, c in zip(ins, got):
+        assert c == O.compress(d), len(d)
+
+
+def test_decompress_corpus_and_kats(ctx):
+    rnd = O.corpus_round()
+    comps = [O.compress(d) for _, d in rnd]
+    comps += [k[1] for k in kats.DECODE_KATS]
+    comps += [(O.CORPUS / "Mark.Twain-Tom.Sawyer.txt.rawsnappy").read_bytes()]
+    want = [d for _, d in rnd] + [k[2] for k in kats.DECODE_KATS]
+    want += [(O.CORPUS / "Mark.Twain-Tom.Sawyer.txt").read_bytes()]
+    got, errs = gpu_decompress(ctx, comps)
+    for i, (w, g) in enumerate(zip(want, got)):
+        assert errs[i][0] == 0, (i, errs[i])
+        assert g == w, i
+
+
+def test_decompress_random_roundtrip(ctx):
+    ins = random_inputs(11, 600) + kats.small_copy_inputs()
+    ins += kats.small_regular_inputs()[::5]
+    comps = [O.compress(d) for d in ins]
+    got, errs = gpu_decompress(ctx, comps)
+    for i, (d, g) in enumerate(zip(ins, got)):
+        assert errs[i][0] == 0, (i, errs[i])
+        assert g == d, (i, len(d))
+
+
+def test_gpu_roundtrip_gpu(ctx):
+    ins = random_inputs(13, 200) + [d for _, d in O.corpus_round()]
+    comps = gpu_compress(ctx, ins)
+    got, errs = gpu_decompress(ctx, comps)
+    for i, (d, g) in enumerate(zip(ins, got)):
+        assert errs[i][0] == 0 and g == d, i
+
+
+def test_decompress_error_kats_exact_fields(ctx):
+    import rust_snappy_amd as R
+    names = R.error.KINDS
+    datas, caps = [], []
+    for name, data, want, bad_header in kats.ERROR_KATS:
+        datas.append(data)
+        caps.append(1024 if bad_header else O.decompress_len(data))
+    got, errs = gpu_decompress(ctx, datas, caps)
+    for (name, data, want, bad_header), e in zip(kats.ERROR_KATS, errs):
+        variant = names[e[0]][0]
+        assert variant == want[0], (name, e)
+        assert tuple(e[1:1 + len(want) - 1]) == tuple(want[1:]), (name, e)
+        # and the oracle agrees field for field
+        try:
+            O.decompress(data, 1024 if bad_header else O.decompress_len(data))
+            raise AssertionError("oracle accepted " + name)
+        except O.SnapError as oe:
+            assert (oe.kind, oe.a, oe.b, oe.c) == e, (name, e)
+
+
+def test_decompress_corrupt_never_faults_and_matches_oracle(ctx):
+    rng = random.Random(5)
+    base = [O.compress(d) for _, d in O.corpus_round()[:4]]
+    base += [(O.CORPUS / n).read_bytes() for n in
+             ("baddata1.snappy", "baddata2.snappy", "baddata3.snappy")]
+    muts = list(base[4:])
+    for c in base[:4]:
+        for _ in range(40):
+            b = bytearray(c)
+            for _ in range(rng.randrange(1, 4)):
+                b[rng.randrange(len(b))] = rng.randrange(256)
+            if rng.random() < 0.3:
+                b = b[:rng.randrange(1, len(b))]
+            muts.append(bytes(b))
+    caps = []
+    for m in muts:
+        try:
+            caps.append(min(O.decompress_len(m), 1 << 22))
+        except O.SnapError:
+            caps.append(1024)
+    got, errs = gpu_decompress(ctx, muts, caps)
+    for m, cap, g, e in zip(muts, caps, got, errs):
+        try:
+            want = O.decompress(m, cap)
+            assert e[0] == 0 and g == want
+        except O.SnapError as oe:
+            assert (oe.kind, oe.a, oe.b, oe.c) == e, (e, oe)
+
+
+def test_buffer_too_small_batch(ctx):
+    from rust_snappy_amd import batch
+    import torch
+    data = [b"hello world, hello world", b"abc"]
+    src = batch.StreamBatch.from_bytes(data)
+    dst = batch.StreamBatch.empty([10, 64])
+    out_lens = torch.zeros(2, dtype=torch.int64, device="cuda")
+    errs = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    import rust_snappy_amd as R
+    R.raw.compress_batch(ctx, src.d_ptrs, src.d_lens, dst.d_ptrs, dst.d_lens,
+                         out_lens, errs, host_in_lens=src.h_lens)
+    ctx.synchronize()
+    e = batch.read_errors(errs)
+    assert e[0] == (2, 10, 32 + 24 + 4, 0)   # BufferTooSmall{given,min}
+    assert e[1][0] == 0
+    assert dst.stream_bytes(1, int(out_lens[1])) == O.compress(b"abc")
+
+
+def test_scalar_mirror_and_snappy_c_api(ctx):
+    import ctypes as C
+    import rust_snappy_amd as R
+    from rust_snappy_amd import _lib
+    enc, dec = R.raw.Encoder(ctx), R.raw.Decoder(ctx)
+    html = (O.CORPUS / "html").read_bytes()
+    c = enc.compress_vec(html)
+    assert c == O.compress(html)
+    assert dec.decompress_vec(c) == html
+    with pytest.raises(R.Error) as ei:
+        dec.decompress_vec(b"\x11\x00a\x01\xFF")
+    assert ei.value == R.Error(9, 255, 1)       # Offset{offset:255,dst_pos:1}
+    with pytest.raises(R.Error) as ei:
+        dec.decompress(b"", bytearray(4))
+    assert ei.value.key() == ("Empty",)
+    with pytest.raises(R.Error) as ei:
+        enc.compress(b"abc", bytearray(10))
+    assert ei.value.key() == ("BufferTooSmall", 10, 35)
+    # the four symbols the reference binds (snappy-cpp/src/lib.rs:66-88)
+    L = _lib.load()
+    cap = C.c_size_t(L.snappy_max_compressed_length(len(html)))
+    out = C.create_string_buffer(cap.value)
+    assert L.snappy_compress(html, len(html), out, C.byref(cap)) == 0
+    assert out.raw[:cap.value] == c
+    n = C.c_size_t(0)
+    assert L.snappy_uncompressed_length(c, len(c), C.byref(n)) == 0
+    back = C.create_string_buffer(n.value)
+    assert L.snappy_uncompress(c, len(c), back, C.byref(n)) == 0
+    assert back.raw[:n.value] == html
+    assert L.snappy_validate_compressed_buffer(c, len(c)) == 0
+    bad = (O.CORPUS / "baddata1.snappy").read_bytes()
+    assert L.snappy_validate_compressed_buffer(bad, len(bad)) == 1
+
+
+def test_tiled_corpus_properties(ctx):
+    """cfg2-shaped batch at reduced tiling: every round's outputs equal round
+    0 (independence of streams) and round 0 equals the oracle."""
+    from rust_snappy_amd import batch
+    rnd = [d for _, d in O.corpus_round()]
+    rounds = 24
+    src = batch.StreamBatch.from_bytes(rnd * rounds)
+    dst, lens, errs = batch.compress(ctx, src)
+    want = [O.compress(d) for d in rnd]
+    for r in range(rounds):
+        for j in range(12):
+            i = r * 12 + j
+            assert errs[i][0] == 0
+            assert dst.stream_bytes(i, lens[i]) == want[j], (r, j)
+    comp = batch.StreamBatch.from_bytes(want * rounds)
+    out, olens, errs = batch.decompress(ctx, comp)
+    for r in range(rounds):
+        for j in range(12):
+            i = r * 12 + j
+            assert errs[i][0] == 0
+            assert out.stream_bytes(i, olens[i]) == rnd[j], (r, j)
