@@ -61,6 +61,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # In a torch process both libsnapmi.so and torch need the HIP runtime
+    # (SONAME libamdhip64.so.7).  torch dlopens its bundled copy by absolute
+    # path, so it must come first: libsnapmi.so then binds to that same copy
+    # by SONAME.  Two HIP/HSA runtimes in one process cannot both open the GPU.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not LIB_PATH.exists():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with "
