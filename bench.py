@@ -130,6 +130,9 @@ def main():
                     help="uncompressed GiB per GPU (BASELINE cfg2: 8)")
     ap.add_argument("--no-cpu", action="store_true",
                     help="skip the cpu_baseline leg")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="experiment builds only: skip the parity gate "
+                         "(the JSON line is then marked invalid)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -191,25 +194,28 @@ def main():
     do_decompress()
     ctx.synchronize()
     cl = comp_lens.cpu().numpy()
+    if args.no_verify:
+        shas, rounds_checked = [], 0
     def kinds(t):
         return np.frombuffer(t.cpu().numpy().tobytes(),
                              dtype="<i4").reshape(n, 8)[:, 0]
     assert (kinds(comp_errs) == 0).all(), "compress reported errors"
-    assert (kinds(back_errs) == 0).all(), "decompress reported errors"
-    for j in range(12):  # round 0 against the reference-pinned sha256 table
+    assert args.no_verify or (kinds(back_errs) == 0).all(), \
+        "decompress reported errors"
+    for j in range(12 if not args.no_verify else 0):  # round 0 vs sha256
         got = comp.stream_bytes(j, cl[j])
         n_in, n_out, sha = shas[j]
         assert len(got) == n_out and hashlib.sha256(got).hexdigest() == sha, \
             f"compressed bytes of stream {j} differ from the oracle's"
-    assert (cl.reshape(rounds, 12) == cl[:12][None, :]).all()
+    assert args.no_verify or (cl.reshape(rounds, 12) == cl[:12][None, :]).all()
     c_stride = int(comp.offsets[12]) if rounds > 1 else 0
-    if rounds > 1:  # every round's compressed slab equals round 0's
+    if rounds > 1 and not args.no_verify:  # every round equals round 0
         per = comp.data[:rounds * c_stride].view(rounds, c_stride)
         for j in range(12):
             o, m = int(comp.offsets[j]), int(cl[j])
             assert bool((per[:, o:o + m] == per[0:1, o:o + m]).all()), j
     per = back.data[:rounds * round_stride].view(rounds, round_stride)
-    for j in range(12):  # every round trips back to the original bytes
+    for j in range(12 if not args.no_verify else 0):  # round trip == input
         o, m = int(r_offs[j]), int(r_lens[j])
         assert bool((per[:, o:o + m] == d_round[None, o:o + m]).all()), \
             f"round trip of stream {j} differs from the input"
@@ -302,6 +308,8 @@ def main():
                           "compact": round(float(np.mean(compact_ms)), 3),
                           "decompress": round(kd * 1e3, 3)},
         }
+        if args.no_verify:
+            line["INVALID"] = "experiment build, parity gate skipped"
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(rnd)
         print(json.dumps(line), flush=True)

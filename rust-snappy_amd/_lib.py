@@ -9,7 +9,9 @@ import os
 from pathlib import Path
 
 PKG_DIR = Path(__file__).resolve().parent
-LIB_PATH = PKG_DIR / "libsnapmi.so"
+# SNAPMI_LIB selects another build of the same ABI (ablation / experiment
+# builds made by `make -C rust-snappy_amd/csrc ablate`); never a CPU codec.
+LIB_PATH = Path(os.environ.get("SNAPMI_LIB", PKG_DIR / "libsnapmi.so"))
 
 
 class SnapmiError(C.Structure):

@@ -38,7 +38,7 @@ struct snapmi_ctx {
     // grow-only device scratch
     DevBuf blk_first, slot_first, blk_size, blk_off, slots;
     // staging for the host-pointer (scalar) entry points
-    DevBuf st_in, st_out, st_desc;
+    DevBuf st_in, st_out, st_desc, st_prof;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timing_valid = false;
     bool timing_is_compress = false;
@@ -290,6 +290,14 @@ int snapmi_compress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     a.n_streams = (uint32_t)n;
     a.host_blocks = (uint32_t)blocks;
     a.host_slots = (uint32_t)slots;
+    a.prof = nullptr;
+#ifdef SNAPMI_PROFILE
+    if ((rc = reserve(ctx, ctx->st_prof, 16 * sizeof(uint64_t))))
+        return rc;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->st_prof.p, 0, 16 * sizeof(uint64_t),
+                                ctx->stream));
+    a.prof = (unsigned long long *)ctx->st_prof.p;
+#endif
 
     hipStream_t s = ctx->stream;
     ctx->timing_valid = false;
@@ -377,6 +385,18 @@ int snapmi_decompress_len_batch(snapmi_ctx *ctx,
     HIP_TRY(ctx, hipGetLastError());
     return SNAPMI_OK;
 }
+
+#ifdef SNAPMI_PROFILE
+// experiment builds only: copy out the 16 cycle counters of the last
+// compress batch (not part of include/snapmi.h)
+int snapmi_debug_profile(snapmi_ctx *ctx, uint64_t *out16)
+{
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out16, ctx->st_prof.p, 16 * sizeof(uint64_t),
+                           hipMemcpyDeviceToHost));
+    return SNAPMI_OK;
+}
+#endif
 
 int snapmi_last_timing(snapmi_ctx *ctx, snapmi_timing *out)
 {

@@ -9,16 +9,26 @@
 //     independent (fresh zeroed table per block, offsets never leave the
 //     block: reference src/compress.rs:148,514-516), so the grid is simply
 //     "all blocks of all streams of the batch";
-//   * the u16 hash table (<=32 KiB) lives in LDS, zeroed with ds_write_b128;
-//     5 blocks are resident per CU (5 x 32 KiB = 160 KiB);
-//   * the sequential state (s, next_emit, d, skip, hashes) is wave-uniform
-//     and sits in SGPRs; hashes are taken from a 256-byte register window of
-//     the input (v_readlane), not from memory;
-//   * a probe is verified AND extended in one step: the 64 lanes load
-//     4 bytes each at candidate+4i and s+4i, one ballot gives the match
-//     length (reference extend_match, src/compress.rs:378-412, is a serial
-//     8-byte loop);
-//   * literals are copied 256 bytes per wave instruction.
+//   * the u16 hash table (<=32 KiB) lives in LDS; 5 blocks are resident per
+//     CU (5 x 32 KiB = 160 KiB);
+//   * the reference probes one position at a time (src/compress.rs:207-245).
+//     Here the 64 lanes evaluate the next 64 positions of the reference's
+//     probe schedule at once.  The sequential table semantics
+//     ("candidate = table[h]; table[h] = s", in probe order) are reproduced
+//     by ONE LDS atomic: ds_mskor_rtn_b32 replaces the 16-bit field and
+//     returns the old dword, and gfx950 applies the lanes of one DS atomic
+//     that hit the same address in ascending lane order (checked on hardware
+//     by tests/hw/lds_atomic_order.hip and at context creation).  Entries
+//     written by lanes past the first hit are rolled back;
+//   * every lane compares 16 bytes at its candidate, so the first hit also
+//     has its match length (reference extend_match, src/compress.rs:378-412);
+//     longer matches continue 256 bytes per wave instruction;
+//   * the step after a copy (reference :290-313: insert s-1, check s, fall
+//     back to probing s+1...) is the same batch with two leading lanes, so
+//     the kernel does one LDS atomic + one candidate gather per emitted copy;
+//   * output bytes are assembled in SGPRs and a 256-byte VGPR stage and leave
+//     as coalesced 256-byte stores, so no store sits on the per-copy
+//     dependency chain; long literals are copied 256 B per instruction.
 //
 // Blocks 0 of every stream are written straight into the caller's output
 // (after the varint); later blocks go to scratch slots and are moved into
@@ -36,115 +46,238 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x, uint32_t shift)
     return (x * 0x1E35A7BDu) >> shift; // reference src/compress.rs:523-525
 }
 
-struct BlockEnc {
-    const uint8_t *src; // block start
-    uint64_t avail;     // readable bytes from src (>= n)
-    uint32_t n;         // block length
-    uint8_t *dst;
-    uint32_t d;
+// Offsets of the reference's probe schedule from the position where the
+// probe loop is (re)entered: skip = 32; step = skip >> 5; skip += step
+// (reference src/compress.rs:204-211).  d[i] is the i-th probed offset.
+struct DeltaTable {
+    uint32_t d[448];
+};
+constexpr DeltaTable make_delta()
+{
+    DeltaTable t{};
+    uint32_t skip = 32, p = 0;
+    for (int i = 0; i < 448; i++) {
+        t.d[i] = p < 0x100000u ? p : 0x100000u;
+        const uint32_t step = skip >> 5;
+        p += step;
+        skip += step;
+    }
+    return t;
+}
+__device__ const DeltaTable kDelta = make_delta();
+
+// 16 unaligned bytes.
+struct B16 {
+    uint32_t w[4];
+};
+__device__ __forceinline__ B16 ld128u(const uint8_t *p)
+{
+    B16 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+
+// number of equal leading bytes of two 16-byte values (0..16)
+__device__ __forceinline__ uint32_t common16(const B16 &a, const B16 &b)
+{
+    const uint64_t d0 = (((uint64_t)(a.w[1] ^ b.w[1])) << 32) | (a.w[0] ^ b.w[0]);
+    const uint64_t d1 = (((uint64_t)(a.w[3] ^ b.w[3])) << 32) | (a.w[2] ^ b.w[2]);
+    // branch-free on purpose: both halves are always needed, so the compiler
+    // keeps the candidate read as one 16-byte load
+    const uint32_t m0 = d0 ? (uint32_t)__builtin_ctzll(d0) >> 3 : 8u;
+    const uint32_t m1 = d1 ? (uint32_t)__builtin_ctzll(d1) >> 3 : 8u;
+    return m0 == 8 ? 8 + m1 : m0;
+}
+
+// ds_mskor_rtn_b32: MEM = (MEM & ~mask) | data, returns the old dword.
+__device__ __forceinline__ uint32_t lds_mskor_rtn(uint32_t byte_addr,
+                                                  uint32_t mask, uint32_t data)
+{
+    uint32_t old;
+    asm volatile("ds_mskor_rtn_b32 %0, %1, %2, %3\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(old)
+                 : "v"(byte_addr), "v"(mask), "v"(data)
+                 : "memory");
+    return old;
+}
+
+// Output assembly: bytes -> 64-bit SGPR accumulator -> dwords of a 256-byte
+// VGPR stage (one v_cndmask per dword) -> one coalesced 256-byte store.
+struct OutStage {
+    uint8_t *dst;     // block output base
+    uint32_t flushed; // bytes already stored
+    uint32_t stage;   // lane i = i-th pending dword
+    uint32_t k;       // complete dwords in stage
+    uint64_t acc;     // pending bytes (low cnt bytes valid, rest zero)
+    uint32_t cnt;     // 0..3
     uint32_t lane;
 
-    // reference emit_literal, src/compress.rs:433-474
-    __device__ __forceinline__ void emit_literal(uint32_t from, uint32_t to)
+    __device__ __forceinline__ void init(uint8_t *d, uint32_t l)
     {
-        const uint32_t len = to - from;
-        const uint32_t n1 = len - 1;
-        uint32_t hdr;
-        if (n1 < 60) {
-            if (lane == 0)
-                dst[d] = (uint8_t)(n1 << 2);
-            hdr = 1;
-        } else if (n1 < 256) {
-            if (lane == 0) {
-                dst[d] = 60 << 2;
-                dst[d + 1] = (uint8_t)n1;
+        dst = d;
+        flushed = 0;
+        stage = 0;
+        k = 0;
+        acc = 0;
+        cnt = 0;
+        lane = l;
+    }
+    __device__ __forceinline__ uint32_t pos() const
+    {
+        return flushed + 4 * k + cnt;
+    }
+    // append the low nb (1..4) bytes of v; bytes above nb must be zero
+    __device__ __forceinline__ void put(uint32_t v, uint32_t nb)
+    {
+        acc |= (uint64_t)v << (8 * cnt);
+        cnt += nb;
+        if (cnt >= 4) {
+            stage = lane == k ? (uint32_t)acc : stage;
+            acc >>= 32;
+            cnt -= 4;
+            k++;
+            if (k == kWave) {
+                st32u(dst + flushed + 4 * lane, stage);
+                flushed += 4 * kWave;
+                k = 0;
             }
-            hdr = 2;
-        } else {
-            if (lane == 0) {
-                dst[d] = 61 << 2;
-                dst[d + 1] = (uint8_t)n1;
-                dst[d + 2] = (uint8_t)(n1 >> 8);
-            }
-            hdr = 3;
         }
-        uint8_t *o = dst + d + hdr;
-        const uint8_t *in = src + from;
+    }
+    // store everything pending; afterwards the stage is empty at `flushed`
+    __device__ __forceinline__ void drain()
+    {
+        if (lane < k)
+            st32u(dst + flushed + 4 * lane, stage);
+        flushed += 4 * k;
+        if (lane < cnt)
+            dst[flushed + lane] = (uint8_t)(acc >> (8 * lane));
+        flushed += cnt;
+        k = 0;
+        cnt = 0;
+        acc = 0;
+    }
+    // reference emit_copy / emit_copy2, src/compress.rs:323-369
+    __device__ __forceinline__ void emit_copy(uint32_t offset, uint32_t len)
+    {
+        const uint32_t off16 = (offset & 0xFFFFu) << 8;
+        while (len >= 68) {
+            put(((63u << 2) | 2u) | off16, 3);
+            len -= 64;
+        }
+        if (len > 64) {
+            put(((59u << 2) | 2u) | off16, 3);
+            len -= 60;
+        }
+        if (len <= 11 && offset <= 2047)
+            put((((offset >> 8) << 5) | ((len - 4) << 2) | 1u) |
+                    ((offset & 0xFFu) << 8),
+                2);
+        else
+            put((((len - 1) << 2) | 2u) | off16, 3);
+    }
+    // literal tag, reference src/compress.rs:436-463
+    __device__ __forceinline__ void emit_literal_tag(uint32_t len)
+    {
+        const uint32_t n1 = len - 1;
+        if (n1 < 60)
+            put(n1 << 2, 1);
+        else if (n1 < 256)
+            put((60u << 2) | (n1 << 8), 2);
+        else
+            put((61u << 2) | (n1 << 8), 3);
+    }
+    // literal of <= 16 bytes whose bytes are in (lo, hi)
+    __device__ __forceinline__ void emit_literal_small(uint64_t lo,
+                                                       uint64_t hi,
+                                                       uint32_t len)
+    {
+        // byte sequence: tag, b0 .. b[len-1]
+        const uint32_t first = len < 3 ? len : 3;
+        const uint32_t m0 = (1u << (8 * first)) - 1; // first <= 3
+        put(((len - 1) << 2) | (((uint32_t)lo & m0) << 8), 1 + first);
+        uint32_t left = len - first;
+        if (left == 0)
+            return;
+        // remaining bytes b3.. : (hi:lo) >> 24
+        uint64_t t0 = (lo >> 24) | (hi << 40); // b3..b10
+        uint64_t t1 = hi >> 24;                // b11..b15
+        for (;;) {
+            const uint32_t nb = left < 4 ? left : 4;
+            const uint32_t mask =
+                nb == 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1);
+            put((uint32_t)t0 & mask, nb);
+            left -= nb;
+            if (left == 0)
+                return;
+            t0 = (t0 >> 32) | (t1 << 32);
+            t1 >>= 32;
+        }
+    }
+    // literal of any length copied memory to memory, 256 B per instruction
+    // (reference emit_literal's memcpy, src/compress.rs:464-473)
+    __device__ __forceinline__ void emit_literal_bulk(const uint8_t *in,
+                                                      uint32_t len)
+    {
+        emit_literal_tag(len);
+        drain();
+        uint8_t *o = dst + flushed;
         for (uint32_t i = 4 * lane; i + 4 <= len; i += 4 * kWave)
             st32u(o + i, ld32u(in + i));
         const uint32_t t = len & ~3u;
         if (lane < (len & 3u))
             o[t + lane] = in[t + lane];
-        d += hdr + len;
-    }
-
-    // reference emit_copy / emit_copy2, src/compress.rs:323-369
-    __device__ __forceinline__ void emit_copy(uint32_t offset, uint32_t len)
-    {
-        while (len >= 68) {
-            if (lane == 0) {
-                dst[d] = (uint8_t)((63u << 2) | 2u);
-                dst[d + 1] = (uint8_t)offset;
-                dst[d + 2] = (uint8_t)(offset >> 8);
-            }
-            d += 3;
-            len -= 64;
-        }
-        if (len > 64) {
-            if (lane == 0) {
-                dst[d] = (uint8_t)((59u << 2) | 2u);
-                dst[d + 1] = (uint8_t)offset;
-                dst[d + 2] = (uint8_t)(offset >> 8);
-            }
-            d += 3;
-            len -= 60;
-        }
-        if (len <= 11 && offset <= 2047) {
-            if (lane == 0) {
-                dst[d] =
-                    (uint8_t)(((offset >> 8) << 5) | ((len - 4) << 2) | 1u);
-                dst[d + 1] = (uint8_t)offset;
-            }
-            d += 2;
-        } else {
-            if (lane == 0) {
-                dst[d] = (uint8_t)(((len - 1) << 2) | 2u);
-                dst[d + 1] = (uint8_t)offset;
-                dst[d + 2] = (uint8_t)(offset >> 8);
-            }
-            d += 3;
-        }
-    }
-
-    // Length of the common prefix of src[cand..] and src[s..], bounded by the
-    // block end (reference: 4-byte verify at src/compress.rs:239-243 /
-    // :305-306 plus extend_match :378-412, fused).  >= 4 means "hit".
-    __device__ __forceinline__ uint32_t match_len(uint32_t cand, uint32_t s)
-    {
-        uint32_t len = 0;
-        const uint32_t room = n - s;
-        for (uint32_t pos = 0;; pos += 4 * kWave) {
-            const uint32_t off = pos + 4 * lane;
-            uint32_t eq = 0;
-            if (off < room) {
-                const uint32_t a = ld32g(src, cand + off, avail);
-                const uint32_t b = ld32g(src, s + off, avail);
-                const uint32_t x = a ^ b;
-                eq = x ? ((uint32_t)__builtin_ctz(x) >> 3) : 4u;
-                const uint32_t lim = room - off;
-                eq = eq < lim ? eq : lim;
-            }
-            const uint64_t stop = __ballot(eq < 4);
-            if (stop == 0) {
-                len += 4 * kWave;
-                continue;
-            }
-            const uint32_t f = (uint32_t)__builtin_ctzll(stop);
-            len += 4 * f + (uint32_t)__builtin_amdgcn_readlane(eq, f);
-            return len;
-        }
+        flushed += len;
     }
 };
+
+// Continue a match past its first 16 bytes: common prefix of src[c..] and
+// src[p..] bounded by the block end n, 256 bytes per wave instruction
+// (reference extend_match, src/compress.rs:378-412).
+__device__ __forceinline__ uint32_t extend_match(const uint8_t *src,
+                                                 uint32_t n, uint32_t c,
+                                                 uint32_t p, uint32_t lane)
+{
+    uint32_t len = 0;
+    const uint32_t room = n - p;
+    for (uint32_t pos = 0;; pos += 4 * kWave) {
+        const uint32_t off = pos + 4 * lane;
+        uint32_t eq = 0;
+        if (off < room) {
+            // dword loads clamped to the block; a clamped load is shifted so
+            // the wanted bytes sit at the bottom (the rest is cut by `lim`)
+            const uint32_t pa = c + off, pb = p + off;
+            const uint32_t ca = pa < n - 4 ? pa : n - 4;
+            const uint32_t cb = pb < n - 4 ? pb : n - 4;
+            const uint32_t va = ld32u(src + ca) >> (8 * (pa - ca));
+            const uint32_t vb = ld32u(src + cb) >> (8 * (pb - cb));
+            const uint32_t x = va ^ vb;
+            eq = x ? ((uint32_t)__builtin_ctz(x) >> 3) : 4u;
+            const uint32_t lim = room - off;
+            eq = eq < lim ? eq : lim;
+        }
+        const uint64_t stop = __ballot(eq < 4);
+        if (stop == 0) {
+            len += 4 * kWave;
+            continue;
+        }
+        const uint32_t f = (uint32_t)__builtin_ctzll(stop);
+        return len + 4 * f + rdlane(eq, f);
+    }
+}
+
+#ifdef SNAPMI_PROFILE
+#define TICK(i)                                                               \
+    do {                                                                      \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");           \
+        const uint64_t _t = __builtin_readcyclecounter();                     \
+        pt[i] += _t - t_last;                                                 \
+        t_last = _t;                                                          \
+    } while (0)
+#else
+#define TICK(i)                                                               \
+    do {                                                                      \
+    } while (0)
+#endif
 
 } // namespace
 
@@ -174,39 +307,38 @@ __global__ __launch_bounds__(64) void k_compress_blocks(CompressArgs a)
     const uint32_t k = b - a.blk_first[st];
     const uint64_t total = a.in_lens[st];
     const uint64_t boff = (uint64_t)k * kMaxBlock;
+    const uint8_t *src = (const uint8_t *)a.in_ptrs[st] + boff;
+    const uint64_t avail = total - boff;
+    const uint32_t n = avail < kMaxBlock ? (uint32_t)avail : kMaxBlock;
 
-    BlockEnc e;
-    e.lane = lane;
-    e.src = (const uint8_t *)a.in_ptrs[st] + boff;
-    e.avail = total - boff;
-    e.n = e.avail < kMaxBlock ? (uint32_t)e.avail : kMaxBlock;
-    e.d = 0;
+    uint8_t *dst;
     if (k == 0) {
         // varint(total) then block 0, in place: reference
         // src/compress.rs:128 and src/bytes.rs:61-70
-        e.dst = (uint8_t *)a.out_ptrs[st];
+        dst = (uint8_t *)a.out_ptrs[st];
         if (lane == 0) {
             uint64_t v = total;
             uint32_t i = 0;
             while (v >= 0x80) {
-                e.dst[i++] = (uint8_t)v | 0x80;
+                dst[i++] = (uint8_t)v | 0x80;
                 v >>= 7;
             }
-            e.dst[i] = (uint8_t)v;
+            dst[i] = (uint8_t)v;
         }
-        e.dst += varint_len(total);
+        dst += varint_len(total);
     } else {
         const uint32_t slot = a.slot_first[st] + k - 1;
         if (slot >= a.host_slots)
             return; // stream rejected by k_plan_compress (E_ARGUMENT)
-        e.dst = a.scratch + (uint64_t)slot * kSlotBytes;
+        dst = a.scratch + (uint64_t)slot * kSlotBytes;
     }
-    const uint32_t n = e.n;
+    OutStage out;
+    out.init(dst, lane);
 
     if (n < kMinNonLiteral) { // reference src/compress.rs:140-146
-        e.emit_literal(0, n);
+        out.emit_literal_bulk(src, n);
         if (lane == 0)
-            a.blk_size[b] = e.d;
+            a.blk_size[b] = out.flushed;
         return;
     }
 
@@ -219,59 +351,130 @@ __global__ __launch_bounds__(64) void k_compress_blocks(CompressArgs a)
     for (uint32_t i = 8 * lane; i < tsize; i += 8 * kWave)
         *(uint4 *)&table[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
+    const uint32_t tbase = (uint32_t)(uintptr_t)&table[0];
 
-    ByteWindow win;
-    win.init(e.src, e.avail);
+    // this lane's slice of the probe schedule
+    const uint32_t c1 = lane >= 2 ? kDelta.d[lane - 2] : 0;
+    const uint32_t c2 = lane >= 1 ? kDelta.d[lane - 1] : 0;
+    const uint32_t c3 = kDelta.d[lane];
 
-    // reference Block::compress, src/compress.rs:195-317
-    uint32_t s = 1, next_emit = 0;
+    // reference Block::compress, src/compress.rs:195-317.
+    //  chain == false: probing started at position 1 (block start);
+    //  chain == true : a copy just ended at s (s < s_limit): lane 0 inserts
+    //                  s-1, lane 1 is the check at s (:290-306), lanes 2..
+    //                  are the probe loop restarted at s+1 (:310-312,:204).
+    //  q: probes of the current run already done by earlier batches.
     const uint32_t s_limit = n - kInputMargin;
-    uint32_t next_hash = hash32(win.get32(1), shift);
+    uint32_t s = 0, next_emit = 0, q = 0;
+    bool chain = false;
+#ifdef SNAPMI_PROFILE
+    uint64_t pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t t_last = __builtin_readcyclecounter();
+    uint64_t n_batches = 0, n_copies = 0;
+#endif
     for (;;) {
-        uint32_t skip = 32, s_next = s, cand, mlen;
-        for (;;) { // probe loop, :207-245
-            s = s_next;
-            const uint32_t step = skip >> 5;
-            s_next = s + step;
-            skip += step;
-            if (s_next > s_limit)
-                goto done;
-            cand = uni(table[next_hash]);
-            if (lane == 0)
-                table[next_hash] = (uint16_t)s;
-            next_hash = hash32(win.get32(s_next), shift);
-            mlen = e.match_len(cand, s);
-            if (mlen >= 4)
-                break;
+#ifdef SNAPMI_PROFILE
+        n_batches++;
+#endif
+        TICK(0);
+        uint32_t p, nextp;
+        bool active = true, probe = true;
+        const uint32_t run0 = chain ? s + 1 : 1; // where the probe run began
+        if (q == 0) {
+            if (!chain) {
+                p = lane ? run0 + c2 : 0;
+                nextp = run0 + c3;
+                active = lane != 0; // lane 0 only fetches bytes 0..15
+            } else {
+                p = lane == 0 ? s - 1 : (lane == 1 ? s : run0 + c1);
+                nextp = lane <= 1 ? 0 : run0 + c2;
+                probe = lane != 0;
+            }
+        } else {
+            p = run0 + kDelta.d[q + lane];
+            nextp = run0 + kDelta.d[q + lane + 1];
         }
-        e.emit_literal(next_emit, s);
-        for (;;) { // copy chain, :258-315
-            const uint32_t base = s;
-            s += mlen;
-            e.emit_copy(base - cand, mlen);
-            next_emit = s;
-            if (s >= s_limit)
-                goto done;
-            const uint64_t x = win.get64(s - 1);
-            if (lane == 0)
-                table[hash32((uint32_t)x, shift)] = (uint16_t)(s - 1);
-            const uint32_t h = hash32((uint32_t)(x >> 8), shift);
-            cand = uni(table[h]);
-            if (lane == 0)
-                table[h] = (uint16_t)s;
-            mlen = e.match_len(cand, s);
-            if (mlen < 4) {
-                next_hash = hash32((uint32_t)(x >> 16), shift);
-                s += 1;
-                break;
+        // reference: "if s_next > s_limit return done()", :212-214
+        const bool valid = active && nextp <= s_limit;
+        const uint32_t pc = p < n - 16 ? p : n - 16;
+        const B16 x = ld128u(src + pc);
+        TICK(1);
+        const uint32_t h = hash32(x.w[0], shift);
+        uint32_t cand = 0;
+        if (valid) {
+            const uint32_t sh = (h & 1) * 16;
+            const uint32_t old = lds_mskor_rtn(tbase + (h >> 1) * 4,
+                                               0xFFFFu << sh, p << sh);
+            cand = (old >> sh) & 0xFFFFu;
+        }
+        TICK(2);
+        const B16 y = ld128u(src + cand);
+        TICK(3);
+        const uint32_t m = common16(x, y);
+        const uint64_t hits = __ballot(valid && probe && m >= 4);
+        if (hits == 0) {
+            if (__ballot(active && !valid) != 0)
+                break; // ran into s_limit: done
+            q += q ? kWave : (chain ? kWave - 2 : kWave - 1);
+            continue;
+        }
+        const uint32_t kh = (uint32_t)__builtin_ctzll(hits);
+        const uint32_t pk = rdlane(p, kh);
+        const uint32_t ck = rdlane(cand, kh);
+        uint32_t len = rdlane(m, kh);
+        // lanes past the hit never ran in the reference: give the table
+        // back the value that was there before the first of them
+        if (valid && lane > kh && cand <= pk)
+            table[h] = (uint16_t)cand;
+
+        TICK(4);
+        // literal next_emit .. pk (reference :250-257)
+        const uint32_t lit = pk - next_emit;
+        if (lit) {
+            if (q == 0 && lit <= 16) {
+                const uint32_t ll = chain ? 1 : 0; // lane holding next_emit
+                const uint64_t lo =
+                    ((uint64_t)rdlane(x.w[1], ll) << 32) |
+                    rdlane(x.w[0], ll);
+                const uint64_t hi =
+                    ((uint64_t)rdlane(x.w[3], ll) << 32) |
+                    rdlane(x.w[2], ll);
+                out.emit_literal_small(lo, hi, lit);
+            } else {
+                out.emit_literal_bulk(src + next_emit, lit);
             }
         }
+        TICK(5);
+        if (len == 16)
+            len += extend_match(src, n, ck + 16, pk + 16, lane);
+        TICK(6);
+        out.emit_copy(pk - ck, len);
+        TICK(7);
+#ifdef SNAPMI_PROFILE
+        n_copies++;
+#endif
+        s = pk + len;
+        next_emit = s;
+        chain = true;
+        q = 0;
+        if (s >= s_limit) // reference :275-277
+            break;
     }
-done:
     if (next_emit < n) // reference done(), src/compress.rs:417-426
-        e.emit_literal(next_emit, n);
+        out.emit_literal_bulk(src + next_emit, n - next_emit);
+    out.drain();
     if (lane == 0)
-        a.blk_size[b] = e.d;
+        a.blk_size[b] = out.flushed;
+#ifdef SNAPMI_PROFILE
+    TICK(8);
+    if (lane == 0 && a.prof) {
+        for (int i = 0; i < 9; i++)
+            atomicAdd(&a.prof[i], (unsigned long long)pt[i]);
+        atomicAdd(&a.prof[10], (unsigned long long)n_batches);
+        atomicAdd(&a.prof[11], (unsigned long long)n_copies);
+        atomicAdd(&a.prof[12], 1ull);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------

@@ -28,6 +28,13 @@ __device__ __forceinline__ uint32_t uni(uint32_t v)
     return __builtin_amdgcn_readfirstlane(v);
 }
 
+// v_readlane_b32 with a wave-uniform lane index.  The builtin returns int:
+// always go through this wrapper so the value is never sign-extended.
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t lane)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane);
+}
+
 __device__ __forceinline__ uint64_t uni64(uint64_t v)
 {
     uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
@@ -120,8 +127,8 @@ struct ByteWindow {
     // dwords idx, idx+1 (idx uniform)
     __device__ __forceinline__ uint64_t pair(uint32_t idx) const
     {
-        uint32_t lo = __builtin_amdgcn_readlane(v, idx);
-        uint32_t hi = __builtin_amdgcn_readlane(v, idx + 1);
+        uint32_t lo = rdlane(v, idx);
+        uint32_t hi = rdlane(v, idx + 1);
         return ((uint64_t)hi << 32) | lo;
     }
     // u32 at uniform stream offset p (bytes past avail read as zero)
@@ -139,9 +146,9 @@ struct ByteWindow {
             refill(p);
         uint32_t o = (uint32_t)(p - base);
         uint32_t i = o >> 2, r = 8 * (o & 3);
-        uint32_t w0 = __builtin_amdgcn_readlane(v, i);
-        uint32_t w1 = __builtin_amdgcn_readlane(v, i + 1);
-        uint32_t w2 = __builtin_amdgcn_readlane(v, i + 2);
+        uint32_t w0 = rdlane(v, i);
+        uint32_t w1 = rdlane(v, i + 1);
+        uint32_t w2 = rdlane(v, i + 2);
         uint64_t lo = ((uint64_t)w1 << 32) | w0;
         if (r == 0)
             return lo;

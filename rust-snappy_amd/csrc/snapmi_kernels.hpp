@@ -25,6 +25,8 @@ struct CompressArgs {
     uint32_t n_streams;
     uint32_t host_blocks; // launch geometry computed from the host lengths
     uint32_t host_slots;
+    // experiment builds (-DSNAPMI_PROFILE) only: 16 u64 cycle counters
+    unsigned long long *prof;
 };
 
 // Batch of raw streams to decompress.
