@@ -26,9 +26,12 @@
 //   * the step after a copy (reference :290-313: insert s-1, check s, fall
 //     back to probing s+1...) is the same batch with two leading lanes, so
 //     the kernel does one LDS atomic + one candidate gather per emitted copy;
-//   * output bytes are assembled in SGPRs and a 256-byte VGPR stage and leave
-//     as coalesced 256-byte stores, so no store sits on the per-copy
-//     dependency chain; long literals are copied 256 B per instruction.
+//   * the match finder only records (literal, copy) tokens in two VGPRs, one
+//     token per lane; every 64 tokens the wave encodes them all at once:
+//     each lane sizes its own elements, a DPP wave scan places them, and the
+//     lanes write their tags and copy their literal bytes in parallel.  No
+//     store (and no vmcnt wait for one) sits on the per-copy dependency
+//     chain; literals longer than 64 bytes are copied 256 B per instruction.
 //
 // Blocks 0 of every stream are written straight into the caller's output
 // (after the varint); later blocks go to scratch slots and are moved into
@@ -101,132 +104,176 @@ __device__ __forceinline__ uint32_t lds_mskor_rtn(uint32_t byte_addr,
     return old;
 }
 
-// Output assembly: bytes -> 64-bit SGPR accumulator -> dwords of a 256-byte
-// VGPR stage (one v_cndmask per dword) -> one coalesced 256-byte store.
-struct OutStage {
-    uint8_t *dst;     // block output base
-    uint32_t flushed; // bytes already stored
-    uint32_t stage;   // lane i = i-th pending dword
-    uint32_t k;       // complete dwords in stage
-    uint64_t acc;     // pending bytes (low cnt bytes valid, rest zero)
-    uint32_t cnt;     // 0..3
+// DPP helpers: wave64 inclusive add-scan without LDS (row_shr within rows of
+// 16, then row_bcast:15 / row_bcast:31 across rows).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_add(uint32_t v)
+{
+    // lanes without a source (bound_ctrl) and rows outside ROW_MASK add 0
+    const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(
+        0, (int)v, CTRL, ROW_MASK, 0xF, false);
+    return v + t;
+}
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
+{
+    v = dpp_add<0x111, 0xF>(v); // row_shr:1
+    v = dpp_add<0x112, 0xF>(v); // row_shr:2
+    v = dpp_add<0x114, 0xF>(v); // row_shr:4
+    v = dpp_add<0x118, 0xF>(v); // row_shr:8
+    v = dpp_add<0x142, 0xA>(v); // row_bcast:15 -> rows 1,3
+    v = dpp_add<0x143, 0xC>(v); // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+// Tokens of the greedy parse, one per lane, encoded 64 at a time.
+//   a = literal length | copy offset << 16
+//   b = copy length    | literal start << 16      (copy length 0: no copy)
+// A token with neither literal nor copy is never recorded, so the pattern
+// "both zero" encodes the one length that does not fit 16 bits: a 65536-byte
+// literal (a whole block without a single match).
+struct TokenSink {
+    const uint8_t *src; // block input
+    uint32_t n;         // block length
+    uint8_t *dst;       // block output
+    uint32_t d;         // bytes written so far
+    uint32_t a, b;      // this lane's token
+    uint32_t t;         // tokens pending (uniform)
     uint32_t lane;
 
-    __device__ __forceinline__ void init(uint8_t *d, uint32_t l)
+    __device__ __forceinline__ void init(const uint8_t *s, uint32_t len,
+                                         uint8_t *o, uint32_t l)
     {
-        dst = d;
-        flushed = 0;
-        stage = 0;
-        k = 0;
-        acc = 0;
-        cnt = 0;
+        src = s;
+        n = len;
+        dst = o;
+        d = 0;
+        a = b = 0;
+        t = 0;
         lane = l;
     }
-    __device__ __forceinline__ uint32_t pos() const
+
+    __device__ __forceinline__ void record(uint32_t lit_start,
+                                           uint32_t lit_len, uint32_t offset,
+                                           uint32_t copy_len)
     {
-        return flushed + 4 * k + cnt;
+        const bool me = lane == t;
+        a = me ? ((lit_len & 0xFFFFu) | (offset << 16)) : a;
+        b = me ? (copy_len | (lit_start << 16)) : b;
+        t++;
+        if (t == kWave)
+            flush();
     }
-    // append the low nb (1..4) bytes of v; bytes above nb must be zero
-    __device__ __forceinline__ void put(uint32_t v, uint32_t nb)
+
+    // Encode the pending tokens: reference emit_literal (src/compress.rs:
+    // 433-474) and emit_copy / emit_copy2 (:323-369), one token per lane.
+    __device__ __forceinline__ void flush()
     {
-        acc |= (uint64_t)v << (8 * cnt);
-        cnt += nb;
-        if (cnt >= 4) {
-            stage = lane == k ? (uint32_t)acc : stage;
-            acc >>= 32;
-            cnt -= 4;
-            k++;
-            if (k == kWave) {
-                st32u(dst + flushed + 4 * lane, stage);
-                flushed += 4 * kWave;
-                k = 0;
+        const bool act = lane < t;
+        const uint32_t C = act ? (b & 0xFFFFu) : 0; // copy length
+        uint32_t L = act ? (a & 0xFFFFu) : 0;       // literal length
+        if (act && L == 0 && C == 0)
+            L = kMaxBlock;
+        const uint32_t O = a >> 16;                 // copy offset
+        const uint32_t P = b >> 16;                 // literal start
+        // literal tag size (:436-463)
+        const uint32_t lt = L == 0 ? 0 : (L <= 60 ? 1 : (L <= 256 ? 2 : 3));
+        // copy pieces (:339-356): n64 x copy2(64), maybe copy2(60), then the
+        // tail as copy1 or copy2
+        const uint32_t n64 = C >= 68 ? (C - 4) >> 6 : 0;
+        const uint32_t rem = C - (n64 << 6);
+        const uint32_t mid = rem > 64 ? 1 : 0;
+        const uint32_t fin_len = rem - 60 * mid;
+        const bool c1 = fin_len <= 11 && O <= 2047;
+        const uint32_t fin = C == 0 ? 0 : (c1 ? 2 : 3);
+        const uint32_t size = lt + L + 3 * (n64 + mid) + fin;
+        const uint32_t incl = wave_inclusive_scan(size);
+        uint8_t *o = dst + d + (incl - size);
+        d += rdlane(incl, kWave - 1);
+        t = 0;
+
+        // literal tag
+        if (lt) {
+            const uint32_t n1 = L - 1;
+            if (lt == 1) {
+                o[0] = (uint8_t)(n1 << 2);
+            } else {
+                o[0] = lt == 2 ? (60u << 2) : (61u << 2);
+                o[1] = (uint8_t)n1;
+                if (lt == 3)
+                    o[2] = (uint8_t)(n1 >> 8);
             }
         }
-    }
-    // store everything pending; afterwards the stage is empty at `flushed`
-    __device__ __forceinline__ void drain()
-    {
-        if (lane < k)
-            st32u(dst + flushed + 4 * lane, stage);
-        flushed += 4 * k;
-        if (lane < cnt)
-            dst[flushed + lane] = (uint8_t)(acc >> (8 * lane));
-        flushed += cnt;
-        k = 0;
-        cnt = 0;
-        acc = 0;
-    }
-    // reference emit_copy / emit_copy2, src/compress.rs:323-369
-    __device__ __forceinline__ void emit_copy(uint32_t offset, uint32_t len)
-    {
-        const uint32_t off16 = (offset & 0xFFFFu) << 8;
-        while (len >= 68) {
-            put(((63u << 2) | 2u) | off16, 3);
-            len -= 64;
+        o += lt;
+        // literal bytes, one lane per literal while they are short
+        const uint8_t *in = src + P;
+        if (L && L <= 16 && P + 16 <= n) {
+            uint32_t w[4];
+            __builtin_memcpy(w, in, 16);
+            if (L >= 4)
+                st32u(o, w[0]);
+            if (L >= 8)
+                st32u(o + 4, w[1]);
+            if (L >= 12)
+                st32u(o + 8, w[2]);
+            if (L >= 16)
+                st32u(o + 12, w[3]);
+            const uint32_t tl = L & 3u, tb = L & ~3u;
+            const uint32_t ti = (L >> 2) & 3u; // dword holding the tail
+            const uint32_t tw =
+                ti == 0 ? w[0] : (ti == 1 ? w[1] : (ti == 2 ? w[2] : w[3]));
+            if (tl >= 1)
+                o[tb] = (uint8_t)tw;
+            if (tl >= 2)
+                o[tb + 1] = (uint8_t)(tw >> 8);
+            if (tl >= 3)
+                o[tb + 2] = (uint8_t)(tw >> 16);
+        } else if (L && L <= 64) {
+            uint32_t i = 0;
+            for (; i + 4 <= L; i += 4)
+                st32u(o + i, ld32u(in + i));
+            for (; i < L; i++)
+                o[i] = in[i];
         }
-        if (len > 64) {
-            put(((59u << 2) | 2u) | off16, 3);
-            len -= 60;
+        // copies
+        uint8_t *oc = o + L;
+        const uint8_t olo = (uint8_t)O, ohi = (uint8_t)(O >> 8);
+        for (uint32_t i = 0; i < n64; i++) {
+            oc[0] = (uint8_t)((63u << 2) | 2u);
+            oc[1] = olo;
+            oc[2] = ohi;
+            oc += 3;
         }
-        if (len <= 11 && offset <= 2047)
-            put((((offset >> 8) << 5) | ((len - 4) << 2) | 1u) |
-                    ((offset & 0xFFu) << 8),
-                2);
-        else
-            put((((len - 1) << 2) | 2u) | off16, 3);
-    }
-    // literal tag, reference src/compress.rs:436-463
-    __device__ __forceinline__ void emit_literal_tag(uint32_t len)
-    {
-        const uint32_t n1 = len - 1;
-        if (n1 < 60)
-            put(n1 << 2, 1);
-        else if (n1 < 256)
-            put((60u << 2) | (n1 << 8), 2);
-        else
-            put((61u << 2) | (n1 << 8), 3);
-    }
-    // literal of <= 16 bytes whose bytes are in (lo, hi)
-    __device__ __forceinline__ void emit_literal_small(uint64_t lo,
-                                                       uint64_t hi,
-                                                       uint32_t len)
-    {
-        // byte sequence: tag, b0 .. b[len-1]
-        const uint32_t first = len < 3 ? len : 3;
-        const uint32_t m0 = (1u << (8 * first)) - 1; // first <= 3
-        put(((len - 1) << 2) | (((uint32_t)lo & m0) << 8), 1 + first);
-        uint32_t left = len - first;
-        if (left == 0)
-            return;
-        // remaining bytes b3.. : (hi:lo) >> 24
-        uint64_t t0 = (lo >> 24) | (hi << 40); // b3..b10
-        uint64_t t1 = hi >> 24;                // b11..b15
-        for (;;) {
-            const uint32_t nb = left < 4 ? left : 4;
-            const uint32_t mask =
-                nb == 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1);
-            put((uint32_t)t0 & mask, nb);
-            left -= nb;
-            if (left == 0)
-                return;
-            t0 = (t0 >> 32) | (t1 << 32);
-            t1 >>= 32;
+        if (mid) {
+            oc[0] = (uint8_t)((59u << 2) | 2u);
+            oc[1] = olo;
+            oc[2] = ohi;
+            oc += 3;
         }
-    }
-    // literal of any length copied memory to memory, 256 B per instruction
-    // (reference emit_literal's memcpy, src/compress.rs:464-473)
-    __device__ __forceinline__ void emit_literal_bulk(const uint8_t *in,
-                                                      uint32_t len)
-    {
-        emit_literal_tag(len);
-        drain();
-        uint8_t *o = dst + flushed;
-        for (uint32_t i = 4 * lane; i + 4 <= len; i += 4 * kWave)
-            st32u(o + i, ld32u(in + i));
-        const uint32_t t = len & ~3u;
-        if (lane < (len & 3u))
-            o[t + lane] = in[t + lane];
-        flushed += len;
+        if (fin == 2) {
+            oc[0] = (uint8_t)(((O >> 8) << 5) | ((fin_len - 4) << 2) | 1u);
+            oc[1] = olo;
+        } else if (fin == 3) {
+            oc[0] = (uint8_t)(((fin_len - 1) << 2) | 2u);
+            oc[1] = olo;
+            oc[2] = ohi;
+        }
+        // long literals: the whole wave copies each, 256 B per instruction
+        uint64_t longs = __ballot(L > 64);
+        while (longs) {
+            const uint32_t j = (uint32_t)__builtin_ctzll(longs);
+            longs &= longs - 1;
+            const uint32_t Lj = rdlane(L, j);
+            const uint32_t Pj = rdlane(P, j);
+            const uint64_t oj = ((uint64_t)rdlane((uint32_t)((uintptr_t)o >> 32), j) << 32) |
+                                rdlane((uint32_t)(uintptr_t)o, j);
+            uint8_t *to = (uint8_t *)(uintptr_t)oj;
+            const uint8_t *from = src + Pj;
+            for (uint32_t i = 4 * lane; i + 4 <= Lj; i += 4 * kWave)
+                st32u(to + i, ld32u(from + i));
+            const uint32_t tb = Lj & ~3u;
+            if (lane < (Lj & 3u))
+                to[tb + lane] = from[tb + lane];
+        }
     }
 };
 
@@ -332,13 +379,14 @@ __global__ __launch_bounds__(64) void k_compress_blocks(CompressArgs a)
             return; // stream rejected by k_plan_compress (E_ARGUMENT)
         dst = a.scratch + (uint64_t)slot * kSlotBytes;
     }
-    OutStage out;
-    out.init(dst, lane);
+    TokenSink out;
+    out.init(src, n, dst, lane);
 
     if (n < kMinNonLiteral) { // reference src/compress.rs:140-146
-        out.emit_literal_bulk(src, n);
+        out.record(0, n, 0, 0);
+        out.flush();
         if (lane == 0)
-            a.blk_size[b] = out.flushed;
+            a.blk_size[b] = out.d;
         return;
     }
 
@@ -354,9 +402,11 @@ __global__ __launch_bounds__(64) void k_compress_blocks(CompressArgs a)
     const uint32_t tbase = (uint32_t)(uintptr_t)&table[0];
 
     // this lane's slice of the probe schedule
-    const uint32_t c1 = lane >= 2 ? kDelta.d[lane - 2] : 0;
     const uint32_t c2 = lane >= 1 ? kDelta.d[lane - 1] : 0;
     const uint32_t c3 = kDelta.d[lane];
+    // after a copy ending at s: lane 0 -> s-1, lane 1 -> s, lane j -> s+1+d[j-2]
+    const uint32_t cB = lane >= 2 ? 1 + kDelta.d[lane - 2] : lane - 1;
+    const uint32_t cBn = lane >= 2 ? 1 + c2 : 0; // offset of the next probe
 
     // reference Block::compress, src/compress.rs:195-317.
     //  chain == false: probing started at position 1 (block start);
@@ -386,8 +436,8 @@ __global__ __launch_bounds__(64) void k_compress_blocks(CompressArgs a)
                 nextp = run0 + c3;
                 active = lane != 0; // lane 0 only fetches bytes 0..15
             } else {
-                p = lane == 0 ? s - 1 : (lane == 1 ? s : run0 + c1);
-                nextp = lane <= 1 ? 0 : run0 + c2;
+                p = s + cB;
+                nextp = s + cBn;
                 probe = lane != 0;
             }
         } else {
@@ -428,27 +478,12 @@ __global__ __launch_bounds__(64) void k_compress_blocks(CompressArgs a)
             table[h] = (uint16_t)cand;
 
         TICK(4);
-        // literal next_emit .. pk (reference :250-257)
-        const uint32_t lit = pk - next_emit;
-        if (lit) {
-            if (q == 0 && lit <= 16) {
-                const uint32_t ll = chain ? 1 : 0; // lane holding next_emit
-                const uint64_t lo =
-                    ((uint64_t)rdlane(x.w[1], ll) << 32) |
-                    rdlane(x.w[0], ll);
-                const uint64_t hi =
-                    ((uint64_t)rdlane(x.w[3], ll) << 32) |
-                    rdlane(x.w[2], ll);
-                out.emit_literal_small(lo, hi, lit);
-            } else {
-                out.emit_literal_bulk(src + next_emit, lit);
-            }
-        }
         TICK(5);
         if (len == 16)
             len += extend_match(src, n, ck + 16, pk + 16, lane);
         TICK(6);
-        out.emit_copy(pk - ck, len);
+        // literal next_emit..pk (reference :250-257) + copy (:272-273)
+        out.record(next_emit, pk - next_emit, pk - ck, len);
         TICK(7);
 #ifdef SNAPMI_PROFILE
         n_copies++;
@@ -461,10 +496,11 @@ __global__ __launch_bounds__(64) void k_compress_blocks(CompressArgs a)
             break;
     }
     if (next_emit < n) // reference done(), src/compress.rs:417-426
-        out.emit_literal_bulk(src + next_emit, n - next_emit);
-    out.drain();
+        out.record(next_emit, n - next_emit, 0, 0);
+    if (out.t)
+        out.flush();
     if (lane == 0)
-        a.blk_size[b] = out.flushed;
+        a.blk_size[b] = out.d;
 #ifdef SNAPMI_PROFILE
     TICK(8);
     if (lane == 0 && a.prof) {
