@@ -343,6 +343,17 @@ int snapmi_decompress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     a.out_lens = d_out_lens;
     a.errs = d_errs;
     a.n_streams = (uint32_t)n;
+    a.prof = nullptr;
+#ifdef SNAPMI_PROFILE
+    {
+        int rc = reserve(ctx, ctx->st_prof, 16 * sizeof(uint64_t));
+        if (rc)
+            return rc;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->st_prof.p, 0, 16 * sizeof(uint64_t),
+                                    ctx->stream));
+        a.prof = (unsigned long long *)ctx->st_prof.p;
+    }
+#endif
     hipStream_t s = ctx->stream;
     ctx->timing_valid = false;
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], s));
@@ -380,6 +391,7 @@ int snapmi_decompress_len_batch(snapmi_ctx *ctx,
     a.out_lens = d_out_lens;
     a.errs = d_errs;
     a.n_streams = (uint32_t)n;
+    a.prof = nullptr;
     hipLaunchKernelGGL(k_decompress_len, dim3((uint32_t)((n + 255) / 256)),
                        dim3(256), 0, ctx->stream, a);
     HIP_TRY(ctx, hipGetLastError());

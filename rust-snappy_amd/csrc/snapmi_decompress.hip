@@ -1,30 +1,46 @@
 // snapmi_decompress.hip -- Snappy raw stream decompressor for gfx950 (CDNA4).
 //
 // Semantics (element order, every bounds check, which error wins and with
-// which field values) follow the reference src/decompress.rs exactly; the
-// execution model is CDNA4's:
+// which field values) follow the reference src/decompress.rs exactly.  The
+// reference walks one element at a time (tag dispatch loop, :130-148); here
+// one wavefront owns one raw stream (a raw stream has no block index --
+// reference src/compress.rs:128-153 -- so the stream is the parallel unit,
+// and a batch supplies thousands of them) and works in three wave-wide steps:
 //
-//   * one wavefront per raw stream (a raw stream has no block index --
-//     reference src/compress.rs:128-153 -- so the stream is the parallel
-//     unit; the batch supplies thousands of them and the dispatcher balances
-//     them dynamically: one 64-thread workgroup per stream);
-//   * the tag stream is parsed out of a 256-byte register window of the
-//     compressed bytes (v_readlane + scalar shifts), so walking from one
-//     element to the next costs no memory round trip;
-//   * the decoder state (s, d, lengths, offsets) is wave-uniform in SGPRs;
-//     the 64 lanes move the bytes: literals 256 B per instruction, copies
-//     (len <= 64) one byte per lane, overlapping copies (offset < len) by
-//     replicating the pattern with a per-lane modulo;
-//   * the output stays in HBM/L2 (no LDS), which keeps 32 waves per CU
-//     resident; a back-reference that may read bytes this wave stored since
-//     its last drain first waits for those stores (workgroup-scope fence =
-//     s_waitcnt vmcnt(0) on gfx950), tracked with one watermark.
+//   1. PARSE  every lane decodes "the element that would start at byte
+//      s+lane" of the compressed stream (tag, length, offset, encoded size);
+//      a scalar walk over those 64 speculative decodes (v_readlane, ~6 SALU
+//      per element) picks the real element starts; a DPP scan of their
+//      output lengths gives every element its output position; all of the
+//      reference's bounds checks are evaluated per element, in parallel.
+//   2. COMPACT  element records move to lanes 0..E-1 (ds_permute).
+//   3. EXPAND  the window's output is produced 64 bytes per pass, one lane
+//      per output byte: the lane finds its element (bit mask + v_mbcnt),
+//      fetches the record (ds_bpermute), and reads its source byte from the
+//      compressed stream (literal), from a 4 KiB LDS ring holding the most
+//      recent output (near back-references, no memory round trip), from
+//      another lane of the same pass (source inside this pass), or from HBM
+//      (far back-references).  Overlapping copies (offset < length) index
+//      the pattern with a per-lane modulo, so they never depend on
+//      themselves.  Stores are 64 contiguous bytes per pass.
+//
+// A far back-reference may only read output whose stores have completed; one
+// watermark tracks that, and the wave drains its stores (workgroup-scope
+// fence = s_waitcnt vmcnt(0) on gfx950) at most once per ring length.
+//
+// Anything irregular -- a failed check, a literal longer than 64 bytes --
+// leaves the wide path: long literals are copied 256 B per instruction, and
+// on the first failed check the stream is finished by the sequential decoder
+// below, which is a direct restatement of the reference's loop and produces
+// the exact snap::Error variant and field values.
 #include "snapmi_device.hpp"
 #include "snapmi_kernels.hpp"
 
 namespace snapmi {
 
 namespace {
+
+constexpr uint32_t kRing = 4096;
 
 // reference bytes::read_varu64, src/bytes.rs:73-90 (returns header length,
 // 0 = invalid).  Executed redundantly by every lane on uniform data.
@@ -68,29 +84,6 @@ __device__ __forceinline__ int read_header(const uint8_t *in, uint64_t in_len,
     return SNAPMI_OK;
 }
 
-} // namespace
-
-// decompress_len, reference src/decompress.rs:30-35: one thread per stream.
-__global__ __launch_bounds__(256) void k_decompress_len(DecompressArgs a)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n_streams)
-        return;
-    const uint64_t in_len = a.in_lens[i];
-    a.out_lens[i] = 0;
-    if (in_len == 0) {
-        set_error(a.errs, i, SNAPMI_OK, 0, 0, 0);
-        return;
-    }
-    uint32_t hdr;
-    uint64_t dlen;
-    if (read_header((const uint8_t *)a.in_ptrs[i], in_len, &hdr, &dlen,
-                    a.errs, i) != SNAPMI_OK)
-        return;
-    a.out_lens[i] = dlen;
-    set_error(a.errs, i, SNAPMI_OK, 0, 0, 0);
-}
-
 #define SNAPMI_FAIL(kind, fa, fb, fc)                                         \
     do {                                                                      \
         if (lane == 0) {                                                      \
@@ -100,45 +93,20 @@ __global__ __launch_bounds__(256) void k_decompress_len(DecompressArgs a)
         return;                                                               \
     } while (0)
 
-// ---------------------------------------------------------------------
-// K2: one wavefront per raw stream.
-// ---------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_decompress_streams(DecompressArgs a)
+// The reference's element-at-a-time loop (src/decompress.rs:130-343), state
+// in SGPRs, bytes moved by the lanes.  Used to finish a stream once the wide
+// path has met something irregular; resumes at (s, d).
+__device__ __forceinline__ void decode_sequential(const DecompressArgs &a,
+                                               uint64_t st, uint32_t lane,
+                                               const uint8_t *src,
+                                               uint64_t src_len, uint8_t *dst,
+                                               uint64_t dst_len, uint64_t s,
+                                               uint64_t d)
 {
-    const uint32_t lane = threadIdx.x;
-    const uint64_t st = blockIdx.x;
-    const uint8_t *in = (const uint8_t *)a.in_ptrs[st];
-    const uint64_t in_len = a.in_lens[st];
-
-    // reference Decoder::decompress, src/decompress.rs:75-95
-    if (in_len == 0)
-        SNAPMI_FAIL(SNAPMI_EMPTY, 0, 0, 0);
-    uint32_t hdr = 0;
-    uint64_t dst_len = 0;
-    {
-        snapmi_error *e = lane == 0 ? a.errs : nullptr;
-        if (read_header(in, in_len, &hdr, &dst_len, e, st) != SNAPMI_OK) {
-            if (lane == 0)
-                a.out_lens[st] = 0;
-            return;
-        }
-    }
-    const uint64_t cap = a.out_caps[st];
-    if (dst_len > cap)
-        SNAPMI_FAIL(SNAPMI_BUFFER_TOO_SMALL, cap, dst_len, 0);
-
-    const uint8_t *src = in + hdr;
-    const uint64_t src_len = in_len - hdr;
-    uint8_t *dst = (uint8_t *)a.out_ptrs[st];
-
     ByteWindow win;
     win.init(src, src_len);
+    uint64_t pend = 0; // dst[pend..d) may still be in flight (stores)
 
-    uint64_t s = 0;      // position in src
-    uint64_t d = 0;      // position in dst
-    uint64_t pend = 0;   // dst[pend..d) may still be in flight (stores)
-
-    // reference Decompress::decompress, src/decompress.rs:130-148
     while (s < src_len) {
         const uint32_t w = win.get32(s); // tag + the 3 bytes after it
         const uint32_t tag = w & 0xFF;
@@ -224,6 +192,378 @@ __global__ __launch_bounds__(64) void k_decompress_streams(DecompressArgs a)
             d = end;
         }
     }
+    if (d != dst_len)
+        SNAPMI_FAIL(SNAPMI_HEADER_MISMATCH, dst_len, d, 0);
+    if (lane == 0) {
+        set_error(a.errs, st, SNAPMI_OK, 0, 0, 0);
+        a.out_lens[st] = dst_len;
+    }
+}
+
+// wave64 DPP helpers (row_shr inside rows of 16, row_bcast across rows)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_get(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK,
+                                                 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_inclusive_add(uint32_t v)
+{
+    v += dpp_get<0x111, 0xF>(v);
+    v += dpp_get<0x112, 0xF>(v);
+    v += dpp_get<0x114, 0xF>(v);
+    v += dpp_get<0x118, 0xF>(v);
+    v += dpp_get<0x142, 0xA>(v);
+    v += dpp_get<0x143, 0xC>(v);
+    return v;
+}
+// OR of v over all lanes (uniform result)
+__device__ __forceinline__ uint32_t wave_or(uint32_t v)
+{
+    v |= dpp_get<0x111, 0xF>(v);
+    v |= dpp_get<0x112, 0xF>(v);
+    v |= dpp_get<0x114, 0xF>(v);
+    v |= dpp_get<0x118, 0xF>(v);
+    v |= dpp_get<0x142, 0xA>(v);
+    v |= dpp_get<0x143, 0xC>(v);
+    return rdlane(v, 63);
+}
+
+__device__ __forceinline__ uint32_t popc_below(uint64_t mask)
+{
+    // number of set bits of `mask` strictly below this lane
+    return __builtin_amdgcn_mbcnt_hi(
+        (uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+}
+
+// 8 bytes at src[pos..] with bytes at or past `avail` read as zero
+__device__ __forceinline__ uint64_t ld64g(const uint8_t *src, uint64_t pos,
+                                          uint64_t avail)
+{
+    if (pos + 8 <= avail) {
+        uint64_t v;
+        __builtin_memcpy(&v, src + pos, 8);
+        return v;
+    }
+    uint64_t v = 0;
+    for (uint32_t k = 0; k < 7; k++)
+        if (pos + k < avail)
+            v |= (uint64_t)src[pos + k] << (8 * k);
+    return v;
+}
+
+#ifdef SNAPMI_PROFILE
+#define TICK(i)                                                               \
+    do {                                                                      \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");           \
+        const uint64_t _t = __builtin_readcyclecounter();                     \
+        pt[i] += _t - t_last;                                                 \
+        t_last = _t;                                                          \
+    } while (0)
+#define COUNT(x) (x)++
+#else
+#define TICK(i)                                                               \
+    do {                                                                      \
+    } while (0)
+#define COUNT(x)                                                              \
+    do {                                                                      \
+    } while (0)
+#endif
+
+} // namespace
+
+// decompress_len, reference src/decompress.rs:30-35: one thread per stream.
+__global__ __launch_bounds__(256) void k_decompress_len(DecompressArgs a)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_streams)
+        return;
+    const uint64_t in_len = a.in_lens[i];
+    a.out_lens[i] = 0;
+    if (in_len == 0) {
+        set_error(a.errs, i, SNAPMI_OK, 0, 0, 0);
+        return;
+    }
+    uint32_t hdr;
+    uint64_t dlen;
+    if (read_header((const uint8_t *)a.in_ptrs[i], in_len, &hdr, &dlen,
+                    a.errs, i) != SNAPMI_OK)
+        return;
+    a.out_lens[i] = dlen;
+    set_error(a.errs, i, SNAPMI_OK, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------
+// K2: one wavefront per raw stream.
+// ---------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_decompress_streams(DecompressArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t ring[kRing];
+
+    const uint32_t lane = threadIdx.x;
+    const uint64_t st = blockIdx.x;
+    const uint8_t *in = (const uint8_t *)a.in_ptrs[st];
+    const uint64_t in_len = a.in_lens[st];
+
+    // reference Decoder::decompress, src/decompress.rs:75-95
+    if (in_len == 0)
+        SNAPMI_FAIL(SNAPMI_EMPTY, 0, 0, 0);
+    uint32_t hdr = 0;
+    uint64_t dst_len = 0;
+    {
+        snapmi_error *e = lane == 0 ? a.errs : nullptr;
+        if (read_header(in, in_len, &hdr, &dst_len, e, st) != SNAPMI_OK) {
+            if (lane == 0)
+                a.out_lens[st] = 0;
+            return;
+        }
+    }
+    // the header came through vector loads: pin it (and everything derived
+    // from it) to SGPRs so the decoder state is scalar
+    hdr = uni(hdr);
+    dst_len = uni64(dst_len);
+    const uint64_t cap = a.out_caps[st];
+    if (dst_len > cap)
+        SNAPMI_FAIL(SNAPMI_BUFFER_TOO_SMALL, cap, dst_len, 0);
+
+    const uint8_t *src = in + hdr;
+    const uint64_t src_len = in_len - hdr;
+    uint8_t *dst = (uint8_t *)a.out_ptrs[st];
+
+    uint64_t s = 0;       // position in src (uniform)
+    uint64_t d = 0;       // position in dst (uniform)
+    uint64_t done_lo = 0; // stores to dst[0..done_lo) have completed
+    uint64_t ring_lo = 0; // ring holds dst[max(ring_lo, d-kRing+64) .. d)
+
+#ifdef SNAPMI_PROFILE
+    uint64_t pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t t_last = __builtin_readcyclecounter();
+    uint64_t n_win = 0, n_pass = 0, n_elem = 0, n_fence = 0, n_res = 0;
+#endif
+    while (s < src_len) {
+        COUNT(n_win);
+        TICK(0);
+        // ---- 1. PARSE: the element that would start at src[s + lane] ----
+        const uint64_t pos = s + lane;
+        const uint64_t w = ld64g(src, pos, src_len);
+        TICK(1);
+        const uint32_t tag = (uint32_t)w & 0xFF;
+        const uint32_t b14 = (uint32_t)(w >> 8); // the 4 bytes after the tag
+        const uint32_t type = tag & 3;
+        const bool is_lit = type == 0;
+        uint32_t olen; // output bytes (capped for the walk when huge)
+        uint32_t key;  // literal: offset of its bytes from s; copy: offset
+        uint32_t enc;  // encoded size in the stream (capped)
+        bool bad = false, lng = false;
+        uint64_t lit_len64 = 0;
+        if (is_lit) {
+            // reference read_literal, src/decompress.rs:161-228
+            const uint32_t n6 = tag >> 2;
+            uint32_t hd = 1;
+            uint64_t L = n6 + 1;
+            if (n6 >= 60) {
+                const uint32_t nb = n6 - 59;
+                bad = pos + 5 > src_len; // :189-198
+                L = (uint64_t)(nb == 4 ? b14 : b14 & ((1u << (8 * nb)) - 1)) +
+                    1;
+                hd = 1 + nb;
+            }
+            bad = bad || (src_len - (pos + hd) < L); // :209-217 (src side)
+            lng = L > 64;
+            lit_len64 = L;
+            olen = lng ? 0 : (uint32_t)L;
+            key = lane + hd;
+            enc = L > 0x0FFFFFFFull ? 0x10000000u : hd + (uint32_t)L;
+        } else {
+            // reference TagEntry::offset / read_copy, :233-250,433-474
+            const uint32_t nb = type == 1 ? 1 : (type == 2 ? 2 : 4);
+            olen = type == 1 ? 4 + ((tag >> 2) & 7) : 1 + (tag >> 2);
+            key = type == 1 ? (((tag >> 5) << 8) | (b14 & 0xFF))
+                            : (type == 2 ? (b14 & 0xFFFF) : b14);
+            bad = pos + 1 + nb > src_len; // CopyRead
+            enc = 1 + nb;
+        }
+        TICK(2);
+        // scalar walk over the speculative decodes: which lanes are starts
+        const uint32_t walk_v = enc | (lng ? 0x80000000u : 0);
+        uint64_t starts = 0;
+        uint32_t cur = 0;
+        bool hit_long = false;
+        while (cur < kWave && s + cur < src_len) {
+            const uint32_t wv = rdlane(walk_v, cur);
+            if (wv >> 31) {
+                hit_long = true;
+                break;
+            }
+            starts |= 1ull << cur;
+            cur += wv;
+        }
+        TICK(3);
+        const bool is_start = (starts >> lane) & 1;
+        // output position of every element: DPP scan of the lengths
+        const uint32_t ol = is_start ? olen : 0;
+        const uint32_t incl = wave_inclusive_add(ol);
+        const uint32_t W = rdlane(incl, kWave - 1); // window output bytes
+        const uint32_t rel = incl - ol;             // this element's offset
+        const uint64_t de = d + rel;
+        // the reference's remaining checks, per element (:209-217,:245-250,
+        // :327-332); de + olen cannot wrap: both are < 2^33
+        if (is_lit)
+            bad = bad || (de + olen > dst_len);
+        else
+            bad = bad || (de <= (uint64_t)key - 1) || (de + olen > dst_len);
+        if (__ballot(is_start && bad) != 0) {
+            // first failed check: the sequential decoder reproduces the
+            // exact snap::Error from this window's start
+            decode_sequential(a, st, lane, src, src_len, dst, dst_len, s, d);
+            return;
+        }
+
+        TICK(4);
+        // ---- 2. COMPACT element records to lanes 0..E-1 ------------------
+        const uint32_t E = (uint32_t)__builtin_popcountll(starts);
+#ifdef SNAPMI_PROFILE
+        n_elem += E;
+#endif
+        const uint32_t below = popc_below(starts);
+        const uint32_t slot = is_start ? below : E + (lane - below);
+        const uint32_t f_rel = (uint32_t)__builtin_amdgcn_ds_permute(
+            (int)(slot << 2), (int)rel);
+        const uint32_t f_info = (uint32_t)__builtin_amdgcn_ds_permute(
+            (int)(slot << 2), (int)(olen | (is_lit ? 0x80000000u : 0)));
+        const uint32_t f_key = (uint32_t)__builtin_amdgcn_ds_permute(
+            (int)(slot << 2), (int)key);
+        const bool is_elem = lane < E;
+
+        TICK(5);
+        // ---- 3. EXPAND: 64 output bytes per pass --------------------------
+        for (uint32_t c0 = 0; c0 < W; c0 += kWave) {
+            COUNT(n_pass);
+            const uint64_t cs = d + c0; // absolute position of lane 0's byte
+            const uint32_t r = c0 + lane;
+            const bool act = r < W;
+            // element of each byte: starts inside this pass as a bit mask
+            const uint32_t erel = f_rel - c0;
+            const bool in_pass = is_elem && erel < kWave;
+            const uint32_t blo =
+                (in_pass && erel < 32) ? (1u << erel) : 0;
+            const uint32_t bhi =
+                (in_pass && erel >= 32) ? (1u << (erel - 32)) : 0;
+            const uint64_t M = ((uint64_t)wave_or(bhi) << 32) | wave_or(blo);
+            const uint32_t nbefore = (uint32_t)__builtin_popcountll(
+                __ballot(is_elem && f_rel < c0));
+            const uint32_t idx = nbefore - 1 + popc_below(M) +
+                                 (uint32_t)((M >> lane) & 1);
+            const uint32_t e_rel = (uint32_t)__builtin_amdgcn_ds_bpermute(
+                (int)(idx << 2), (int)f_rel);
+            const uint32_t e_info = (uint32_t)__builtin_amdgcn_ds_bpermute(
+                (int)(idx << 2), (int)f_info);
+            const uint32_t e_key = (uint32_t)__builtin_amdgcn_ds_bpermute(
+                (int)(idx << 2), (int)f_key);
+            const uint32_t k = r - e_rel; // byte index inside the element
+            const bool lit = (e_info >> 31) != 0;
+            const uint32_t elen = e_info & 0x7FFFFFFFu;
+
+            TICK(6);
+            // where the byte comes from
+            uint32_t val = 0;
+            uint64_t sp = 0;       // copy: absolute source position in dst
+            bool from_pass = false, from_ring = false, from_hbm = false;
+            if (act) {
+                if (lit) {
+                    val = src[s + e_key + k];
+                } else {
+                    const uint32_t off = e_key;
+                    uint32_t back = off; // distance from this byte to source
+                    if (off < elen) {
+                        // overlapping copy: pattern index k mod off (exact
+                        // for k, off < 64), source before the element start
+                        const uint32_t q = (uint32_t)(
+                            ((float)k + 0.5f) *
+                            __builtin_amdgcn_rcpf((float)off));
+                        back = off + q * off;
+                    }
+                    sp = cs + lane - back;
+                    if (back <= lane) {
+                        from_pass = true; // written by this very pass
+                    } else if (sp >= ring_lo && back <= kRing - kWave) {
+                        from_ring = true;
+                    } else {
+                        from_hbm = true;
+                    }
+                }
+            }
+            // far sources must be completed stores
+            if (__ballot(from_hbm && sp >= done_lo) != 0) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                done_lo = cs;
+                COUNT(n_fence);
+            }
+            if (from_ring)
+                val = ring[(uint32_t)sp & (kRing - 1)];
+            if (from_hbm)
+                val = dst[sp];
+            // sources inside this pass: take the value from the lane that
+            // produces it, once that lane has its own value
+            TICK(7);
+            uint64_t ready = __ballot(!from_pass);
+            const uint32_t src_lane = lane - (uint32_t)(cs + lane - sp);
+            while (~ready != 0) {
+                COUNT(n_res);
+                const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute(
+                    (int)(src_lane << 2), (int)val);
+                const bool can = from_pass && ((ready >> src_lane) & 1);
+                val = can ? got : val;
+                from_pass = from_pass && !can;
+                ready = __ballot(!from_pass);
+            }
+            if (act) {
+                dst[cs + lane] = (uint8_t)val;
+                ring[(uint32_t)(cs + lane) & (kRing - 1)] = (uint8_t)val;
+            }
+            TICK(8);
+        }
+        d += W;
+        s += cur;
+
+        // ---- long literal: 256 bytes per instruction ----------------------
+        if (hit_long) {
+            const uint32_t ll = cur; // its lane in this window
+            const uint64_t L =
+                ((uint64_t)rdlane((uint32_t)(lit_len64 >> 32), ll) << 32) |
+                rdlane((uint32_t)lit_len64, ll);
+            const uint32_t hd = rdlane(key, ll) - ll;
+            const bool lbad = __ballot(bad && lane == ll) != 0;
+            if (lbad || dst_len - d < L) {
+                decode_sequential(a, st, lane, src, src_len, dst, dst_len, s,
+                                  d);
+                return;
+            }
+            const uint8_t *from = src + s + hd;
+            uint8_t *to = dst + d;
+            for (uint64_t i = 4 * lane; i + 4 <= L; i += 4 * kWave)
+                st32u(to + i, ld32u(from + i));
+            const uint64_t t = L & ~3ull;
+            if (lane < (L & 3))
+                to[t + lane] = from[t + lane];
+            s += hd + L;
+            d += L;
+            ring_lo = d; // these bytes are not in the ring
+        }
+    }
+#ifdef SNAPMI_PROFILE
+    TICK(9);
+    if (lane == 0 && a.prof) {
+        for (int i = 0; i < 10; i++)
+            atomicAdd(&a.prof[i], (unsigned long long)pt[i]);
+        atomicAdd(&a.prof[10], (unsigned long long)n_win);
+        atomicAdd(&a.prof[11], (unsigned long long)n_pass);
+        atomicAdd(&a.prof[12], (unsigned long long)n_elem);
+        atomicAdd(&a.prof[13], (unsigned long long)n_fence);
+        atomicAdd(&a.prof[14], (unsigned long long)n_res);
+        atomicAdd(&a.prof[15], 1ull);
+    }
+#endif
     if (d != dst_len)
         SNAPMI_FAIL(SNAPMI_HEADER_MISMATCH, dst_len, d, 0);
     if (lane == 0) {

@@ -38,6 +38,8 @@ struct DecompressArgs {
     uint64_t *out_lens;
     snapmi_error *errs; // [n] or nullptr
     uint32_t n_streams;
+    // experiment builds (-DSNAPMI_PROFILE) only: 16 u64 cycle counters
+    unsigned long long *prof;
 };
 
 __global__ void k_plan_compress(CompressArgs a);
