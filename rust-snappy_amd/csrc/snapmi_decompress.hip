@@ -270,6 +270,19 @@ __device__ __forceinline__ uint64_t ld64g(const uint8_t *src, uint64_t pos,
     } while (0)
 #endif
 
+// 8 bytes at src[pos..] for a stream of avail >= 8 readable bytes; bytes at
+// or past `avail` read as zero.  Branch-free: the load address is clamped
+// into the stream and the value shifted back into place.
+__device__ __forceinline__ uint64_t ld64c(const uint8_t *src, uint64_t pos,
+                                          uint64_t avail)
+{
+    const uint64_t pc = pos < avail - 8 ? pos : avail - 8;
+    uint64_t v;
+    __builtin_memcpy(&v, src + pc, 8);
+    const uint64_t sh = pos - pc; // 0 inside the stream
+    return sh < 8 ? v >> (8 * sh) : 0;
+}
+
 } // namespace
 
 // decompress_len, reference src/decompress.rs:30-35: one thread per stream.
@@ -335,108 +348,126 @@ __global__ __launch_bounds__(64) void k_decompress_streams(DecompressArgs a)
     uint64_t done_lo = 0; // stores to dst[0..done_lo) have completed
     uint64_t ring_lo = 0; // ring holds dst[max(ring_lo, d-kRing+64) .. d)
 
+    // streams too short for the 8-byte window loads take the plain loop
+    if (src_len < 8) {
+        decode_sequential(a, st, lane, src, src_len, dst, dst_len, s, d);
+        return;
+    }
 #ifdef SNAPMI_PROFILE
     uint64_t pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t t_last = __builtin_readcyclecounter();
     uint64_t n_win = 0, n_pass = 0, n_elem = 0, n_fence = 0, n_res = 0;
 #endif
+    uint64_t w = ld64c(src, lane, src_len); // 8 bytes at src[s + lane]
     while (s < src_len) {
         COUNT(n_win);
         TICK(0);
         // ---- 1. PARSE: the element that would start at src[s + lane] ----
         const uint64_t pos = s + lane;
-        const uint64_t w = ld64g(src, pos, src_len);
-        TICK(1);
+        const uint32_t limit =
+            src_len - s < kWave ? (uint32_t)(src_len - s) : kWave;
         const uint32_t tag = (uint32_t)w & 0xFF;
         const uint32_t b14 = (uint32_t)(w >> 8); // the 4 bytes after the tag
         const uint32_t type = tag & 3;
         const bool is_lit = type == 0;
-        uint32_t olen; // output bytes (capped for the walk when huge)
-        uint32_t key;  // literal: offset of its bytes from s; copy: offset
-        uint32_t enc;  // encoded size in the stream (capped)
-        bool bad = false, lng = false;
-        uint64_t lit_len64 = 0;
-        if (is_lit) {
-            // reference read_literal, src/decompress.rs:161-228
-            const uint32_t n6 = tag >> 2;
-            uint32_t hd = 1;
-            uint64_t L = n6 + 1;
-            if (n6 >= 60) {
-                const uint32_t nb = n6 - 59;
-                bad = pos + 5 > src_len; // :189-198
-                L = (uint64_t)(nb == 4 ? b14 : b14 & ((1u << (8 * nb)) - 1)) +
-                    1;
-                hd = 1 + nb;
-            }
-            bad = bad || (src_len - (pos + hd) < L); // :209-217 (src side)
-            lng = L > 64;
-            lit_len64 = L;
-            olen = lng ? 0 : (uint32_t)L;
-            key = lane + hd;
-            enc = L > 0x0FFFFFFFull ? 0x10000000u : hd + (uint32_t)L;
-        } else {
-            // reference TagEntry::offset / read_copy, :233-250,433-474
-            const uint32_t nb = type == 1 ? 1 : (type == 2 ? 2 : 4);
-            olen = type == 1 ? 4 + ((tag >> 2) & 7) : 1 + (tag >> 2);
-            key = type == 1 ? (((tag >> 5) << 8) | (b14 & 0xFF))
-                            : (type == 2 ? (b14 & 0xFFFF) : b14);
-            bad = pos + 1 + nb > src_len; // CopyRead
-            enc = 1 + nb;
-        }
+        // literal view (reference read_literal, src/decompress.rs:161-228)
+        const uint32_t n6 = tag >> 2;
+        const uint32_t lnb = n6 >= 60 ? n6 - 59 : 0; // extra length bytes
+        const uint32_t lmask = lnb == 4 ? 0xFFFFFFFFu : ((1u << (8 * lnb)) - 1);
+        const uint64_t L = lnb ? (uint64_t)(b14 & lmask) + 1 : n6 + 1;
+        const uint32_t lhd = 1 + lnb;
+        const bool lbad = (lnb && pos + 5 > src_len) ||      // :189-198
+                          (src_len - (pos + lhd) < L);       // :209-217 (src)
+        // copy view (reference TagEntry::offset / read_copy, :233-250,433-474)
+        const uint32_t cnb = type == 1 ? 1 : (type == 2 ? 2 : 4);
+        const uint32_t clen = type == 1 ? 4 + ((tag >> 2) & 7) : 1 + (tag >> 2);
+        const uint32_t coff = type == 1 ? (((tag >> 5) << 8) | (b14 & 0xFF))
+                                        : (type == 2 ? (b14 & 0xFFFF) : b14);
+        const bool cbad = pos + 1 + cnb > src_len; // CopyRead
+        // merged
+        const bool lng = is_lit && L > 64;
+        const bool in_stream = lane < limit;
+        const bool elem_pos = in_stream && !lng; // may start a window element
+        const uint32_t olen = is_lit ? (lng ? 0 : (uint32_t)L) : clen;
+        const uint32_t enc = is_lit ? (lng ? 0 : lhd + (uint32_t)L) : 1 + cnb;
+        const uint32_t key = is_lit ? lane + lhd : coff;
+        const bool sbad = is_lit ? lbad : cbad;
+        // record gathered per element: enc | olen<<7 | lit<<14 | bad<<15 |
+        // elem_pos<<16 | lng<<17
+        const uint32_t rec = enc | (olen << 7) | (is_lit ? 1u << 14 : 0) |
+                             (sbad ? 1u << 15 : 0) |
+                             (elem_pos ? 1u << 16 : 0) | (lng ? 1u << 17 : 0);
+        TICK(1);
         TICK(2);
-        // scalar walk over the speculative decodes: which lanes are starts
-        const uint32_t walk_v = enc | (lng ? 0x80000000u : 0);
-        uint64_t starts = 0;
-        uint32_t cur = 0;
-        bool hit_long = false;
-        while (cur < kWave && s + cur < src_len) {
-            const uint32_t wv = rdlane(walk_v, cur);
-            if (wv >> 31) {
-                hit_long = true;
-                break;
-            }
-            starts |= 1ull << cur;
-            cur += wv;
+        // Element starts by pointer jumping: x = position (0..63, 64 = out)
+        // of the t-th element in lane t; nk = 2^k-fold successor.
+        uint32_t nk = elem_pos ? (lane + enc < kWave ? lane + enc : kWave)
+                               : kWave;
+        uint32_t x = lane == 0 ? 0 : kWave;
+#pragma unroll
+        for (uint32_t k = 0; k < 6; k++) {
+            const uint32_t sh = 1u << k;
+            const uint32_t xp = (uint32_t)__builtin_amdgcn_ds_bpermute(
+                (int)(((lane - sh) & 63) << 2), (int)x);
+            const uint32_t g = (uint32_t)__builtin_amdgcn_ds_bpermute(
+                (int)((xp & 63) << 2), (int)nk);
+            const uint32_t sq = (uint32_t)__builtin_amdgcn_ds_bpermute(
+                (int)((nk & 63) << 2), (int)nk);
+            if (lane >= sh && lane < 2 * sh)
+                x = xp >= kWave ? kWave : g;
+            nk = nk >= kWave ? kWave : sq;
+            if (k < 5 && rdlane(x, 2 * sh - 1) >= kWave)
+                break; // the chain has left the window
+        }
+        // element t's record, from the lane of its first byte
+        const uint32_t xr = (uint32_t)__builtin_amdgcn_ds_bpermute(
+            (int)((x & 63) << 2), (int)rec);
+        const uint32_t xkey = (uint32_t)__builtin_amdgcn_ds_bpermute(
+            (int)((x & 63) << 2), (int)key);
+        const bool is_elem = x < kWave && ((xr >> 16) & 1);
+        const uint64_t emask = __ballot(is_elem); // a prefix of the lanes
+        const uint32_t E = (uint32_t)__builtin_popcountll(emask);
+        // what follows the last element: end of window, or a long literal
+        const uint32_t xE = E < kWave ? rdlane(x, E) : kWave;
+        const bool hit_long =
+            E < kWave && xE < kWave && ((rdlane(xr, E) >> 17) & 1);
+        uint32_t cur = 0; // bytes of the stream consumed by this window
+        if (E) {
+            const uint32_t lr = rdlane(xr, E - 1);
+            cur = rdlane(x, E - 1) + (lr & 0x7F);
         }
         TICK(3);
-        const bool is_start = (starts >> lane) & 1;
+        const uint32_t e_olen = is_elem ? (xr >> 7) & 0x7F : 0;
+        const bool e_lit = (xr >> 14) & 1;
         // output position of every element: DPP scan of the lengths
-        const uint32_t ol = is_start ? olen : 0;
-        const uint32_t incl = wave_inclusive_add(ol);
+        const uint32_t incl = wave_inclusive_add(e_olen);
         const uint32_t W = rdlane(incl, kWave - 1); // window output bytes
-        const uint32_t rel = incl - ol;             // this element's offset
-        const uint64_t de = d + rel;
+        const uint32_t f_rel = incl - e_olen;       // element's offset in it
+        const uint64_t de = d + f_rel;
         // the reference's remaining checks, per element (:209-217,:245-250,
         // :327-332); de + olen cannot wrap: both are < 2^33
-        if (is_lit)
-            bad = bad || (de + olen > dst_len);
-        else
-            bad = bad || (de <= (uint64_t)key - 1) || (de + olen > dst_len);
-        if (__ballot(is_start && bad) != 0) {
+        bool bad = (xr >> 15) & 1;
+        bad = bad || (de + e_olen > dst_len) ||
+              (!e_lit && de <= (uint64_t)xkey - 1);
+        if (__ballot(is_elem && bad) != 0) {
             // first failed check: the sequential decoder reproduces the
             // exact snap::Error from this window's start
             decode_sequential(a, st, lane, src, src_len, dst, dst_len, s, d);
             return;
         }
-
+        const uint32_t f_info = e_olen | (e_lit ? 0x80000000u : 0);
+        const uint32_t f_key = xkey;
         TICK(4);
-        // ---- 2. COMPACT element records to lanes 0..E-1 ------------------
-        const uint32_t E = (uint32_t)__builtin_popcountll(starts);
 #ifdef SNAPMI_PROFILE
         n_elem += E;
 #endif
-        const uint32_t below = popc_below(starts);
-        const uint32_t slot = is_start ? below : E + (lane - below);
-        const uint32_t f_rel = (uint32_t)__builtin_amdgcn_ds_permute(
-            (int)(slot << 2), (int)rel);
-        const uint32_t f_info = (uint32_t)__builtin_amdgcn_ds_permute(
-            (int)(slot << 2), (int)(olen | (is_lit ? 0x80000000u : 0)));
-        const uint32_t f_key = (uint32_t)__builtin_amdgcn_ds_permute(
-            (int)(slot << 2), (int)key);
-        const bool is_elem = lane < E;
-
+        // next window's bytes: issued now, consumed after the expand
+        uint64_t w_next = 0;
+        if (!hit_long)
+            w_next = ld64c(src, s + cur + lane, src_len);
         TICK(5);
-        // ---- 3. EXPAND: 64 output bytes per pass --------------------------
+
+        // ---- 2. EXPAND: 64 output bytes per pass --------------------------
         for (uint32_t c0 = 0; c0 < W; c0 += kWave) {
             COUNT(n_pass);
             const uint64_t cs = d + c0; // absolute position of lane 0's byte
@@ -445,8 +476,7 @@ __global__ __launch_bounds__(64) void k_decompress_streams(DecompressArgs a)
             // element of each byte: starts inside this pass as a bit mask
             const uint32_t erel = f_rel - c0;
             const bool in_pass = is_elem && erel < kWave;
-            const uint32_t blo =
-                (in_pass && erel < 32) ? (1u << erel) : 0;
+            const uint32_t blo = (in_pass && erel < 32) ? (1u << erel) : 0;
             const uint32_t bhi =
                 (in_pass && erel >= 32) ? (1u << (erel - 32)) : 0;
             const uint64_t M = ((uint64_t)wave_or(bhi) << 32) | wave_or(blo);
@@ -463,56 +493,47 @@ __global__ __launch_bounds__(64) void k_decompress_streams(DecompressArgs a)
             const uint32_t k = r - e_rel; // byte index inside the element
             const bool lit = (e_info >> 31) != 0;
             const uint32_t elen = e_info & 0x7FFFFFFFu;
-
             TICK(6);
+
             // where the byte comes from
-            uint32_t val = 0;
-            uint64_t sp = 0;       // copy: absolute source position in dst
-            bool from_pass = false, from_ring = false, from_hbm = false;
-            if (act) {
-                if (lit) {
-                    val = src[s + e_key + k];
-                } else {
-                    const uint32_t off = e_key;
-                    uint32_t back = off; // distance from this byte to source
-                    if (off < elen) {
-                        // overlapping copy: pattern index k mod off (exact
-                        // for k, off < 64), source before the element start
-                        const uint32_t q = (uint32_t)(
-                            ((float)k + 0.5f) *
-                            __builtin_amdgcn_rcpf((float)off));
-                        back = off + q * off;
-                    }
-                    sp = cs + lane - back;
-                    if (back <= lane) {
-                        from_pass = true; // written by this very pass
-                    } else if (sp >= ring_lo && back <= kRing - kWave) {
-                        from_ring = true;
-                    } else {
-                        from_hbm = true;
-                    }
-                }
+            const uint32_t off = e_key;
+            uint32_t back = off; // copy: distance from this byte to its source
+            if (off < elen) {
+                // overlapping copy: pattern index k mod off (exact for
+                // k, off < 64); the source lies before the element start
+                const uint32_t q = (uint32_t)(
+                    ((float)k + 0.5f) * __builtin_amdgcn_rcpf((float)off));
+                back = off + q * off;
             }
+            const uint64_t sp = cs + lane - back; // copy source position
+            const bool cpy = act && !lit;
+            bool from_pass = cpy && back <= lane; // written by this very pass
+            const bool from_ring = cpy && !from_pass && sp >= ring_lo &&
+                                   back <= kRing - kWave;
+            const bool from_hbm = cpy && !from_pass && !from_ring;
             // far sources must be completed stores
             if (__ballot(from_hbm && sp >= done_lo) != 0) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                 done_lo = cs;
                 COUNT(n_fence);
             }
-            if (from_ring)
-                val = ring[(uint32_t)sp & (kRing - 1)];
-            if (from_hbm)
-                val = dst[sp];
+            // one global load (literal bytes and far sources) and one LDS
+            // read (near sources), both unconditional at safe addresses
+            const uint8_t *gp = (act && lit) ? src + s + e_key + k
+                                             : (from_hbm ? dst + sp : src);
+            const uint32_t vg = *gp;
+            const uint32_t vr = ring[(uint32_t)sp & (kRing - 1)];
+            uint32_t val = from_ring ? vr : vg;
+            TICK(7);
             // sources inside this pass: take the value from the lane that
             // produces it, once that lane has its own value
-            TICK(7);
             uint64_t ready = __ballot(!from_pass);
-            const uint32_t src_lane = lane - (uint32_t)(cs + lane - sp);
+            const uint32_t src_lane = lane - back;
             while (~ready != 0) {
                 COUNT(n_res);
                 const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute(
-                    (int)(src_lane << 2), (int)val);
-                const bool can = from_pass && ((ready >> src_lane) & 1);
+                    (int)((src_lane & 63) << 2), (int)val);
+                const bool can = from_pass && ((ready >> (src_lane & 63)) & 1);
                 val = can ? got : val;
                 from_pass = from_pass && !can;
                 ready = __ballot(!from_pass);
@@ -525,30 +546,33 @@ __global__ __launch_bounds__(64) void k_decompress_streams(DecompressArgs a)
         }
         d += W;
         s += cur;
+        w = w_next;
 
         // ---- long literal: 256 bytes per instruction ----------------------
         if (hit_long) {
-            const uint32_t ll = cur; // its lane in this window
-            const uint64_t L =
-                ((uint64_t)rdlane((uint32_t)(lit_len64 >> 32), ll) << 32) |
-                rdlane((uint32_t)lit_len64, ll);
-            const uint32_t hd = rdlane(key, ll) - ll;
-            const bool lbad = __ballot(bad && lane == ll) != 0;
-            if (lbad || dst_len - d < L) {
+            const uint32_t ll = xE; // its lane in this window
+            const uint64_t Lq = ((uint64_t)rdlane((uint32_t)(L >> 32), ll)
+                                 << 32) |
+                                rdlane((uint32_t)L, ll);
+            const uint32_t hd = rdlane(lhd, ll);
+            const bool qbad = __ballot(lbad && lane == ll) != 0;
+            if (qbad || dst_len - d < Lq) {
                 decode_sequential(a, st, lane, src, src_len, dst, dst_len, s,
                                   d);
                 return;
             }
             const uint8_t *from = src + s + hd;
             uint8_t *to = dst + d;
-            for (uint64_t i = 4 * lane; i + 4 <= L; i += 4 * kWave)
+            for (uint64_t i = 4 * lane; i + 4 <= Lq; i += 4 * kWave)
                 st32u(to + i, ld32u(from + i));
-            const uint64_t t = L & ~3ull;
-            if (lane < (L & 3))
+            const uint64_t t = Lq & ~3ull;
+            if (lane < (Lq & 3))
                 to[t + lane] = from[t + lane];
-            s += hd + L;
-            d += L;
+            s += hd + Lq;
+            d += Lq;
             ring_lo = d; // these bytes are not in the ring
+            if (s < src_len)
+                w = ld64c(src, s + lane, src_len);
         }
     }
 #ifdef SNAPMI_PROFILE
