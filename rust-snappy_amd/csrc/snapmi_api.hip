@@ -38,7 +38,8 @@ struct snapmi_ctx {
     // grow-only device scratch
     DevBuf blk_first, slot_first, blk_size, blk_off, slots;
     // staging for the host-pointer (scalar) entry points
-    DevBuf st_in, st_out, st_desc, st_prof;
+    DevBuf st_in, st_out, st_desc, st_prof, ticket;
+    int num_cus = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timing_valid = false;
     bool timing_is_compress = false;
@@ -140,6 +141,14 @@ int snapmi_ctx_create(int device, void *hip_stream, snapmi_ctx **out)
     if (!ctx)
         return SNAPMI_E_DEVICE;
     ctx->device = device;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+            delete ctx;
+            return SNAPMI_E_DEVICE;
+        }
+        ctx->num_cus = prop.multiProcessorCount;
+    }
     if (hip_stream) {
         ctx->stream = (hipStream_t)hip_stream;
     } else {
@@ -169,7 +178,7 @@ void snapmi_ctx_destroy(snapmi_ctx *ctx)
         (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf *b : {&ctx->blk_first, &ctx->slot_first, &ctx->blk_size,
                       &ctx->blk_off, &ctx->slots, &ctx->st_in, &ctx->st_out,
-                      &ctx->st_desc})
+                      &ctx->st_desc, &ctx->st_prof, &ctx->ticket})
         if (b->p)
             (void)hipFree(b->p);
     for (auto &ev : ctx->ev)
@@ -272,7 +281,8 @@ int snapmi_compress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
         (rc = reserve(ctx, ctx->slot_first, (n + 1) * sizeof(uint32_t))) ||
         (rc = reserve(ctx, ctx->blk_size, (blocks + 1) * sizeof(uint32_t))) ||
         (rc = reserve(ctx, ctx->blk_off, (blocks + 2) * sizeof(uint64_t))) ||
-        (rc = reserve(ctx, ctx->slots, (slots + 1) * (size_t)kSlotBytes)))
+        (rc = reserve(ctx, ctx->slots, (slots + 1) * (size_t)kSlotBytes)) ||
+        (rc = reserve(ctx, ctx->ticket, 64)))
         return rc;
 
     CompressArgs a;
@@ -290,6 +300,7 @@ int snapmi_compress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     a.n_streams = (uint32_t)n;
     a.host_blocks = (uint32_t)blocks;
     a.host_slots = (uint32_t)slots;
+    a.ticket = (uint32_t *)ctx->ticket.p;
     a.prof = nullptr;
 #ifdef SNAPMI_PROFILE
     if ((rc = reserve(ctx, ctx->st_prof, 16 * sizeof(uint64_t))))
@@ -304,9 +315,20 @@ int snapmi_compress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], s));
     hipLaunchKernelGGL(k_plan_compress, dim3(1), dim3(1024), 0, s, a);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], s));
-    if (blocks)
-        hipLaunchKernelGGL(k_compress_blocks, dim3((uint32_t)blocks),
-                           dim3(64), 0, s, a);
+    if (blocks) {
+        // persistent: one 5-wave workgroup per CU (all of its LDS), each
+        // wavefront pulls blocks from the ticket counter
+        const uint64_t want = (blocks + kCompressWaves - 1) / kCompressWaves;
+#ifdef SNAPMI_NOLOOP
+        const uint32_t wgs = (uint32_t)want;
+#else
+        const uint32_t wgs =
+            (uint32_t)(want < (uint64_t)ctx->num_cus ? want : ctx->num_cus);
+#endif
+        HIP_TRY(ctx, hipMemsetAsync(ctx->ticket.p, 0, 64, s));
+        hipLaunchKernelGGL(k_compress_blocks, dim3(wgs),
+                           dim3(kCompressWaves * 64), 0, s, a);
+    }
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], s));
     if (blocks) {
         hipLaunchKernelGGL(k_scan_sizes, dim3(1), dim3(1024), 0, s, a);

@@ -5,12 +5,17 @@
 // and the literal / copy-1 / copy-2 encoders) and must be bit-exact.  How it
 // is computed is CDNA4-native:
 //
-//   * one wavefront (a 64-thread workgroup) owns one 64 KiB block; blocks are
-//     independent (fresh zeroed table per block, offsets never leave the
-//     block: reference src/compress.rs:148,514-516), so the grid is simply
+//   * one wavefront owns one 64 KiB block at a time; blocks are independent
+//     (fresh zeroed table per block, offsets never leave the block:
+//     reference src/compress.rs:148,514-516), so the work list is simply
 //     "all blocks of all streams of the batch";
-//   * the u16 hash table (<=32 KiB) lives in LDS; 5 blocks are resident per
-//     CU (5 x 32 KiB = 160 KiB);
+//   * the u16 hash table (<=32 KiB) lives in LDS.  gfx950 hands out LDS in
+//     1280-byte granules, so five separate 32 KiB workgroups do NOT fit a CU
+//     (5 x 33280 > 163840; measured: tests/hw/lds_occupancy.hip).  The kernel
+//     therefore runs ONE persistent workgroup of five wavefronts per CU that
+//     owns all 160 KiB (5 x 32768 = 128 granules exactly); each wavefront
+//     keeps its own table and pulls 64 KiB blocks from a device-wide ticket
+//     counter until the batch is empty;
 //   * the reference probes one position at a time (src/compress.rs:207-245).
 //     Here the 64 lanes evaluate the next 64 positions of the reference's
 //     probe schedule at once.  The sequential table semantics
@@ -190,6 +195,9 @@ struct TokenSink {
         uint8_t *o = dst + d + (incl - size);
         d += rdlane(incl, kWave - 1);
         t = 0;
+#ifdef SNAPMI_ABLATE_FLUSH
+        return; // experiment: sizes only, nothing written
+#endif
 
         // literal tag
         if (lt) {
@@ -328,18 +336,12 @@ __device__ __forceinline__ uint32_t extend_match(const uint8_t *src,
 
 } // namespace
 
-// ---------------------------------------------------------------------
-// K1: one wavefront per block.
-// ---------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_compress_blocks(CompressArgs a)
+// One 64 KiB block, by one wavefront.
+__device__ __forceinline__ void compress_one_block(
+    const CompressArgs &a, const uint32_t b, const uint32_t lane,
+    uint16_t *const table, const uint32_t tbase, const uint32_t c2,
+    const uint32_t c3, const uint32_t cB, const uint32_t cBn)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t table[kMaxTable];
-
-    const uint32_t lane = threadIdx.x;
-    const uint32_t b = blockIdx.x;
-    const uint32_t nblocks = a.blk_first[a.n_streams];
-    if (b >= nblocks)
-        return;
 
     // stream lookup: blk_first[st] <= b < blk_first[st + 1]
     uint32_t lo = 0, hi = a.n_streams;
@@ -398,15 +400,9 @@ __global__ __launch_bounds__(64) void k_compress_blocks(CompressArgs a)
     }
     for (uint32_t i = 8 * lane; i < tsize; i += 8 * kWave)
         *(uint4 *)&table[i] = make_uint4(0, 0, 0, 0);
-    __syncthreads();
-    const uint32_t tbase = (uint32_t)(uintptr_t)&table[0];
-
-    // this lane's slice of the probe schedule
-    const uint32_t c2 = lane >= 1 ? kDelta.d[lane - 1] : 0;
-    const uint32_t c3 = kDelta.d[lane];
-    // after a copy ending at s: lane 0 -> s-1, lane 1 -> s, lane j -> s+1+d[j-2]
-    const uint32_t cB = lane >= 2 ? 1 + kDelta.d[lane - 2] : lane - 1;
-    const uint32_t cBn = lane >= 2 ? 1 + c2 : 0; // offset of the next probe
+    // LDS operations of one wavefront execute in order: no barrier needed
+    // between the zero fill and the first table access of this wavefront
+    __builtin_amdgcn_wave_barrier();
 
     // reference Block::compress, src/compress.rs:195-317.
     //  chain == false: probing started at position 1 (block start);
@@ -509,6 +505,59 @@ __global__ __launch_bounds__(64) void k_compress_blocks(CompressArgs a)
         atomicAdd(&a.prof[10], (unsigned long long)n_batches);
         atomicAdd(&a.prof[11], (unsigned long long)n_copies);
         atomicAdd(&a.prof[12], 1ull);
+    }
+#endif
+}
+
+// Device-wide block ticket: lane 0 takes it, the wavefront shares it.
+__device__ __noinline__ uint32_t next_ticket(uint32_t *ticket, uint32_t lane)
+{
+    uint32_t tk = 0;
+    if (lane == 0)
+        tk = atomicAdd(ticket, 1u);
+    return uni(tk);
+}
+
+// ---------------------------------------------------------------------
+// K1: persistent workgroups of five wavefronts, one 32 KiB table each.
+// ---------------------------------------------------------------------
+__global__ __launch_bounds__(kCompressWaves * 64) void k_compress_blocks(
+    CompressArgs a)
+{
+    __shared__ __attribute__((aligned(16)))
+    uint16_t tables[kCompressWaves][kMaxTable];
+
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    uint16_t *const table = tables[wave];
+    const uint32_t tbase = (uint32_t)(uintptr_t)&table[0];
+    uint32_t nblocks = a.blk_first[a.n_streams];
+    if (nblocks > a.host_blocks)
+        nblocks = a.host_blocks;
+
+    // this lane's slice of the probe schedule
+    const uint32_t c2 = lane >= 1 ? kDelta.d[lane - 1] : 0;
+    const uint32_t c3 = kDelta.d[lane];
+    // after a copy ending at s: lane 0 -> s-1, lane 1 -> s, lane j -> s+1+d[j-2]
+    const uint32_t cB = lane >= 2 ? 1 + kDelta.d[lane - 2] : lane - 1;
+    const uint32_t cBn = lane >= 2 ? 1 + c2 : 0; // offset of the next probe
+
+#ifdef SNAPMI_NOLOOP
+    {
+        const uint32_t b = blockIdx.x * kCompressWaves + wave;
+        if (b < nblocks)
+            compress_one_block(a, b, lane, table, tbase, c2, c3, cB, cBn);
+    }
+#elif defined(SNAPMI_STRIDE)
+    for (uint32_t b = blockIdx.x * kCompressWaves + wave; b < nblocks;
+         b += gridDim.x * kCompressWaves)
+        compress_one_block(a, b, lane, table, tbase, c2, c3, cB, cBn);
+#else
+    // one ticket per wavefront per block
+    uint32_t b = next_ticket(a.ticket, lane);
+    while (b < nblocks) {
+        compress_one_block(a, b, lane, table, tbase, c2, c3, cB, cBn);
+        b = next_ticket(a.ticket, lane);
     }
 #endif
 }

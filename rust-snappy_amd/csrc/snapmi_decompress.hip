@@ -348,18 +348,17 @@ __global__ __launch_bounds__(64) void k_decompress_streams(DecompressArgs a)
     uint64_t done_lo = 0; // stores to dst[0..done_lo) have completed
     uint64_t ring_lo = 0; // ring holds dst[max(ring_lo, d-kRing+64) .. d)
 
-    // streams too short for the 8-byte window loads take the plain loop
-    if (src_len < 8) {
-        decode_sequential(a, st, lane, src, src_len, dst, dst_len, s, d);
-        return;
-    }
+    // Leaves the wide path: streams too short for the 8-byte window loads,
+    // and the first failed check (the sequential decoder then reproduces the
+    // exact snap::Error, resuming at the current (s, d)).
+    bool irregular = src_len < 8;
 #ifdef SNAPMI_PROFILE
     uint64_t pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t t_last = __builtin_readcyclecounter();
     uint64_t n_win = 0, n_pass = 0, n_elem = 0, n_fence = 0, n_res = 0;
 #endif
-    uint64_t w = ld64c(src, lane, src_len); // 8 bytes at src[s + lane]
-    while (s < src_len) {
+    uint64_t w = irregular ? 0 : ld64c(src, lane, src_len); // src[s+lane..]
+    while (!irregular && s < src_len) {
         COUNT(n_win);
         TICK(0);
         // ---- 1. PARSE: the element that would start at src[s + lane] ----
@@ -450,10 +449,8 @@ __global__ __launch_bounds__(64) void k_decompress_streams(DecompressArgs a)
         bad = bad || (de + e_olen > dst_len) ||
               (!e_lit && de <= (uint64_t)xkey - 1);
         if (__ballot(is_elem && bad) != 0) {
-            // first failed check: the sequential decoder reproduces the
-            // exact snap::Error from this window's start
-            decode_sequential(a, st, lane, src, src_len, dst, dst_len, s, d);
-            return;
+            irregular = true; // first failed check, in this window
+            break;
         }
         const uint32_t f_info = e_olen | (e_lit ? 0x80000000u : 0);
         const uint32_t f_key = xkey;
@@ -557,9 +554,8 @@ __global__ __launch_bounds__(64) void k_decompress_streams(DecompressArgs a)
             const uint32_t hd = rdlane(lhd, ll);
             const bool qbad = __ballot(lbad && lane == ll) != 0;
             if (qbad || dst_len - d < Lq) {
-                decode_sequential(a, st, lane, src, src_len, dst, dst_len, s,
-                                  d);
-                return;
+                irregular = true;
+                break;
             }
             const uint8_t *from = src + s + hd;
             uint8_t *to = dst + d;
@@ -574,6 +570,10 @@ __global__ __launch_bounds__(64) void k_decompress_streams(DecompressArgs a)
             if (s < src_len)
                 w = ld64c(src, s + lane, src_len);
         }
+    }
+    if (irregular) {
+        decode_sequential(a, st, lane, src, src_len, dst, dst_len, s, d);
+        return;
     }
 #ifdef SNAPMI_PROFILE
     TICK(9);

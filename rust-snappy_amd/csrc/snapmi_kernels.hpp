@@ -25,9 +25,14 @@ struct CompressArgs {
     uint32_t n_streams;
     uint32_t host_blocks; // launch geometry computed from the host lengths
     uint32_t host_slots;
+    uint32_t *ticket; // device-wide block ticket counter, zeroed per launch
     // experiment builds (-DSNAPMI_PROFILE) only: 16 u64 cycle counters
     unsigned long long *prof;
 };
+
+// wavefronts (= hash tables) per persistent compress workgroup: 5 x 32 KiB
+// is all of a CU's LDS
+constexpr uint32_t kCompressWaves = 5;
 
 // Batch of raw streams to decompress.
 struct DecompressArgs {
