@@ -78,7 +78,7 @@ __device__ const DeltaTable kDelta = make_delta();
 struct B16 {
     uint32_t w[4];
 };
-__device__ __forceinline__ B16 ld128u(const uint8_t *p)
+__device__ __forceinline__ B16 ld128u(gcptr p)
 {
     B16 v;
     __builtin_memcpy(&v, p, 16);
@@ -137,16 +137,16 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
 // "both zero" encodes the one length that does not fit 16 bits: a 65536-byte
 // literal (a whole block without a single match).
 struct TokenSink {
-    const uint8_t *src; // block input
+    gcptr src;          // block input
     uint32_t n;         // block length
-    uint8_t *dst;       // block output
+    gptr dst;           // block output
     uint32_t d;         // bytes written so far
     uint32_t a, b;      // this lane's token
     uint32_t t;         // tokens pending (uniform)
     uint32_t lane;
 
-    __device__ __forceinline__ void init(const uint8_t *s, uint32_t len,
-                                         uint8_t *o, uint32_t l)
+    __device__ __forceinline__ void init(gcptr s, uint32_t len, gptr o,
+                                         uint32_t l)
     {
         src = s;
         n = len;
@@ -192,7 +192,7 @@ struct TokenSink {
         const uint32_t fin = C == 0 ? 0 : (c1 ? 2 : 3);
         const uint32_t size = lt + L + 3 * (n64 + mid) + fin;
         const uint32_t incl = wave_inclusive_scan(size);
-        uint8_t *o = dst + d + (incl - size);
+        gptr o = dst + d + (incl - size);
         d += rdlane(incl, kWave - 1);
         t = 0;
 #ifdef SNAPMI_ABLATE_FLUSH
@@ -213,7 +213,7 @@ struct TokenSink {
         }
         o += lt;
         // literal bytes, one lane per literal while they are short
-        const uint8_t *in = src + P;
+        gcptr in = src + P;
         if (L && L <= 16 && P + 16 <= n) {
             uint32_t w[4];
             __builtin_memcpy(w, in, 16);
@@ -243,7 +243,7 @@ struct TokenSink {
                 o[i] = in[i];
         }
         // copies
-        uint8_t *oc = o + L;
+        gptr oc = o + L;
         const uint8_t olo = (uint8_t)O, ohi = (uint8_t)(O >> 8);
         for (uint32_t i = 0; i < n64; i++) {
             oc[0] = (uint8_t)((63u << 2) | 2u);
@@ -274,8 +274,8 @@ struct TokenSink {
             const uint32_t Pj = rdlane(P, j);
             const uint64_t oj = ((uint64_t)rdlane((uint32_t)((uintptr_t)o >> 32), j) << 32) |
                                 rdlane((uint32_t)(uintptr_t)o, j);
-            uint8_t *to = (uint8_t *)(uintptr_t)oj;
-            const uint8_t *from = src + Pj;
+            gptr to = (gptr)(uintptr_t)oj;
+            gcptr from = src + Pj;
             for (uint32_t i = 4 * lane; i + 4 <= Lj; i += 4 * kWave)
                 st32u(to + i, ld32u(from + i));
             const uint32_t tb = Lj & ~3u;
@@ -288,9 +288,9 @@ struct TokenSink {
 // Continue a match past its first 16 bytes: common prefix of src[c..] and
 // src[p..] bounded by the block end n, 256 bytes per wave instruction
 // (reference extend_match, src/compress.rs:378-412).
-__device__ __forceinline__ uint32_t extend_match(const uint8_t *src,
-                                                 uint32_t n, uint32_t c,
-                                                 uint32_t p, uint32_t lane)
+__device__ __forceinline__ uint32_t extend_match(gcptr src, uint32_t n,
+                                                 uint32_t c, uint32_t p,
+                                                 uint32_t lane)
 {
     uint32_t len = 0;
     const uint32_t room = n - p;
@@ -339,7 +339,7 @@ __device__ __forceinline__ uint32_t extend_match(const uint8_t *src,
 // One 64 KiB block, by one wavefront.
 __device__ __forceinline__ void compress_one_block(
     const CompressArgs &a, const uint32_t b, const uint32_t lane,
-    uint16_t *const table, const uint32_t tbase, const uint32_t c2,
+    const lptr16 table, const uint32_t tbase, const uint32_t c2,
     const uint32_t c3, const uint32_t cB, const uint32_t cBn)
 {
 
@@ -356,15 +356,15 @@ __device__ __forceinline__ void compress_one_block(
     const uint32_t k = b - a.blk_first[st];
     const uint64_t total = a.in_lens[st];
     const uint64_t boff = (uint64_t)k * kMaxBlock;
-    const uint8_t *src = (const uint8_t *)a.in_ptrs[st] + boff;
+    gcptr src = (gcptr)a.in_ptrs[st] + boff;
     const uint64_t avail = total - boff;
     const uint32_t n = avail < kMaxBlock ? (uint32_t)avail : kMaxBlock;
 
-    uint8_t *dst;
+    gptr dst;
     if (k == 0) {
         // varint(total) then block 0, in place: reference
         // src/compress.rs:128 and src/bytes.rs:61-70
-        dst = (uint8_t *)a.out_ptrs[st];
+        dst = (gptr)a.out_ptrs[st];
         if (lane == 0) {
             uint64_t v = total;
             uint32_t i = 0;
@@ -379,7 +379,7 @@ __device__ __forceinline__ void compress_one_block(
         const uint32_t slot = a.slot_first[st] + k - 1;
         if (slot >= a.host_slots)
             return; // stream rejected by k_plan_compress (E_ARGUMENT)
-        dst = a.scratch + (uint64_t)slot * kSlotBytes;
+        dst = (gptr)a.scratch + (uint64_t)slot * kSlotBytes;
     }
     TokenSink out;
     out.init(src, n, dst, lane);
@@ -399,7 +399,8 @@ __device__ __forceinline__ void compress_one_block(
         tsize *= 2;
     }
     for (uint32_t i = 8 * lane; i < tsize; i += 8 * kWave)
-        *(uint4 *)&table[i] = make_uint4(0, 0, 0, 0);
+        *(__attribute__((address_space(3))) u32x4 *)&table[i] =
+            (u32x4){0, 0, 0, 0};
     // LDS operations of one wavefront execute in order: no barrier needed
     // between the zero fill and the first table access of this wavefront
     __builtin_amdgcn_wave_barrier();
@@ -529,8 +530,8 @@ __global__ __launch_bounds__(kCompressWaves * 64) void k_compress_blocks(
 
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = uni(threadIdx.x >> 6);
-    uint16_t *const table = tables[wave];
-    const uint32_t tbase = (uint32_t)(uintptr_t)&table[0];
+    const lptr16 table = (lptr16)&tables[wave][0];
+    const uint32_t tbase = (uint32_t)(uintptr_t)table; // LDS byte offset
     uint32_t nblocks = a.blk_first[a.n_streams];
     if (nblocks > a.host_blocks)
         nblocks = a.host_blocks;
@@ -616,7 +617,7 @@ __global__ __launch_bounds__(1024) void k_plan_compress(CompressArgs a)
                 set_error(a.errs, i, SNAPMI_BUFFER_TOO_SMALL, a.out_caps[i],
                           need, 0);
             } else if (len == 0) { // src/compress.rs:120-125
-                ((uint8_t *)a.out_ptrs[i])[0] = 0;
+                ((gptr)a.out_ptrs[i])[0] = 0;
                 a.out_lens[i] = 1;
                 set_error(a.errs, i, SNAPMI_OK, 0, 0, 0);
             } else {
@@ -718,10 +719,9 @@ __global__ __launch_bounds__(256) void k_compact(CompressArgs a)
             a.out_lens[st] = vl + (a.blk_off[first + nb] - a.blk_off[first]);
         return;
     }
-    const uint8_t *from =
-        a.scratch + (uint64_t)(a.slot_first[st] + k - 1) * kSlotBytes;
-    uint8_t *to =
-        (uint8_t *)a.out_ptrs[st] + vl + (a.blk_off[b] - a.blk_off[first]);
+    gcptr from = (gcptr)a.scratch +
+                 (uint64_t)(a.slot_first[st] + k - 1) * kSlotBytes;
+    gptr to = (gptr)a.out_ptrs[st] + vl + (a.blk_off[b] - a.blk_off[first]);
     const uint32_t size = a.blk_size[b];
     // align the destination to 16 bytes, then 16-byte stores fed by
     // unaligned 16-byte loads (the slot is 16-aligned, `to` is arbitrary).
@@ -732,9 +732,9 @@ __global__ __launch_bounds__(256) void k_compact(CompressArgs a)
         to[threadIdx.x] = from[threadIdx.x];
     const uint32_t body = (size - head) & ~15u;
     for (uint32_t i = 16 * threadIdx.x; i < body; i += 16 * blockDim.x) {
-        uint4 v;
+        u32x4 v;
         __builtin_memcpy(&v, from + head + i, 16);
-        *(uint4 *)(to + head + i) = v;
+        *(__attribute__((address_space(1))) u32x4 *)(to + head + i) = v;
     }
     const uint32_t tail = size - head - body;
     if (threadIdx.x < tail)

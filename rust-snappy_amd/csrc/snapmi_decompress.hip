@@ -44,7 +44,7 @@ constexpr uint32_t kRing = 4096;
 
 // reference bytes::read_varu64, src/bytes.rs:73-90 (returns header length,
 // 0 = invalid).  Executed redundantly by every lane on uniform data.
-__device__ __forceinline__ uint32_t read_varint(const uint8_t *p, uint64_t n,
+__device__ __forceinline__ uint32_t read_varint(gcptr p, uint64_t n,
                                                 uint64_t *value)
 {
     uint64_t acc = 0;
@@ -65,7 +65,7 @@ __device__ __forceinline__ uint32_t read_varint(const uint8_t *p, uint64_t n,
 
 // Header::read + the checks of Decoder::decompress, reference
 // src/decompress.rs:75-95,362-374.  Returns kind; on success fills hdr/dlen.
-__device__ __forceinline__ int read_header(const uint8_t *in, uint64_t in_len,
+__device__ __forceinline__ int read_header(gcptr in, uint64_t in_len,
                                            uint32_t *hdr, uint64_t *dlen,
                                            snapmi_error *errs, uint64_t i)
 {
@@ -98,8 +98,8 @@ __device__ __forceinline__ int read_header(const uint8_t *in, uint64_t in_len,
 // path has met something irregular; resumes at (s, d).
 __device__ __forceinline__ void decode_sequential(const DecompressArgs &a,
                                                uint64_t st, uint32_t lane,
-                                               const uint8_t *src,
-                                               uint64_t src_len, uint8_t *dst,
+                                               gcptr src,
+                                               uint64_t src_len, gptr dst,
                                                uint64_t dst_len, uint64_t s,
                                                uint64_t d)
 {
@@ -126,8 +126,8 @@ __device__ __forceinline__ void decode_sequential(const DecompressArgs &a,
             }
             if (src_len - s < len || dst_len - d < len)
                 SNAPMI_FAIL(SNAPMI_LITERAL, len, src_len - s, dst_len - d);
-            const uint8_t *from = src + s;
-            uint8_t *to = dst + d;
+            gcptr from = src + s;
+            gptr to = dst + d;
             for (uint64_t i = 4 * lane; i + 4 <= len; i += 4 * kWave)
                 st32u(to + i, ld32u(from + i));
             const uint64_t t = len & ~3ull;
@@ -237,7 +237,7 @@ __device__ __forceinline__ uint32_t popc_below(uint64_t mask)
 }
 
 // 8 bytes at src[pos..] with bytes at or past `avail` read as zero
-__device__ __forceinline__ uint64_t ld64g(const uint8_t *src, uint64_t pos,
+__device__ __forceinline__ uint64_t ld64g(gcptr src, uint64_t pos,
                                           uint64_t avail)
 {
     if (pos + 8 <= avail) {
@@ -273,7 +273,7 @@ __device__ __forceinline__ uint64_t ld64g(const uint8_t *src, uint64_t pos,
 // 8 bytes at src[pos..] for a stream of avail >= 8 readable bytes; bytes at
 // or past `avail` read as zero.  Branch-free: the load address is clamped
 // into the stream and the value shifted back into place.
-__device__ __forceinline__ uint64_t ld64c(const uint8_t *src, uint64_t pos,
+__device__ __forceinline__ uint64_t ld64c(gcptr src, uint64_t pos,
                                           uint64_t avail)
 {
     const uint64_t pc = pos < avail - 8 ? pos : avail - 8;
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void k_decompress_len(DecompressArgs a)
     }
     uint32_t hdr;
     uint64_t dlen;
-    if (read_header((const uint8_t *)a.in_ptrs[i], in_len, &hdr, &dlen,
+    if (read_header((gcptr)a.in_ptrs[i], in_len, &hdr, &dlen,
                     a.errs, i) != SNAPMI_OK)
         return;
     a.out_lens[i] = dlen;
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(64) void k_decompress_streams(DecompressArgs a)
 
     const uint32_t lane = threadIdx.x;
     const uint64_t st = blockIdx.x;
-    const uint8_t *in = (const uint8_t *)a.in_ptrs[st];
+    gcptr in = (gcptr)a.in_ptrs[st];
     const uint64_t in_len = a.in_lens[st];
 
     // reference Decoder::decompress, src/decompress.rs:75-95
@@ -339,9 +339,9 @@ __global__ __launch_bounds__(64) void k_decompress_streams(DecompressArgs a)
     if (dst_len > cap)
         SNAPMI_FAIL(SNAPMI_BUFFER_TOO_SMALL, cap, dst_len, 0);
 
-    const uint8_t *src = in + hdr;
+    gcptr src = in + hdr;
     const uint64_t src_len = in_len - hdr;
-    uint8_t *dst = (uint8_t *)a.out_ptrs[st];
+    gptr dst = (gptr)a.out_ptrs[st];
 
     uint64_t s = 0;       // position in src (uniform)
     uint64_t d = 0;       // position in dst (uniform)
@@ -516,8 +516,8 @@ __global__ __launch_bounds__(64) void k_decompress_streams(DecompressArgs a)
             }
             // one global load (literal bytes and far sources) and one LDS
             // read (near sources), both unconditional at safe addresses
-            const uint8_t *gp = (act && lit) ? src + s + e_key + k
-                                             : (from_hbm ? dst + sp : src);
+            gcptr gp = (act && lit) ? src + s + e_key + k
+                                    : (from_hbm ? (gcptr)(dst + sp) : src);
             const uint32_t vg = *gp;
             const uint32_t vr = ring[(uint32_t)sp & (kRing - 1)];
             uint32_t val = from_ring ? vr : vg;
@@ -557,8 +557,8 @@ __global__ __launch_bounds__(64) void k_decompress_streams(DecompressArgs a)
                 irregular = true;
                 break;
             }
-            const uint8_t *from = src + s + hd;
-            uint8_t *to = dst + d;
+            gcptr from = src + s + hd;
+            gptr to = dst + d;
             for (uint64_t i = 4 * lane; i + 4 <= Lq; i += 4 * kWave)
                 st32u(to + i, ld32u(from + i));
             const uint64_t t = Lq & ~3ull;

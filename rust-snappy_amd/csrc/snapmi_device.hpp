@@ -23,6 +23,16 @@ constexpr uint64_t kMaxInput = 0xFFFFFFFFull; // reference src/lib.rs:93
 // a multiple of 16 so scratch slots stay 16-byte aligned.
 constexpr uint32_t kSlotBytes = 76496;
 
+// Explicit address spaces.  Pointers fetched from the descriptor arrays are
+// generic to the compiler; without these it emits flat_load/flat_store, which
+// count against both vmcnt and lgkmcnt and so serialise LDS and HBM waits.
+typedef __attribute__((address_space(1))) uint8_t g_u8;
+typedef g_u8 *gptr;        // global (HBM) bytes
+typedef const g_u8 *gcptr; // global (HBM) bytes, read only
+typedef __attribute__((address_space(3))) uint16_t l_u16;
+typedef l_u16 *lptr16; // LDS u16
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ uint32_t uni(uint32_t v)
 {
     return __builtin_amdgcn_readfirstlane(v);
@@ -44,21 +54,21 @@ __device__ __forceinline__ uint64_t uni64(uint64_t v)
 
 // gfx950 global memory takes unaligned dword accesses; the compiler emits a
 // single global_load_dword / global_store_dword for these.
-__device__ __forceinline__ uint32_t ld32u(const uint8_t *p)
+__device__ __forceinline__ uint32_t ld32u(gcptr p)
 {
     uint32_t v;
     __builtin_memcpy(&v, p, 4);
     return v;
 }
 
-__device__ __forceinline__ void st32u(uint8_t *p, uint32_t v)
+__device__ __forceinline__ void st32u(gptr p, uint32_t v)
 {
     __builtin_memcpy(p, &v, 4);
 }
 
 // Dword at base[pos..pos+4) where only base[0..avail) may be touched; bytes
 // past `avail` read as zero.
-__device__ __forceinline__ uint32_t ld32g(const uint8_t *base, uint64_t pos,
+__device__ __forceinline__ uint32_t ld32g(gcptr base, uint64_t pos,
                                           uint64_t avail)
 {
     if (pos + 4 <= avail)
@@ -107,12 +117,12 @@ __device__ __forceinline__ void set_error(snapmi_error *errs, uint64_t i,
 // read with two v_readlane + one 64-bit scalar shift, i.e. without a memory
 // round trip.  Refills are one coalesced 256-byte global load.
 struct ByteWindow {
-    const uint8_t *src; // stream start
+    gcptr src;          // stream start
     uint64_t avail;     // readable bytes from src
     uint64_t base;      // stream offset of lane 0's dword
     uint32_t v;         // this lane's dword
 
-    __device__ __forceinline__ void init(const uint8_t *s, uint64_t a)
+    __device__ __forceinline__ void init(gcptr s, uint64_t a)
     {
         src = s;
         avail = a;
