@@ -38,7 +38,7 @@ struct snapmi_ctx {
     // grow-only device scratch
     DevBuf blk_first, slot_first, blk_size, blk_off, slots;
     // staging for the host-pointer (scalar) entry points
-    DevBuf st_in, st_out, st_desc, st_prof, ticket;
+    DevBuf st_in, st_out, st_desc, st_prof, ticket, order;
     int num_cus = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timing_valid = false;
@@ -178,7 +178,8 @@ void snapmi_ctx_destroy(snapmi_ctx *ctx)
         (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf *b : {&ctx->blk_first, &ctx->slot_first, &ctx->blk_size,
                       &ctx->blk_off, &ctx->slots, &ctx->st_in, &ctx->st_out,
-                      &ctx->st_desc, &ctx->st_prof, &ctx->ticket})
+                      &ctx->st_desc, &ctx->st_prof, &ctx->ticket,
+                      &ctx->order})
         if (b->p)
             (void)hipFree(b->p);
     for (auto &ev : ctx->ev)
@@ -365,6 +366,13 @@ int snapmi_decompress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     a.out_lens = d_out_lens;
     a.errs = d_errs;
     a.n_streams = (uint32_t)n;
+    {
+        int rc = reserve(ctx, ctx->order, n * sizeof(uint32_t));
+        if (rc)
+            return rc;
+    }
+    a.order = (uint32_t *)ctx->order.p;
+    a.bucket_pos = nullptr;
     a.prof = nullptr;
 #ifdef SNAPMI_PROFILE
     {
@@ -379,6 +387,7 @@ int snapmi_decompress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     hipStream_t s = ctx->stream;
     ctx->timing_valid = false;
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], s));
+    hipLaunchKernelGGL(k_plan_decompress, dim3(1), dim3(1024), 0, s, a);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], s));
     hipLaunchKernelGGL(k_decompress_streams, dim3((uint32_t)n), dim3(64), 0,
                        s, a);
@@ -413,6 +422,8 @@ int snapmi_decompress_len_batch(snapmi_ctx *ctx,
     a.out_lens = d_out_lens;
     a.errs = d_errs;
     a.n_streams = (uint32_t)n;
+    a.order = nullptr;
+    a.bucket_pos = nullptr;
     a.prof = nullptr;
     hipLaunchKernelGGL(k_decompress_len, dim3((uint32_t)((n + 255) / 256)),
                        dim3(256), 0, ctx->stream, a);

@@ -307,6 +307,41 @@ __global__ __launch_bounds__(256) void k_decompress_len(DecompressArgs a)
 }
 
 // ---------------------------------------------------------------------
+// Plan: dispatch order.  Streams differ in size by orders of magnitude and a
+// stream is decoded by one wavefront, so the longest streams must start
+// first or they become the tail of the launch.  One workgroup sorts the
+// stream indices by floor(log2(compressed length)), largest bucket first
+// (counting sort: histogram, bucket offsets, scatter).
+// ---------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_plan_decompress(DecompressArgs a)
+{
+    __shared__ uint32_t hist[64];
+    if (threadIdx.x < 64)
+        hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < a.n_streams; i += blockDim.x) {
+        const uint64_t len = a.in_lens[i];
+        const uint32_t bk = len ? 63 - (uint32_t)__builtin_clzll(len) : 0;
+        atomicAdd(&hist[63 - bk], 1u); // reversed: big buckets first
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t k = 0; k < 64; k++) {
+            const uint32_t c = hist[k];
+            hist[k] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < a.n_streams; i += blockDim.x) {
+        const uint64_t len = a.in_lens[i];
+        const uint32_t bk = len ? 63 - (uint32_t)__builtin_clzll(len) : 0;
+        a.order[atomicAdd(&hist[63 - bk], 1u)] = i;
+    }
+}
+
+// ---------------------------------------------------------------------
 // K2: one wavefront per raw stream.
 // ---------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_decompress_streams(DecompressArgs a)
@@ -314,7 +349,7 @@ __global__ __launch_bounds__(64) void k_decompress_streams(DecompressArgs a)
     __shared__ __attribute__((aligned(16))) uint8_t ring[kRing];
 
     const uint32_t lane = threadIdx.x;
-    const uint64_t st = blockIdx.x;
+    const uint64_t st = a.order[blockIdx.x];
     gcptr in = (gcptr)a.in_ptrs[st];
     const uint64_t in_len = a.in_lens[st];
 

@@ -43,6 +43,9 @@ struct DecompressArgs {
     uint64_t *out_lens;
     snapmi_error *errs; // [n] or nullptr
     uint32_t n_streams;
+    // [n] stream indices, longest compressed stream first (k_plan_decompress)
+    uint32_t *order;
+    uint32_t *bucket_pos; // [64] scratch of k_plan_decompress
     // experiment builds (-DSNAPMI_PROFILE) only: 16 u64 cycle counters
     unsigned long long *prof;
 };
@@ -52,6 +55,7 @@ __global__ void k_compress_blocks(CompressArgs a);
 __global__ void k_scan_sizes(CompressArgs a);
 __global__ void k_compact(CompressArgs a);
 
+__global__ void k_plan_decompress(DecompressArgs a);
 __global__ void k_decompress_streams(DecompressArgs a);
 __global__ void k_decompress_len(DecompressArgs a);
 
