@@ -58,46 +58,28 @@ def build_round():
 def cpu_baseline(rnd, seconds=8.0):
     """Oracle (the C restatement of the reference, kind 'port') timed on the
     host cores on a bounded sample: the 12-stream round, repeated by every
-    thread for `seconds` per direction."""
+    thread (pthreads inside oracle/liboracle.so) for `seconds` per
+    direction."""
     import ctypes as C
-    import threading
     import oracle_lib as O
     L = O.lib()
     cores = os.cpu_count() or 1
     datas = [d for _, d in rnd]
     comps = [O.compress(d) for d in datas]
-    ubytes = sum(len(d) for d in datas)
-
-    def worker(direction, stop_at, counts, idx):
-        outs = [C.create_string_buffer(max(O.max_compress_len(len(d)), 64))
-                for d in datas]
-        n = C.c_size_t(0)
-        e = O.OracleError()
-        rounds = 0
-        while time.perf_counter() < stop_at:
-            if direction == "c":
-                for d, o in zip(datas, outs):
-                    L.snapo_compress(d, len(d), o, len(o), C.byref(n),
-                                     C.byref(e))
-            else:
-                for c, d, o in zip(comps, datas, outs):
-                    L.snapo_decompress(c, len(c), o, len(o), C.byref(n),
-                                       C.byref(e))
-            rounds += 1
-        counts[idx] = rounds
-
+    n = len(datas)
+    PP = C.c_char_p * n
+    SZ = C.c_size_t * n
+    L.snapo_bench.restype = C.c_double
+    L.snapo_bench.argtypes = [PP, SZ, PP, SZ, C.c_int, C.c_int, C.c_int,
+                              C.c_double, C.POINTER(C.c_uint64)]
     res = {}
-    for direction in ("c", "d"):
-        counts = [0] * cores
+    for direction, key in ((0, "c"), (1, "d")):
+        rounds = C.c_uint64(0)
         t0 = time.perf_counter()
-        stop_at = t0 + seconds
-        th = [threading.Thread(target=worker,
-                               args=(direction, stop_at, counts, i))
-              for i in range(cores)]
-        [t.start() for t in th]
-        [t.join() for t in th]
-        dt = time.perf_counter() - t0
-        res[direction] = (sum(counts) * ubytes / dt / GIB, sum(counts), dt)
+        bps = L.snapo_bench(PP(*datas), SZ(*[len(d) for d in datas]),
+                            PP(*comps), SZ(*[len(c) for c in comps]), n,
+                            direction, cores, seconds, C.byref(rounds))
+        res[key] = (bps / GIB, rounds.value, time.perf_counter() - t0)
     c, d = res["c"][0], res["d"][0]
     combined = 2.0 / (1.0 / c + 1.0 / d)
     out = {
@@ -107,8 +89,18 @@ def cpu_baseline(rnd, seconds=8.0):
         "sample": (f"12-stream zflat/uflat round (2928571 B) x "
                    f"{res['c'][1]} (compress, {res['c'][2]:.1f}s) / x "
                    f"{res['d'][1]} (decompress, {res['d'][2]:.1f}s) on "
-                   f"{cores} threads, oracle/snappy_oracle.c -O3"),
+                   f"{cores} pthreads, oracle/snappy_oracle.c -O3"),
     }
+    # one thread, for comparison with the reference README (1 core)
+    r1 = C.c_uint64(0)
+    c1 = L.snapo_bench(PP(*datas), SZ(*[len(d) for d in datas]), PP(*comps),
+                       SZ(*[len(c) for c in comps]), n, 0, 1, 2.0,
+                       C.byref(r1)) / GIB
+    d1 = L.snapo_bench(PP(*datas), SZ(*[len(d) for d in datas]), PP(*comps),
+                       SZ(*[len(c) for c in comps]), n, 1, 1, 2.0,
+                       C.byref(r1)) / GIB
+    out["one_thread"] = {"compress_gibs": round(c1, 4),
+                         "decompress_gibs": round(d1, 4)}
     if O.libsnappy() is not None:  # informational: Google libsnappy 1.1.8
         t0 = time.perf_counter()
         k = 0
@@ -116,6 +108,7 @@ def cpu_baseline(rnd, seconds=8.0):
             for dd in datas:
                 O.libsnappy_compress(dd)
             k += 1
+        ubytes = sum(len(d) for d in datas)
         out["libsnappy_1_1_8_compress_gibs_1thread"] = round(
             k * ubytes / (time.perf_counter() - t0) / GIB, 4)
     return out

@@ -35,15 +35,30 @@ static int fail(snapo_error *e, int kind, uint64_t a, uint64_t b, uint64_t c)
 }
 
 /* ---- little-endian helpers: src/bytes.rs:95-118 --------------------- */
-static uint32_t le32(const uint8_t *p)
+#if defined(__BYTE_ORDER__) && __BYTE_ORDER__ == __ORDER_LITTLE_ENDIAN__
+static inline uint32_t le32(const uint8_t *p)
+{
+    uint32_t v;
+    memcpy(&v, p, 4); /* one unaligned load, as loadu_u32_le */
+    return v;
+}
+static inline uint64_t le64(const uint8_t *p)
+{
+    uint64_t v;
+    memcpy(&v, p, 8);
+    return v;
+}
+#else
+static inline uint32_t le32(const uint8_t *p)
 {
     return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 |
            (uint32_t)p[3] << 24;
 }
-static uint64_t le64(const uint8_t *p)
+static inline uint64_t le64(const uint8_t *p)
 {
     return (uint64_t)le32(p) | (uint64_t)le32(p + 4) << 32;
 }
+#endif
 
 /* src/bytes.rs:61-70 */
 static size_t put_varint(uint8_t *dst, uint64_t n)
@@ -194,10 +209,21 @@ static size_t compress_block(const uint8_t *src, size_t n, uint8_t *dst,
             size_t base = s;
             size_t c = cand + 4;
             s += 4;
-            while (s < n && src[s] == src[c]) { /* extend to block end */
+            /* extend_match, :378-412: 8 bytes at a time, then bytewise */
+            while (s + 8 <= n) {
+                uint64_t z = le64(src + s) ^ le64(src + c);
+                if (z) {
+                    s += (size_t)__builtin_ctzll(z) >> 3;
+                    goto extended;
+                }
+                s += 8;
+                c += 8;
+            }
+            while (s < n && src[s] == src[c]) {
                 s++;
                 c++;
             }
+        extended:
             d = put_copy(dst, d, base - cand, s - base);
             next_emit = s;
             if (s >= s_limit)
@@ -354,8 +380,13 @@ int snapo_decompress(const uint8_t *input, size_t input_len, uint8_t *output,
             uint64_t end = d + len;
             if (end > dst_len)
                 return fail(err, SNAPO_COPY_WRITE, len, dst_len - d, 0);
-            for (; d != end; d++)
-                dst[d] = dst[d - offset];
+            if (offset >= len) { /* disjoint: one block move */
+                memcpy(dst + d, dst + d - offset, (size_t)len);
+                d = end;
+            } else {
+                for (; d != end; d++) /* overlapping: replicate the pattern */
+                    dst[d] = dst[d - offset];
+            }
         }
     }
     if (d != dst_len)
@@ -555,4 +586,87 @@ int snapo_frame_decompress(const uint8_t *input, size_t n, uint8_t *out,
 #undef NEED
     *written = o;
     return fail(err, SNAPO_OK, 0, 0, 0);
+}
+
+/* ---- multi-threaded timing driver for bench.py's cpu_baseline leg -------
+ * Runs the restatement above on `threads` pthreads for about `seconds`:
+ * every thread loops over the same n streams (compress, or decompress of
+ * their compressed form) into private buffers.  Returns uncompressed bytes
+ * per second summed over the threads.  Test/bench infrastructure only. */
+#include <pthread.h>
+#include <stdlib.h>
+#include <time.h>
+
+typedef struct bench_job {
+    const uint8_t *const *datas;
+    const size_t *lens;
+    const uint8_t *const *comps;
+    const size_t *clens;
+    int n;
+    int direction; /* 0 = compress, 1 = decompress */
+    double seconds;
+    uint64_t rounds; /* out */
+    size_t maxlen;
+} bench_job;
+
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+static void *bench_worker(void *arg)
+{
+    bench_job *j = (bench_job *)arg;
+    size_t cap = snapo_max_compress_len(j->maxlen);
+    uint8_t *out = (uint8_t *)malloc(cap ? cap : 64);
+    snapo_error e;
+    size_t w;
+    const double t_end = now_s() + j->seconds;
+    uint64_t rounds = 0;
+    do {
+        for (int i = 0; i < j->n; i++) {
+            if (j->direction == 0)
+                snapo_compress(j->datas[i], j->lens[i], out, cap, &w, &e);
+            else
+                snapo_decompress(j->comps[i], j->clens[i], out, cap, &w, &e);
+        }
+        rounds++;
+    } while (now_s() < t_end);
+    j->rounds = rounds;
+    free(out);
+    return NULL;
+}
+
+double snapo_bench(const uint8_t *const *datas, const size_t *lens,
+                   const uint8_t *const *comps, const size_t *clens, int n,
+                   int direction, int threads, double seconds,
+                   uint64_t *total_rounds)
+{
+    bench_job *jobs = (bench_job *)calloc((size_t)threads, sizeof *jobs);
+    pthread_t *th = (pthread_t *)calloc((size_t)threads, sizeof *th);
+    size_t maxlen = 0, ubytes = 0;
+    for (int i = 0; i < n; i++) {
+        if (lens[i] > maxlen)
+            maxlen = lens[i];
+        ubytes += lens[i];
+    }
+    const double t0 = now_s();
+    for (int t = 0; t < threads; t++) {
+        jobs[t] = (bench_job){datas, lens, comps, clens, n,
+                              direction, seconds, 0, maxlen};
+        pthread_create(&th[t], NULL, bench_worker, &jobs[t]);
+    }
+    uint64_t rounds = 0;
+    for (int t = 0; t < threads; t++) {
+        pthread_join(th[t], NULL);
+        rounds += jobs[t].rounds;
+    }
+    const double dt = now_s() - t0;
+    if (total_rounds)
+        *total_rounds = rounds;
+    free(jobs);
+    free(th);
+    return (double)rounds * (double)ubytes / dt;
 }
