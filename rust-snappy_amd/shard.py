@@ -1,0 +1,71 @@
+"""Multi-GPU sharding of a batch of independent streams.
+
+Raw streams (and frame chunks) are independent, so the path shards with no
+exchange during compute: every rank takes a contiguous range of streams,
+balanced by uncompressed bytes.  The only collective is the optional gather
+of the (variable-length) results, used to assemble one framed stream.
+
+Works with any torch.distributed backend: `nccl` (= RCCL over xGMI) on GPUs,
+`gloo` on CPU (tests).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def partition_by_bytes(lens, world):
+    """Contiguous ranges [start, end) per rank, balanced by sum(lens)."""
+    lens = np.asarray(lens, dtype=np.int64)
+    n = len(lens)
+    if world <= 1:
+        return [(0, n)]
+    csum = np.concatenate([[0], np.cumsum(lens)])
+    total = int(csum[-1])
+    bounds = [0]
+    for r in range(1, world):
+        target = total * r // world
+        # first index whose prefix reaches the target, kept monotone
+        i = int(np.searchsorted(csum, target, side="left"))
+        bounds.append(min(max(i, bounds[-1]), n))
+    bounds.append(n)
+    return [(bounds[r], bounds[r + 1]) for r in range(world)]
+
+
+def exchange_sizes(local_bytes, device="cpu", group=None):
+    """all_gather of one int64 per rank -> (sizes[world], offsets[world])."""
+    world = dist.get_world_size(group)
+    mine = torch.tensor([int(local_bytes)], dtype=torch.int64, device=device)
+    out = [torch.zeros(1, dtype=torch.int64, device=device)
+           for _ in range(world)]
+    dist.all_gather(out, mine, group=group)
+    sizes = [int(t.item()) for t in out]
+    offs = [0]
+    for s in sizes[:-1]:
+        offs.append(offs[-1] + s)
+    return sizes, offs
+
+
+def gatherv(local, dst=0, group=None):
+    """Variable-length gather of 1-D uint8 tensors to rank `dst`.
+
+    RCCL has no gatherv: sizes are exchanged first, then every rank sends its
+    slab straight into the root's buffer at its prefix offset (grouped
+    point-to-point: on xGMI the root's 7 inbound links work in parallel, which
+    a ring would not).  Returns the concatenation on `dst`, None elsewhere."""
+    rank = dist.get_rank(group)
+    world = dist.get_world_size(group)
+    sizes, offs = exchange_sizes(local.numel(), local.device, group)
+    if rank == dst:
+        out = torch.empty(sum(sizes), dtype=torch.uint8, device=local.device)
+        out[offs[dst]:offs[dst] + sizes[dst]] = local
+        reqs = []
+        for r in range(world):
+            if r != dst and sizes[r]:
+                reqs.append(dist.irecv(out[offs[r]:offs[r] + sizes[r]], src=r,
+                                       group=group))
+        for q in reqs:
+            q.wait()
+        return out
+    if local.numel():
+        dist.send(local.contiguous(), dst=dst, group=group)
+    return None
