@@ -414,6 +414,13 @@ __device__ __forceinline__ void compress_one_block(
     const uint32_t s_limit = n - kInputMargin;
     uint32_t s = 0, next_emit = 0, q = 0;
     bool chain = false;
+    // Register window of the input for hashing: wv0/1/2[lane] = the dword at
+    // block offset wbase + {0,64,128} + lane.  After a copy the next batch's
+    // hash inputs are a lane rotation of these (3 ds_bpermute), so the HBM/L2
+    // round trip for "the 4 bytes at each probed position" leaves the chain.
+    // wv3 is the prefetch slot: loaded one slide ahead of its first use.
+    uint32_t wbase = 0x80000000u, wv0 = 0, wv1 = 0, wv2 = 0, wv3 = 0;
+    const uint32_t cI = cB + 1; // offset of this lane's probe from s - 1
 #ifdef SNAPMI_PROFILE
     uint64_t pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t t_last = __builtin_readcyclecounter();
@@ -444,9 +451,30 @@ __device__ __forceinline__ void compress_one_block(
         // reference: "if s_next > s_limit return done()", :212-214
         const bool valid = active && nextp <= s_limit;
         const uint32_t pc = p < n - 16 ? p : n - 16;
+        uint32_t hx = 0; // the 4 bytes at p, for the hash
+        if (chain && q == 0) {
+            // from the register window: no memory round trip before the hash
+            const uint32_t idx = s - 1 - wbase + cI; // < 192
+            const int sel = (int)((idx & 63) << 2);
+            const uint32_t g0 =
+                (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)wv0);
+            const uint32_t g1 =
+                (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)wv1);
+            const uint32_t g2 =
+                (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)wv2);
+            hx = idx < 64 ? g0 : (idx < 128 ? g1 : g2);
+        }
+        // issued after the window reads so that its latency overlaps the
+        // hash, the LDS atomic and the candidate gather
         const B16 x = ld128u(src + pc);
+        if (!(chain && q == 0)) {
+            hx = x.w[0];
+            // keep this a real (uniform) branch: as a select it would make
+            // the hash wait for x on the window path too
+            asm volatile("" : "+v"(hx));
+        }
         TICK(1);
-        const uint32_t h = hash32(x.w[0], shift);
+        const uint32_t h = hash32(hx, shift);
         uint32_t cand = 0;
         if (valid) {
             const uint32_t sh = (h & 1) * 16;
@@ -489,6 +517,29 @@ __device__ __forceinline__ void compress_one_block(
         next_emit = s;
         chain = true;
         q = 0;
+        // keep the window covering s-1 .. s+158: slide by 64 positions when
+        // s-1 has moved past the first register, restart after a long jump
+        {
+            const uint32_t D = s - 1 - wbase;
+            if (D >= 64) {
+                if (D < 128) {
+                    wv0 = wv1;
+                    wv1 = wv2;
+                    wv2 = wv3;
+                    wbase += 64;
+                    const uint32_t wp = wbase + 192 + lane;
+                    wv3 = ld32u(src + (wp < n - 4 ? wp : n - 4));
+                } else {
+                    wbase = s - 1;
+                    const uint32_t w0 = wbase + lane;
+                    const uint32_t n4 = n - 4;
+                    wv0 = ld32u(src + (w0 < n4 ? w0 : n4));
+                    wv1 = ld32u(src + (w0 + 64 < n4 ? w0 + 64 : n4));
+                    wv2 = ld32u(src + (w0 + 128 < n4 ? w0 + 128 : n4));
+                    wv3 = ld32u(src + (w0 + 192 < n4 ? w0 + 192 : n4));
+                }
+            }
+        }
         if (s >= s_limit) // reference :275-277
             break;
     }
@@ -555,10 +606,12 @@ __global__ __launch_bounds__(kCompressWaves * 64) void k_compress_blocks(
         compress_one_block(a, b, lane, table, tbase, c2, c3, cB, cBn);
 #else
     // one ticket per wavefront per block
-    uint32_t b = next_ticket(a.ticket, lane);
+    // (the helper's result comes back in a VGPR: re-pin it to an SGPR so the
+    // whole block state stays scalar)
+    uint32_t b = uni(next_ticket(a.ticket, lane));
     while (b < nblocks) {
         compress_one_block(a, b, lane, table, tbase, c2, c3, cB, cBn);
-        b = next_ticket(a.ticket, lane);
+        b = uni(next_ticket(a.ticket, lane));
     }
 #endif
 }
