@@ -197,6 +197,56 @@ typedef struct snapmi_timing {
 } snapmi_timing;
 int snapmi_last_timing(snapmi_ctx *ctx, snapmi_timing *out);
 
+/* ------------------------------------------------------------------ */
+/* 4. Snappy frame format on the device (reference src/frame.rs,        */
+/*    src/crc32.rs, src/write.rs, src/read.rs).  One framed stream per  */
+/*    call; every <=64 KiB chunk is an independent raw stream, so the   */
+/*    chunk is the parallel unit.  All d_* pointers are device memory.  */
+/*    Asynchronous like the batch calls.                                */
+/* ------------------------------------------------------------------ */
+
+/* Upper bound of snapmi_frame_compress output for n input bytes:
+ * stream identifier + per chunk (8-byte header + at most the chunk itself,
+ * because of the uncompressed fallback of reference src/frame.rs:85). */
+size_t snapmi_frame_max_len(size_t n);
+
+/*
+ * What write::FrameEncoder::write_all(input) followed by into_inner()
+ * produces (reference src/write.rs:123-192 chunking, src/frame.rs:62-104
+ * compress_frame, src/crc32.rs:35-38 masked CRC32C of the uncompressed chunk):
+ *   d_out_len[0]        : framed length (0 for empty input, as the reference)
+ *   d_chunk_offsets     : optional [chunks+1] offsets of every chunk header
+ *                         in d_out (a side index; not part of the stream)
+ */
+int snapmi_frame_compress(snapmi_ctx *ctx, const void *d_in, uint64_t in_len,
+                          void *d_out, uint64_t out_cap, uint64_t *d_out_len,
+                          uint64_t *d_chunk_offsets);
+
+/*
+ * read::FrameDecoder over the whole stream (reference src/read.rs:105-238):
+ * stream identifier, chunk types, length limits, raw decode, CRC check.
+ *   d_chunk_offsets/n_chunks : optional side index of the chunk headers
+ *                         (as written by snapmi_frame_compress); without it
+ *                         the headers are walked on the device, one after
+ *                         the other (the format has no index)
+ *   d_out == NULL       : only compute the decompressed length
+ *   d_out_len[0]        : decompressed length, 0 on error
+ *   d_err[0]            : first error in stream order (kind 0 = ok);
+ *                         an io::ErrorKind::UnexpectedEof is reported as
+ *                         SNAPMI_E_UNEXPECTED_EOF
+ */
+int snapmi_frame_decompress(snapmi_ctx *ctx, const void *d_in,
+                            uint64_t in_len, void *d_out, uint64_t out_cap,
+                            uint64_t *d_out_len, snapmi_error *d_err,
+                            const uint64_t *d_chunk_offsets,
+                            uint64_t n_chunks);
+
+/* Masked CRC32C (reference CheckSummer::crc32c_masked, src/crc32.rs:35-38)
+ * of n buffers of at most 65536 bytes each. */
+int snapmi_crc32c_masked_batch(snapmi_ctx *ctx, const void *const *d_ptrs,
+                               const uint64_t *d_lens, uint32_t *d_out,
+                               size_t n);
+
 #ifdef __cplusplus
 }
 #endif

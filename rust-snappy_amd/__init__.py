@@ -16,5 +16,8 @@ from .error import DeviceError, Error
 _lib.load()  # fail loudly at import if the HIP library has not been built
 
 from . import raw  # noqa: E402
+from . import frame  # noqa: E402
+from . import frame as read  # snap::read::{FrameDecoder, FrameEncoder}
+from . import frame as write  # snap::write::FrameEncoder
 
-__all__ = ["raw", "Error", "DeviceError"]
+__all__ = ["raw", "frame", "read", "write", "Error", "DeviceError"]

@@ -53,6 +53,12 @@ SYMBOLS = [
     ("snapmi_decompress_len_batch", C.c_int, [_P, _P, _P, _P, _P, _SZ]),
     ("snapmi_ctx_synchronize", C.c_int, [_P]),
     ("snapmi_last_timing", C.c_int, [_P, C.POINTER(SnapmiTiming)]),
+    ("snapmi_frame_max_len", _SZ, [_SZ]),
+    ("snapmi_frame_compress", C.c_int,
+     [_P, _P, C.c_uint64, _P, C.c_uint64, _P, _P]),
+    ("snapmi_frame_decompress", C.c_int,
+     [_P, _P, C.c_uint64, _P, C.c_uint64, _P, _P, _P, C.c_uint64]),
+    ("snapmi_crc32c_masked_batch", C.c_int, [_P, _P, _P, _P, _SZ]),
 ]
 
 _lib = None

@@ -16,73 +16,13 @@
 #include <vector>
 
 #include "snapmi.h"
+#include "snapmi_ctx.hpp"
 #include "snapmi_device.hpp"
 #include "snapmi_kernels.hpp"
 
 using namespace snapmi;
 
 namespace {
-
-struct DevBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-};
-
-} // namespace
-
-struct snapmi_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool owns_stream = false;
-    std::string last_error;
-    // grow-only device scratch
-    DevBuf blk_first, slot_first, blk_size, blk_off, slots;
-    // staging for the host-pointer (scalar) entry points
-    DevBuf st_in, st_out, st_desc, st_prof, ticket, order;
-    int num_cus = 0;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    bool timing_valid = false;
-    bool timing_is_compress = false;
-    uint64_t codec_launches = 0;
-};
-
-namespace {
-
-int fail_ctx(snapmi_ctx *ctx, int kind, const char *fmt, ...)
-{
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    if (ctx)
-        ctx->last_error = buf;
-    return kind;
-}
-
-#define HIP_TRY(ctx, expr)                                                    \
-    do {                                                                      \
-        hipError_t _e = (expr);                                               \
-        if (_e != hipSuccess)                                                 \
-            return fail_ctx((ctx), SNAPMI_E_DEVICE, "%s failed: %s", #expr,   \
-                            hipGetErrorString(_e));                           \
-    } while (0)
-
-int reserve(snapmi_ctx *ctx, DevBuf &b, size_t bytes)
-{
-    if (bytes <= b.cap)
-        return SNAPMI_OK;
-    if (b.p) {
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        HIP_TRY(ctx, hipFree(b.p));
-        b.p = nullptr;
-        b.cap = 0;
-    }
-    size_t want = bytes + bytes / 8 + 256;
-    HIP_TRY(ctx, hipMalloc(&b.p, want));
-    b.cap = want;
-    return SNAPMI_OK;
-}
 
 void set_err(snapmi_error *e, int kind, uint64_t a = 0, uint64_t b = 0,
              uint64_t c = 0)
@@ -179,7 +119,8 @@ void snapmi_ctx_destroy(snapmi_ctx *ctx)
     for (DevBuf *b : {&ctx->blk_first, &ctx->slot_first, &ctx->blk_size,
                       &ctx->blk_off, &ctx->slots, &ctx->st_in, &ctx->st_out,
                       &ctx->st_desc, &ctx->st_prof, &ctx->ticket,
-                      &ctx->order})
+                      &ctx->order, &ctx->fr_tables, &ctx->fr_desc,
+                      &ctx->fr_meta, &ctx->fr_scan, &ctx->fr_slots})
         if (b->p)
             (void)hipFree(b->p);
     for (auto &ev : ctx->ev)
@@ -272,10 +213,25 @@ int snapmi_compress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
         blocks += nb;
         slots += nb - 1;
     }
+    return launch_compress(ctx, d_in_ptrs, d_in_lens, d_out_ptrs, d_out_caps,
+                           d_out_lens, d_errs, n, blocks, slots);
+}
+
+} // extern "C"
+
+namespace snapmi {
+
+int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
+                    const uint64_t *d_in_lens, void *const *d_out_ptrs,
+                    const uint64_t *d_out_caps, uint64_t *d_out_lens,
+                    snapmi_error *d_errs, size_t n, uint64_t blocks,
+                    uint64_t slots)
+{
     if (blocks > 0x7FFFFFFFu)
         return fail_ctx(ctx, SNAPMI_E_ARGUMENT,
                         "compress_batch: %llu blocks in one batch",
                         (unsigned long long)blocks);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
 
     int rc;
     if ((rc = reserve(ctx, ctx->blk_first, (n + 1) * sizeof(uint32_t))) ||
@@ -344,19 +300,11 @@ int snapmi_compress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     return SNAPMI_OK;
 }
 
-int snapmi_decompress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
-                            const uint64_t *d_in_lens,
-                            void *const *d_out_ptrs,
-                            const uint64_t *d_out_caps, uint64_t *d_out_lens,
-                            snapmi_error *d_errs, size_t n)
+int launch_decompress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
+                      const uint64_t *d_in_lens, void *const *d_out_ptrs,
+                      const uint64_t *d_out_caps, uint64_t *d_out_lens,
+                      snapmi_error *d_errs, const uint8_t *d_modes, size_t n)
 {
-    if (!ctx)
-        return SNAPMI_E_ARGUMENT;
-    if (n == 0)
-        return SNAPMI_OK;
-    if (!d_in_ptrs || !d_in_lens || !d_out_ptrs || !d_out_caps ||
-        !d_out_lens || n > 0x7FFFFFFFu)
-        return fail_ctx(ctx, SNAPMI_E_ARGUMENT, "decompress_batch: bad args");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DecompressArgs a;
     a.in_ptrs = d_in_ptrs;
@@ -365,6 +313,7 @@ int snapmi_decompress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     a.out_caps = d_out_caps;
     a.out_lens = d_out_lens;
     a.errs = d_errs;
+    a.modes = d_modes;
     a.n_streams = (uint32_t)n;
     {
         int rc = reserve(ctx, ctx->order, n * sizeof(uint32_t));
@@ -400,6 +349,27 @@ int snapmi_decompress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     return SNAPMI_OK;
 }
 
+} // namespace snapmi
+
+extern "C" {
+
+int snapmi_decompress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
+                            const uint64_t *d_in_lens,
+                            void *const *d_out_ptrs,
+                            const uint64_t *d_out_caps, uint64_t *d_out_lens,
+                            snapmi_error *d_errs, size_t n)
+{
+    if (!ctx)
+        return SNAPMI_E_ARGUMENT;
+    if (n == 0)
+        return SNAPMI_OK;
+    if (!d_in_ptrs || !d_in_lens || !d_out_ptrs || !d_out_caps ||
+        !d_out_lens || n > 0x7FFFFFFFu)
+        return fail_ctx(ctx, SNAPMI_E_ARGUMENT, "decompress_batch: bad args");
+    return launch_decompress(ctx, d_in_ptrs, d_in_lens, d_out_ptrs, d_out_caps,
+                             d_out_lens, d_errs, nullptr, n);
+}
+
 int snapmi_decompress_len_batch(snapmi_ctx *ctx,
                                 const void *const *d_in_ptrs,
                                 const uint64_t *d_in_lens,
@@ -421,6 +391,7 @@ int snapmi_decompress_len_batch(snapmi_ctx *ctx,
     a.out_caps = nullptr;
     a.out_lens = d_out_lens;
     a.errs = d_errs;
+    a.modes = nullptr;
     a.n_streams = (uint32_t)n;
     a.order = nullptr;
     a.bucket_pos = nullptr;

@@ -1,0 +1,95 @@
+// snapmi_ctx.hpp -- private: the context object and helpers shared by the
+// host-side translation units (snapmi_api.hip, snapmi_frame.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+#include "snapmi.h"
+
+namespace snapmi {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+} // namespace snapmi
+
+struct snapmi_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    std::string last_error;
+    // grow-only device scratch of the raw codec
+    snapmi::DevBuf blk_first, slot_first, blk_size, blk_off, slots;
+    // staging for the host-pointer (scalar) entry points
+    snapmi::DevBuf st_in, st_out, st_desc, st_prof, ticket, order;
+    // frame layer scratch (snapmi_frame.hip)
+    snapmi::DevBuf fr_tables, fr_desc, fr_meta, fr_scan, fr_slots;
+    bool fr_tables_ready = false;
+    int num_cus = 0;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool timing_valid = false;
+    bool timing_is_compress = false;
+    uint64_t codec_launches = 0;
+};
+
+namespace snapmi {
+
+inline int fail_ctx(snapmi_ctx *ctx, int kind, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->last_error = buf;
+    return kind;
+}
+
+#define HIP_TRY(ctx, expr)                                                    \
+    do {                                                                      \
+        hipError_t _e = (expr);                                               \
+        if (_e != hipSuccess)                                                 \
+            return snapmi::fail_ctx((ctx), SNAPMI_E_DEVICE, "%s failed: %s",  \
+                                    #expr, hipGetErrorString(_e));            \
+    } while (0)
+
+inline int reserve(snapmi_ctx *ctx, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap)
+        return SNAPMI_OK;
+    if (b.p) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes + bytes / 8 + 256;
+    HIP_TRY(ctx, hipMalloc(&b.p, want));
+    b.cap = want;
+    return SNAPMI_OK;
+}
+
+} // namespace snapmi
+
+// internal launchers (snapmi_api.hip), shared with the frame layer
+namespace snapmi {
+// raw compress of n streams; blocks/slots = launch geometry computed from
+// the (host-known) stream lengths
+int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
+                    const uint64_t *d_in_lens, void *const *d_out_ptrs,
+                    const uint64_t *d_out_caps, uint64_t *d_out_lens,
+                    snapmi_error *d_errs, size_t n, uint64_t blocks,
+                    uint64_t slots);
+// raw decompress; d_modes optional (1 = stored chunk, plain copy)
+int launch_decompress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
+                      const uint64_t *d_in_lens, void *const *d_out_ptrs,
+                      const uint64_t *d_out_caps, uint64_t *d_out_lens,
+                      snapmi_error *d_errs, const uint8_t *d_modes, size_t n);
+} // namespace snapmi

@@ -353,6 +353,24 @@ __global__ __launch_bounds__(64) void k_decompress_streams(DecompressArgs a)
     gcptr in = (gcptr)a.in_ptrs[st];
     const uint64_t in_len = a.in_lens[st];
 
+    if (a.modes && a.modes[st]) {
+        // stored frame chunk (reference src/read.rs:173-199): the payload is
+        // the data; 256 bytes per instruction
+        const uint64_t cap0 = a.out_caps[st];
+        if (in_len > cap0)
+            SNAPMI_FAIL(SNAPMI_BUFFER_TOO_SMALL, cap0, in_len, 0);
+        gptr to = (gptr)a.out_ptrs[st];
+        for (uint64_t i = 4 * lane; i + 4 <= in_len; i += 4 * kWave)
+            st32u(to + i, ld32u(in + i));
+        const uint64_t t = in_len & ~3ull;
+        if (lane < (in_len & 3))
+            to[t + lane] = in[t + lane];
+        if (lane == 0) {
+            set_error(a.errs, st, SNAPMI_OK, 0, 0, 0);
+            a.out_lens[st] = in_len;
+        }
+        return;
+    }
     // reference Decoder::decompress, src/decompress.rs:75-95
     if (in_len == 0)
         SNAPMI_FAIL(SNAPMI_EMPTY, 0, 0, 0);

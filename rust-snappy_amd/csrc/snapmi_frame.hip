@@ -1,0 +1,822 @@
+// snapmi_frame.hip -- Snappy frame format on the device (gfx950).
+//
+// Reference: src/frame.rs (chunk layout, compress_frame), src/crc32.rs
+// (masked CRC32C), src/write.rs (chunking of write::FrameEncoder),
+// src/read.rs (read::FrameDecoder state machine).  A framed stream is a
+// 10-byte stream identifier followed by chunks
+//     type(1) | len24 LE (= 4 + payload) | masked crc32c(uncompressed) LE | payload
+// and every data chunk (<= 64 KiB of input) is an independent raw stream, so
+// the chunk is the parallel unit: the raw codec kernels run unchanged on a
+// batch whose "streams" are the chunks.
+//
+// Kernels here:
+//   k_crc32c          masked CRC32C, one wavefront per buffer, 64 interleaved
+//                     partial CRCs advanced 256 bytes per step with 4 LDS
+//                     table lookups, combined by GF(2) multiplication
+//   k_frame_chunks    compress side: chunk descriptors for the raw compressor
+//   k_frame_sizes     compressed-vs-stored decision (src/frame.rs:85) + sizes
+//   k_scan_u64        exclusive scan (one workgroup)
+//   k_frame_emit      headers + payloads into the framed stream
+//   k_frame_walk      decode side: sequential walk over the chunk headers
+//                     (the format has no index) with the reference's checks
+//   k_frame_index     decode side with a side index: one thread per chunk
+//   k_frame_lens      decompressed length of every data chunk
+//   k_frame_desc      descriptors for the raw decompressor
+//   k_frame_verify    CRC comparison, first error in stream order
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "snapmi.h"
+#include "snapmi_ctx.hpp"
+#include "snapmi_device.hpp"
+#include "snapmi_kernels.hpp"
+
+using namespace snapmi;
+
+namespace snapmi {
+
+constexpr uint32_t kCrcPoly = 0x82F63B78u;      // reference build.rs:6
+constexpr uint32_t kMaxChunk = 76490;           // reference src/frame.rs:12
+constexpr uint32_t kFrameSlot = 76496;          // kMaxChunk rounded to 16
+
+// Tables for k_crc32c, generated once per context on the host (the
+// reference generates its tables at build time, build.rs:97-124).
+struct CrcTables {
+    uint32_t z256[4][256]; // state advanced by 256 zero bytes, per input byte
+    uint32_t lane_mul[64]; // x^(8*4*(64-j)) mod P: final advance of lane j
+    uint32_t init_adv[65537]; // 0xFFFFFFFF advanced by n zero bytes
+};
+
+struct FrameChunk { // one data chunk of a framed stream (decode side)
+    uint64_t payload_off; // offset of the payload in the stream
+    uint32_t payload_len;
+    uint32_t crc;   // stored masked crc
+    uint32_t type;  // 0 compressed, 1 stored
+    uint32_t pad;
+};
+
+// GF(2) polynomial product mod P, reflected representation (bit 31 = x^0)
+__host__ __device__ inline uint32_t gf_mul(uint32_t a, uint32_t b)
+{
+    uint32_t m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) {
+            p ^= b;
+            if ((a & (m - 1)) == 0)
+                break;
+        }
+        m >>= 1;
+        b = (b & 1) ? (b >> 1) ^ kCrcPoly : b >> 1;
+    }
+    return p;
+}
+
+// ---------------------------------------------------------------------
+// K4: masked CRC32C of n buffers (<= 65536 bytes each), one wavefront each.
+// The message is zero-padded at the FRONT to a multiple of 256 bytes (leading
+// zeros do not move a zero state); lane j owns dwords j, j+64, ... and keeps
+// a_j = Z256(a_j) ^ dword, where Z256 = "advance 256 zero bytes" through four
+// 256-entry tables in LDS.  The 64 partial states are advanced to the end
+// (one GF(2) product each), XOR-reduced, and the contribution of the initial
+// state 0xFFFFFFFF is added from a table.  Equals crc32c_slice16 /
+// the SSE4.2 instruction of reference src/crc32.rs:59-111; mask :35-38.
+// ---------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_crc32c(const void *const *ptrs,
+                                               const uint64_t *lens,
+                                               uint32_t *out, uint32_t n,
+                                               const CrcTables *tab)
+{
+    __shared__ uint32_t z[4 * 256];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t i = blockIdx.x;
+    if (i >= n)
+        return;
+    for (uint32_t k = lane; k < 1024; k += 64)
+        z[k] = tab->z256[k >> 8][k & 255];
+    __syncthreads();
+    gcptr m = (gcptr)ptrs[i];
+    const uint32_t len = (uint32_t)lens[i];
+    const uint32_t pad = (256 - (len & 255)) & 255;
+    const uint32_t steps = (len + pad) >> 8;
+    uint32_t a = 0;
+    for (uint32_t t = 0; t < steps; t++) {
+        const uint32_t pos = 256 * t + 4 * lane; // in the padded message
+        uint32_t w;
+        if (pos >= pad) {
+            w = ld32u(m + (pos - pad));
+        } else if (pos + 4 <= pad) {
+            w = 0;
+        } else { // the dword that straddles the start of the data
+            w = 0;
+            for (uint32_t b = pad - pos; b < 4; b++)
+                w |= (uint32_t)m[pos + b - pad] << (8 * b);
+        }
+        a = z[a & 255] ^ z[256 + ((a >> 8) & 255)] ^
+            z[512 + ((a >> 16) & 255)] ^ z[768 + (a >> 24)] ^ w;
+    }
+    uint32_t f = gf_mul(tab->lane_mul[lane], a);
+    for (uint32_t o = 32; o; o >>= 1)
+        f ^= __shfl_xor(f, o);
+    if (lane == 0) {
+        const uint32_t c = ~(f ^ tab->init_adv[len]);
+        out[i] = ((c >> 15) | (c << 17)) + 0xA282EAD8u; // src/crc32.rs:37
+    }
+}
+
+// ---------------------------------------------------------------------
+// compress side
+// ---------------------------------------------------------------------
+struct FrameCompressArgs {
+    const uint8_t *in;
+    uint64_t in_len;
+    uint8_t *out;
+    uint64_t out_cap;
+    uint64_t *out_len;       // [1]
+    uint64_t *chunk_offsets; // optional [n+1]
+    uint32_t n;              // chunks
+    // scratch
+    const void **in_ptrs;
+    uint64_t *in_lens;
+    void **slot_ptrs;
+    uint64_t *clens;   // raw-compressed length of every chunk
+    uint32_t *crcs;
+    uint64_t *sizes;   // 8 + payload
+    uint64_t *offs;    // exclusive scan of sizes, [n+1]
+    uint8_t *slots;
+};
+
+__global__ void k_frame_chunks(FrameCompressArgs a)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n)
+        return;
+    const uint64_t off = (uint64_t)i * kMaxBlock;
+    const uint64_t len =
+        a.in_len - off < kMaxBlock ? a.in_len - off : kMaxBlock;
+    a.in_ptrs[i] = a.in + off;
+    a.in_lens[i] = len;
+    a.slot_ptrs[i] = a.slots + (uint64_t)i * kFrameSlot;
+}
+
+// reference compress_frame, src/frame.rs:83-89
+__global__ void k_frame_sizes(FrameCompressArgs a)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n)
+        return;
+    const uint64_t len = a.in_lens[i];
+    const uint64_t clen = a.clens[i];
+    const bool stored = clen >= len - len / 8;
+    a.sizes[i] = 8 + (stored ? len : clen);
+}
+
+// exclusive scan of n u64 values, out[n] = total; one workgroup
+__global__ __launch_bounds__(1024) void k_scan_u64(const uint64_t *in,
+                                                   uint64_t *out, uint32_t n)
+{
+    __shared__ uint64_t wave_tot[16];
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint64_t carry = 0;
+    for (uint32_t base = 0; base < n; base += blockDim.x) {
+        const uint32_t i = base + threadIdx.x;
+        const uint64_t x = i < n ? in[i] : 0;
+        uint64_t sx = x;
+        for (uint32_t o = 1; o < 64; o <<= 1) {
+            const uint64_t t = __shfl_up(sx, o);
+            if (lane >= o)
+                sx += t;
+        }
+        if (lane == 63)
+            wave_tot[w] = sx;
+        __syncthreads();
+        uint64_t before = 0, all = 0;
+        for (uint32_t j = 0; j < (blockDim.x >> 6); j++) {
+            const uint64_t t = wave_tot[j];
+            if (j < w)
+                before += t;
+            all += t;
+        }
+        __syncthreads();
+        if (i < n)
+            out[i] = carry + before + sx - x;
+        carry += all;
+    }
+    if (threadIdx.x == 0)
+        out[n] = carry;
+}
+
+// one workgroup per chunk: header (src/frame.rs:91-93) + payload
+__global__ __launch_bounds__(256) void k_frame_emit(FrameCompressArgs a)
+{
+    const uint32_t i = blockIdx.x;
+    const uint64_t len = a.in_lens[i];
+    const uint64_t clen = a.clens[i];
+    const bool stored = clen >= len - len / 8;
+    const uint64_t payload = stored ? len : clen;
+    const uint64_t at = 10 + a.offs[i];
+    gptr o = (gptr)a.out + at;
+    if (i == 0 && threadIdx.x < 10) {
+        const uint8_t ident[10] = {0xFF, 0x06, 0x00, 0x00, 's',
+                                   'N',  'a',  'P',  'p',  'Y'};
+        ((gptr)a.out)[threadIdx.x] = ident[threadIdx.x];
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t cl = 4 + (uint32_t)payload;
+        const uint32_t crc = a.crcs[i];
+        o[0] = stored ? 0x01 : 0x00;
+        o[1] = (uint8_t)cl;
+        o[2] = (uint8_t)(cl >> 8);
+        o[3] = (uint8_t)(cl >> 16);
+        o[4] = (uint8_t)crc;
+        o[5] = (uint8_t)(crc >> 8);
+        o[6] = (uint8_t)(crc >> 16);
+        o[7] = (uint8_t)(crc >> 24);
+        if (a.chunk_offsets) {
+            a.chunk_offsets[i] = at;
+            if (i + 1 == a.n)
+                a.chunk_offsets[a.n] = 10 + a.offs[a.n];
+        }
+        if (i + 1 == a.n)
+            a.out_len[0] = 10 + a.offs[a.n];
+    }
+    gcptr from = stored ? (gcptr)a.in_ptrs[i]
+                        : (gcptr)(a.slots + (uint64_t)i * kFrameSlot);
+    gptr to = o + 8;
+    for (uint64_t k = 4 * threadIdx.x; k + 4 <= payload; k += 4 * blockDim.x)
+        st32u(to + k, ld32u(from + k));
+    const uint64_t t = payload & ~3ull;
+    if (threadIdx.x < (payload & 3))
+        to[t + threadIdx.x] = from[t + threadIdx.x];
+}
+
+// ---------------------------------------------------------------------
+// decode side
+// ---------------------------------------------------------------------
+struct FrameDecodeArgs {
+    const uint8_t *in;
+    uint64_t in_len;
+    uint8_t *out; // may be nullptr (lengths only)
+    uint64_t out_cap;
+    uint64_t *out_len; // [1]
+    snapmi_error *err; // [1]
+    const uint64_t *index; // optional chunk header offsets
+    uint32_t n_index;
+    uint32_t cap_chunks; // capacity of chunks[]
+    // scratch
+    FrameChunk *chunks;
+    uint32_t *meta;      // [0] data chunks found, [1] overflow flag,
+                         // [2] index of the data chunk a structural error
+                         //     precedes (0xFFFFFFFF = none)
+    snapmi_error *serr;  // [1] structural error of the walk
+    uint64_t *dlens;     // [n] decompressed length per data chunk
+    uint64_t *offs;      // [n+1]
+    snapmi_error *cerrs; // [n] per-chunk errors (length stage, decode stage)
+    const void **in_ptrs;
+    uint64_t *in_lens;
+    void **out_ptrs;
+    uint64_t *out_caps;
+    uint64_t *out_lens;
+    uint8_t *modes;
+    uint32_t *crcs; // computed
+};
+
+__device__ inline void walk_fail(const FrameDecodeArgs &a, uint32_t n_data,
+                                 int kind, uint64_t fa, uint64_t fb)
+{
+    a.serr[0].kind = kind;
+    a.serr[0].reserved = 0;
+    a.serr[0].a = fa;
+    a.serr[0].b = fb;
+    a.serr[0].c = 0;
+    a.meta[0] = n_data;
+    a.meta[2] = n_data;
+}
+
+// Sequential walk over the chunk headers: reference FrameDecoder::read,
+// src/read.rs:111-236 (checks in the reference's order).  One thread: every
+// hop depends on the previous header.
+__global__ void k_frame_walk(FrameDecodeArgs a)
+{
+    if (blockIdx.x || threadIdx.x)
+        return;
+    gcptr in = (gcptr)a.in;
+    uint64_t r = 0;
+    uint32_t nd = 0;
+    bool seen_ident = false;
+    a.meta[1] = 0;
+    a.meta[2] = 0xFFFFFFFFu;
+    a.serr[0].kind = SNAPMI_OK;
+    for (;;) {
+        if (r == a.in_len)
+            break; // clean EOF, :119-121
+        if (a.in_len - r < 4) {
+            walk_fail(a, nd, SNAPMI_E_UNEXPECTED_EOF, 0, 0);
+            return;
+        }
+        const uint32_t hd = ld32u(in + r);
+        r += 4;
+        const uint32_t ty = hd & 0xFF;
+        const uint64_t len = hd >> 8;
+        if (!seen_ident) { // :123-128
+            if (ty != 0xFF) {
+                walk_fail(a, nd, SNAPMI_STREAM_HEADER, ty, 0);
+                return;
+            }
+            seen_ident = true;
+        }
+        if (len > kMaxChunk) { // :129-135
+            walk_fail(a, nd, SNAPMI_UNSUPPORTED_CHUNK_LENGTH, len, 0);
+            return;
+        }
+        if (ty >= 0x02 && ty <= 0x7F) { // :138-142
+            walk_fail(a, nd, SNAPMI_UNSUPPORTED_CHUNK_TYPE, ty, 0);
+            return;
+        }
+        if ((ty >= 0x80 && ty <= 0xFD) || ty == 0xFE) { // skippable, padding
+            if (a.in_len - r < len) {
+                walk_fail(a, nd, SNAPMI_E_UNEXPECTED_EOF, 0, 0);
+                return;
+            }
+            r += len;
+        } else if (ty == 0xFF) { // :159-172
+            if (len != 6) {
+                walk_fail(a, nd, SNAPMI_UNSUPPORTED_CHUNK_LENGTH, len, 1);
+                return;
+            }
+            if (a.in_len - r < 6) {
+                walk_fail(a, nd, SNAPMI_E_UNEXPECTED_EOF, 0, 0);
+                return;
+            }
+            const uint8_t body[6] = {'s', 'N', 'a', 'P', 'p', 'Y'};
+            uint64_t got = 0;
+            bool same = true;
+            for (int k = 0; k < 6; k++) {
+                const uint8_t b = in[r + k];
+                got |= (uint64_t)b << (8 * k);
+                same = same && b == body[k];
+            }
+            if (!same) {
+                walk_fail(a, nd, SNAPMI_STREAM_HEADER_MISMATCH, got, 0);
+                return;
+            }
+            r += 6;
+        } else { // 0x00 compressed / 0x01 stored: :173-235
+            if (len < 4) {
+                walk_fail(a, nd, SNAPMI_UNSUPPORTED_CHUNK_LENGTH, len, 0);
+                return;
+            }
+            if (a.in_len - r < 4) {
+                walk_fail(a, nd, SNAPMI_E_UNEXPECTED_EOF, 0, 0);
+                return;
+            }
+            const uint32_t crc = ld32u(in + r);
+            r += 4;
+            const uint64_t pl = len - 4;
+            if (ty == 0x01 && pl > kMaxBlock) { // :182-187
+                walk_fail(a, nd, SNAPMI_UNSUPPORTED_CHUNK_LENGTH, pl, 0);
+                return;
+            }
+            if (a.in_len - r < pl) {
+                walk_fail(a, nd, SNAPMI_E_UNEXPECTED_EOF, 0, 0);
+                return;
+            }
+            if (nd < a.cap_chunks) {
+                FrameChunk c;
+                c.payload_off = r;
+                c.payload_len = (uint32_t)pl;
+                c.crc = crc;
+                c.type = ty;
+                c.pad = 0;
+                a.chunks[nd] = c;
+            } else {
+                a.meta[1] = 1; // overflow: caller reruns with more room
+            }
+            nd++;
+            r += pl;
+        }
+    }
+    a.meta[0] = nd;
+}
+
+// With a side index: chunk i's header is at index[i]; all chunks must be
+// data chunks written by snapmi_frame_compress (the stream identifier is
+// checked here as well).
+__global__ void k_frame_index(FrameDecodeArgs a)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    gcptr in = (gcptr)a.in;
+    if (i == 0) {
+        a.meta[0] = a.n_index;
+        a.meta[1] = 0;
+        a.meta[2] = 0xFFFFFFFFu;
+        a.serr[0].kind = SNAPMI_OK;
+        const uint8_t ident[10] = {0xFF, 0x06, 0x00, 0x00, 's',
+                                   'N',  'a',  'P',  'p',  'Y'};
+        bool ok = a.in_len >= 10;
+        for (int k = 0; ok && k < 10; k++)
+            ok = in[k] == ident[k];
+        if (!ok)
+            walk_fail(a, 0, SNAPMI_STREAM_HEADER,
+                      a.in_len ? (uint64_t)in[0] : 0, 0);
+    }
+    if (i >= a.n_index)
+        return;
+    const uint64_t r = a.index[i];
+    FrameChunk c;
+    c.type = 0xFF; // not a data chunk: rejected by k_frame_lens
+    c.payload_len = 0;
+    c.crc = 0;
+    c.payload_off = 0;
+    c.pad = 0;
+    if (r + 8 <= a.in_len) {
+        const uint32_t hd = ld32u(in + r);
+        const uint32_t ty = hd & 0xFF, len = hd >> 8;
+        if (ty <= 1 && len >= 4 && len <= kMaxChunk &&
+            r + 4 + len <= a.in_len && !(ty == 1 && len - 4 > kMaxBlock)) {
+            c.type = ty;
+            c.payload_len = len - 4;
+            c.crc = ld32u(in + r + 4);
+            c.payload_off = r + 8;
+        } else {
+            c.pad = ty; // for the error report
+        }
+    }
+    a.chunks[i] = c;
+}
+
+// decompressed length of every data chunk: reference src/read.rs:181-187
+// (stored) and :215-222 (compressed: decompress_len, then dn <= 65536)
+__global__ void k_frame_lens(FrameDecodeArgs a)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = a.meta[0];
+    if (i >= n || i >= a.cap_chunks)
+        return;
+    const FrameChunk c = a.chunks[i];
+    snapmi_error e;
+    e.kind = SNAPMI_OK;
+    e.reserved = 0;
+    e.a = e.b = e.c = 0;
+    uint64_t dn = 0;
+    if (c.type > 1) { // only reachable through a bad side index
+        e.kind = SNAPMI_UNSUPPORTED_CHUNK_TYPE;
+        e.a = c.pad;
+    } else if (c.type == 1) {
+        dn = c.payload_len;
+    } else {
+        gcptr p = (gcptr)a.in + c.payload_off;
+        uint64_t acc = 0;
+        uint32_t shift = 0, used = 0;
+        bool ok = false;
+        for (uint32_t k = 0; k < c.payload_len; k++) {
+            const uint32_t b = p[k];
+            if (shift >= 64)
+                break;
+            if (b < 0x80) {
+                acc |= (uint64_t)b << shift;
+                used = k + 1;
+                ok = true;
+                break;
+            }
+            acc |= (uint64_t)(b & 0x7F) << shift;
+            shift += 7;
+        }
+        (void)used;
+        if (c.payload_len == 0) {
+            // reference: decompress_len of the scratch reads a stale byte;
+            // the decode of the empty payload then fails with Empty
+            e.kind = SNAPMI_EMPTY;
+        } else if (!ok) {
+            e.kind = SNAPMI_HEADER;
+        } else if (acc > kMaxInput) {
+            e.kind = SNAPMI_TOO_BIG;
+            e.a = acc;
+            e.b = kMaxInput;
+        } else if (acc > kMaxBlock) {
+            e.kind = SNAPMI_UNSUPPORTED_CHUNK_LENGTH;
+            e.a = acc;
+        } else {
+            dn = acc;
+        }
+    }
+    a.dlens[i] = e.kind == SNAPMI_OK ? dn : 0;
+    a.cerrs[i] = e;
+}
+
+// descriptors for the raw decompressor (one "stream" per data chunk)
+__global__ void k_frame_desc(FrameDecodeArgs a)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = a.meta[0];
+    if (i >= n || i >= a.cap_chunks)
+        return;
+    const FrameChunk c = a.chunks[i];
+    const bool bad = a.cerrs[i].kind != SNAPMI_OK;
+    const bool fits = a.offs[n] <= a.out_cap;
+    a.in_ptrs[i] = a.in + c.payload_off;
+    // a chunk that already failed (or an output that does not fit) is
+    // decoded as an empty stored chunk: nothing is written
+    a.in_lens[i] = (bad || !fits) ? 0 : c.payload_len;
+    a.modes[i] = (bad || !fits) ? 1 : (uint8_t)c.type;
+    a.out_ptrs[i] = a.out + a.offs[i];
+    a.out_caps[i] = a.dlens[i];
+    a.out_lens[i] = 0;
+}
+
+// Final verdict: first error in stream order (reference processes chunk by
+// chunk: length checks, raw decode, checksum :225-232 / :189-196).
+__global__ __launch_bounds__(1024) void k_frame_verify(FrameDecodeArgs a,
+                                                       const snapmi_error *derrs)
+{
+    __shared__ uint32_t first_bad;
+    const uint32_t n = a.meta[0] < a.cap_chunks ? a.meta[0] : a.cap_chunks;
+    if (threadIdx.x == 0)
+        first_bad = 0xFFFFFFFFu;
+    __syncthreads();
+    const bool decoded = a.out != nullptr && a.offs[n] <= a.out_cap;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        bool bad = a.cerrs[i].kind != SNAPMI_OK;
+        if (!bad && decoded) {
+            if (derrs[i].kind != SNAPMI_OK) {
+                a.cerrs[i] = derrs[i];
+                bad = true;
+            } else if (a.crcs[i] != a.chunks[i].crc) {
+                snapmi_error e;
+                e.kind = SNAPMI_CHECKSUM;
+                e.reserved = 0;
+                e.a = a.chunks[i].crc;
+                e.b = a.crcs[i];
+                e.c = 0;
+                a.cerrs[i] = e;
+                bad = true;
+            }
+        }
+        if (bad)
+            atomicMin(&first_bad, i);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t sidx = a.meta[2]; // structural error before chunk sidx
+        snapmi_error e;
+        e.kind = SNAPMI_OK;
+        e.reserved = 0;
+        e.a = e.b = e.c = 0;
+        if (first_bad != 0xFFFFFFFFu && first_bad < sidx)
+            e = a.cerrs[first_bad];
+        else if (a.serr[0].kind != SNAPMI_OK)
+            e = a.serr[0];
+        else if (a.out != nullptr && a.offs[n] > a.out_cap) {
+            e.kind = SNAPMI_BUFFER_TOO_SMALL;
+            e.a = a.out_cap;
+            e.b = a.offs[n];
+        }
+        a.err[0] = e;
+        a.out_len[0] = e.kind == SNAPMI_OK ? a.offs[n] : 0;
+    }
+}
+
+// ---------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------
+static int ensure_tables(snapmi_ctx *ctx)
+{
+    if (ctx->fr_tables_ready)
+        return SNAPMI_OK;
+    int rc = reserve(ctx, ctx->fr_tables, sizeof(CrcTables));
+    if (rc)
+        return rc;
+    std::vector<uint8_t> buf(sizeof(CrcTables));
+    CrcTables *t = (CrcTables *)buf.data();
+    uint32_t byte_tab[256];
+    for (uint32_t i = 0; i < 256; i++) { // reference build.rs:110-124
+        uint32_t c = i;
+        for (int k = 0; k < 8; k++)
+            c = (c & 1) ? (c >> 1) ^ kCrcPoly : c >> 1;
+        byte_tab[i] = c;
+    }
+    auto adv1 = [&](uint32_t s) { return byte_tab[s & 255] ^ (s >> 8); };
+    for (int k = 0; k < 4; k++)
+        for (uint32_t b = 0; b < 256; b++) {
+            uint32_t s = b << (8 * k);
+            for (int z = 0; z < 256; z++)
+                s = adv1(s);
+            t->z256[k][b] = s;
+        }
+    // x^(8*n) mod P = the state 0x80000000 (x^0) advanced by n zero bytes
+    for (uint32_t j = 0; j < 64; j++) {
+        uint32_t s = 1u << 31;
+        for (uint32_t z = 0; z < 4 * (64 - j); z++)
+            s = adv1(s);
+        t->lane_mul[j] = s;
+    }
+    uint32_t s = 0xFFFFFFFFu;
+    for (uint32_t n = 0; n <= 65536; n++) {
+        t->init_adv[n] = s;
+        s = adv1(s);
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->fr_tables.p, buf.data(),
+                                sizeof(CrcTables), hipMemcpyHostToDevice,
+                                ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->fr_tables_ready = true;
+    return SNAPMI_OK;
+}
+
+template <class T> static T *carve(uint8_t *&p, size_t count)
+{
+    uintptr_t a = ((uintptr_t)p + 15) & ~(uintptr_t)15;
+    T *r = (T *)a;
+    p = (uint8_t *)(a + count * sizeof(T));
+    return r;
+}
+
+} // namespace snapmi
+
+extern "C" {
+
+size_t snapmi_frame_max_len(size_t n)
+{
+    const size_t chunks = (n + kMaxBlock - 1) / kMaxBlock;
+    return 10 + n + 8 * chunks;
+}
+
+int snapmi_crc32c_masked_batch(snapmi_ctx *ctx, const void *const *d_ptrs,
+                               const uint64_t *d_lens, uint32_t *d_out,
+                               size_t n)
+{
+    if (!ctx || (n && (!d_ptrs || !d_lens || !d_out)) || n > 0x7FFFFFFFu)
+        return SNAPMI_E_ARGUMENT;
+    if (n == 0)
+        return SNAPMI_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_tables(ctx);
+    if (rc)
+        return rc;
+    hipLaunchKernelGGL(k_crc32c, dim3((uint32_t)n), dim3(64), 0, ctx->stream,
+                       d_ptrs, d_lens, d_out, (uint32_t)n,
+                       (const CrcTables *)ctx->fr_tables.p);
+    HIP_TRY(ctx, hipGetLastError());
+    return SNAPMI_OK;
+}
+
+int snapmi_frame_compress(snapmi_ctx *ctx, const void *d_in, uint64_t in_len,
+                          void *d_out, uint64_t out_cap, uint64_t *d_out_len,
+                          uint64_t *d_chunk_offsets)
+{
+    if (!ctx || !d_out_len || (in_len && (!d_in || !d_out)))
+        return SNAPMI_E_ARGUMENT;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    if (in_len == 0) { // the identifier is written lazily: src/write.rs:154-170
+        HIP_TRY(ctx, hipMemsetAsync(d_out_len, 0, sizeof(uint64_t), s));
+        return SNAPMI_OK;
+    }
+    if (out_cap < snapmi_frame_max_len(in_len))
+        return fail_ctx(ctx, SNAPMI_E_ARGUMENT,
+                        "frame_compress: out_cap %llu < frame_max_len %zu",
+                        (unsigned long long)out_cap,
+                        snapmi_frame_max_len(in_len));
+    const uint64_t n64 = (in_len + kMaxBlock - 1) / kMaxBlock;
+    if (n64 > 0x7FFFFFFFu)
+        return fail_ctx(ctx, SNAPMI_E_ARGUMENT, "frame_compress: too long");
+    const uint32_t n = (uint32_t)n64;
+    int rc = ensure_tables(ctx);
+    if (rc)
+        return rc;
+    const size_t desc_bytes =
+        (size_t)n * (8 + 8 + 8 + 8 + 4 + 8 + 8) + 8 + 16 * 8;
+    if ((rc = reserve(ctx, ctx->fr_desc, desc_bytes)) ||
+        (rc = reserve(ctx, ctx->fr_slots, (size_t)n * kFrameSlot)))
+        return rc;
+    FrameCompressArgs a;
+    uint8_t *p = (uint8_t *)ctx->fr_desc.p;
+    a.in = (const uint8_t *)d_in;
+    a.in_len = in_len;
+    a.out = (uint8_t *)d_out;
+    a.out_cap = out_cap;
+    a.out_len = d_out_len;
+    a.chunk_offsets = d_chunk_offsets;
+    a.n = n;
+    a.in_ptrs = carve<const void *>(p, n);
+    a.in_lens = carve<uint64_t>(p, n);
+    a.slot_ptrs = carve<void *>(p, n);
+    a.clens = carve<uint64_t>(p, n);
+    a.sizes = carve<uint64_t>(p, n);
+    a.offs = carve<uint64_t>(p, n + 1);
+    a.crcs = carve<uint32_t>(p, n);
+    a.slots = (uint8_t *)ctx->fr_slots.p;
+
+    const uint32_t tb = 256, gb = (n + tb - 1) / tb;
+    hipLaunchKernelGGL(k_frame_chunks, dim3(gb), dim3(tb), 0, s, a);
+    // every chunk is a one-block raw stream: n blocks, no scratch slots
+    rc = launch_compress(ctx, a.in_ptrs, a.in_lens, a.slot_ptrs, nullptr,
+                         a.clens, nullptr, n, n, 0);
+    if (rc)
+        return rc;
+    hipLaunchKernelGGL(k_crc32c, dim3(n), dim3(64), 0, s, a.in_ptrs,
+                       a.in_lens, a.crcs, n,
+                       (const CrcTables *)ctx->fr_tables.p);
+    hipLaunchKernelGGL(k_frame_sizes, dim3(gb), dim3(tb), 0, s, a);
+    hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, s, a.sizes, a.offs,
+                       n);
+    hipLaunchKernelGGL(k_frame_emit, dim3(n), dim3(256), 0, s, a);
+    HIP_TRY(ctx, hipGetLastError());
+    return SNAPMI_OK;
+}
+
+int snapmi_frame_decompress(snapmi_ctx *ctx, const void *d_in,
+                            uint64_t in_len, void *d_out, uint64_t out_cap,
+                            uint64_t *d_out_len, snapmi_error *d_err,
+                            const uint64_t *d_chunk_offsets,
+                            uint64_t n_chunks)
+{
+    if (!ctx || !d_out_len || !d_err || (in_len && !d_in))
+        return SNAPMI_E_ARGUMENT;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    int rc = ensure_tables(ctx);
+    if (rc)
+        return rc;
+    // capacity for the chunk table: exact with an index, else an estimate
+    // that is retried once with the exact count
+    uint64_t cap = d_chunk_offsets ? n_chunks : in_len / 2048 + 64;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if (cap > 0x7FFFFFFFu)
+            return fail_ctx(ctx, SNAPMI_E_ARGUMENT, "frame: too many chunks");
+        const size_t n = (size_t)cap;
+        const size_t meta_bytes = 64 + sizeof(snapmi_error) +
+                                  n * (sizeof(FrameChunk) + 8 + 8 +
+                                       sizeof(snapmi_error) * 2 + 8 * 5 + 1 +
+                                       4) + 32 * 16;
+        if ((rc = reserve(ctx, ctx->fr_meta, meta_bytes)))
+            return rc;
+        FrameDecodeArgs a;
+        uint8_t *p = (uint8_t *)ctx->fr_meta.p;
+        a.in = (const uint8_t *)d_in;
+        a.in_len = in_len;
+        a.out = (uint8_t *)d_out;
+        a.out_cap = out_cap;
+        a.out_len = d_out_len;
+        a.err = d_err;
+        a.index = d_chunk_offsets;
+        a.n_index = d_chunk_offsets ? (uint32_t)n_chunks : 0;
+        a.cap_chunks = (uint32_t)n;
+        a.meta = carve<uint32_t>(p, 4);
+        a.serr = carve<snapmi_error>(p, 1);
+        a.chunks = carve<FrameChunk>(p, n);
+        a.dlens = carve<uint64_t>(p, n);
+        a.offs = carve<uint64_t>(p, n + 1);
+        a.cerrs = carve<snapmi_error>(p, n);
+        snapmi_error *derrs = carve<snapmi_error>(p, n);
+        a.in_ptrs = carve<const void *>(p, n);
+        a.in_lens = carve<uint64_t>(p, n);
+        a.out_ptrs = carve<void *>(p, n);
+        a.out_caps = carve<uint64_t>(p, n);
+        a.out_lens = carve<uint64_t>(p, n);
+        a.crcs = carve<uint32_t>(p, n);
+        a.modes = carve<uint8_t>(p, n);
+
+        const uint32_t tb = 256;
+        const uint32_t gb = n ? (uint32_t)((n + tb - 1) / tb) : 1;
+        if (d_chunk_offsets)
+            hipLaunchKernelGGL(k_frame_index, dim3(gb), dim3(tb), 0, s, a);
+        else
+            hipLaunchKernelGGL(k_frame_walk, dim3(1), dim3(64), 0, s, a);
+        // the number of data chunks decides the launch sizes below
+        uint32_t meta[4];
+        HIP_TRY(ctx, hipMemcpyAsync(meta, a.meta, sizeof meta,
+                                    hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        if (meta[1] && attempt == 0) { // table too small: rerun exactly
+            cap = meta[0];
+            continue;
+        }
+        const uint32_t nd = meta[0] < n ? meta[0] : (uint32_t)n;
+        const uint32_t gd = nd ? (nd + tb - 1) / tb : 1;
+        hipLaunchKernelGGL(k_frame_lens, dim3(gd), dim3(tb), 0, s, a);
+        hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, s, a.dlens,
+                           a.offs, nd);
+        if (d_out && nd) {
+            hipLaunchKernelGGL(k_frame_desc, dim3(gd), dim3(tb), 0, s, a);
+            rc = launch_decompress(ctx, a.in_ptrs, a.in_lens, a.out_ptrs,
+                                   a.out_caps, a.out_lens, derrs, a.modes,
+                                   nd);
+            if (rc)
+                return rc;
+            // CRC of what was produced (chunks that were skipped have
+            // out_lens 0: their CRC is never compared)
+            hipLaunchKernelGGL(k_crc32c, dim3(nd), dim3(64), 0, s,
+                               (const void *const *)a.out_ptrs, a.out_lens,
+                               a.crcs, nd,
+                               (const CrcTables *)ctx->fr_tables.p);
+        }
+        hipLaunchKernelGGL(k_frame_verify, dim3(1), dim3(1024), 0, s, a,
+                           (const snapmi_error *)derrs);
+        HIP_TRY(ctx, hipGetLastError());
+        return SNAPMI_OK;
+    }
+    return fail_ctx(ctx, SNAPMI_E_DEVICE, "frame: chunk table retry failed");
+}
+
+} // extern "C"

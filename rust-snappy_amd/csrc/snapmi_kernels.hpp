@@ -42,6 +42,8 @@ struct DecompressArgs {
     const uint64_t *out_caps; // [n] or nullptr when out_ptrs is nullptr
     uint64_t *out_lens;
     snapmi_error *errs; // [n] or nullptr
+    // optional [n]: 1 = stored chunk (frame type 0x01): plain copy of the input
+    const uint8_t *modes;
     uint32_t n_streams;
     // [n] stream indices, longest compressed stream first (k_plan_decompress)
     uint32_t *order;
