@@ -102,6 +102,11 @@ def expect_error(ctx, stream, key):
     assert want_oracle is not None, "oracle accepted the stream"
     if want_oracle.kind == -1:
         assert got.variant == "UnexpectedEof"
+    elif got.variant == "StreamHeaderMismatch":
+        # reference field: bytes: Vec<u8>; the ABI packs the 6 bytes LE
+        body = stream[4:10]
+        assert got.kind == want_oracle.kind
+        assert got.fields["bytes"] == int.from_bytes(body, "little")
     else:
         assert got.kind == want_oracle.kind
         nfields = len(got.fields)
