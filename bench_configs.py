@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Secondary benchmarks: BASELINE.json configs 3 and 5 (bench.py is the
+headline config 2).  One JSON line per config on stdout.
+
+  cfg3  FrameEncoder/FrameDecoder (framing + CRC32C kernel) on seeded
+        synthetic English-like text, device resident.  Text: tokens of the
+        four corpus text files drawn i.i.d. from their unigram distribution
+        (torch.multinomial, seed 0x5EED5A4D), single spaces, a newline where a
+        token crosses a 73-byte boundary; a period of --period-mib is generated
+        on the device and tiled to --gib.
+  cfg5  incompressible path: fireworks.jpeg as independent raw streams tiled
+        to --gib (literal fast path; the one workload near the HBM roofline).
+"""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+GIB = float(1 << 30)
+
+
+def synth_text(dev, period_bytes, seed=0x5EED5A4D):
+    import oracle_lib as O
+    words = []
+    for name in ("alice29.txt", "asyoulik.txt", "lcet10.txt", "plrabn12.txt"):
+        words += (O.CORPUS / name).read_bytes().split()
+    vocab, counts = np.unique(np.array(words, dtype=object), return_counts=True)
+    maxlen = max(len(w) for w in vocab)
+    table = np.zeros((len(vocab), maxlen), dtype=np.uint8)
+    lens = np.zeros(len(vocab), dtype=np.int64)
+    for i, w in enumerate(vocab):
+        table[i, :len(w)] = np.frombuffer(w, dtype=np.uint8)
+        lens[i] = len(w)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    p = torch.from_numpy(counts.astype(np.float64)).to(dev)
+    mean_len = float((lens * counts).sum() / counts.sum()) + 1.0
+    ntok = int(period_bytes / mean_len * 1.02) + 16
+    ids = torch.multinomial(p, ntok, replacement=True, generator=g)
+    d_lens = torch.from_numpy(lens).to(dev)[ids] + 1        # token + separator
+    ends = torch.cumsum(d_lens, 0)
+    starts = ends - d_lens
+    total = int(ends[-1].item())
+    out = torch.full((total,), 32, dtype=torch.uint8, device=dev)  # spaces
+    d_table = torch.from_numpy(table).to(dev)
+    for k in range(maxlen):                                   # k-th char
+        m = (d_lens - 1) > k
+        out[starts[m] + k] = d_table[ids[m], k]
+    nl = (starts // 73) != ((ends - 1) // 73)
+    out[ends[nl] - 1] = 10
+    return out[:period_bytes].contiguous()
+
+
+def time_it(fn, steps, ctx):
+    fn()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def cfg3(args, ctx, dev):
+    from rust_snappy_amd import frame
+    import oracle_lib as O
+    period = synth_text(dev, int(args.period_mib * (1 << 20)))
+    reps = max(1, int(args.gib * GIB / period.numel()))
+    data = period.repeat(reps)
+    n = data.numel()
+    out, flen, index = frame.compress_device(ctx, data, want_index=True)
+    # parity: the first 4 MiB against the oracle's restatement of
+    # write::FrameEncoder, chunk for chunk; every period equal to period 0
+    head = data[:4 << 20].cpu().numpy().tobytes()
+    want = O.frame_compress(head)
+    k = (4 << 20) // 65536
+    cut = int(index[k].item())
+    assert out[:cut].cpu().numpy().tobytes() == want[:cut], "framed bytes differ"
+    back, m = frame.decompress_device(ctx, out, flen, index=index, out_cap=n)
+    assert m == n and bool((back[:n] == data).all()), "frame round trip"
+    import ctypes as C
+    from rust_snappy_amd import _lib, raw
+    L = _lib.load()
+    out_len = torch.zeros(1, dtype=torch.int64, device=dev)
+    err = torch.zeros(32, dtype=torch.uint8, device=dev)
+    cap = frame.frame_max_len(n)
+
+    def enc():
+        rc = L.snapmi_frame_compress(ctx._h, C.c_void_p(data.data_ptr()), n,
+                                     C.c_void_p(out.data_ptr()), cap,
+                                     C.c_void_p(out_len.data_ptr()),
+                                     C.c_void_p(index.data_ptr()))
+        assert rc == 0
+
+    def dec():
+        rc = L.snapmi_frame_decompress(ctx._h, C.c_void_p(out.data_ptr()),
+                                       flen, C.c_void_p(back.data_ptr()), n,
+                                       C.c_void_p(out_len.data_ptr()),
+                                       C.c_void_p(err.data_ptr()),
+                                       C.c_void_p(index.data_ptr()),
+                                       index.numel() - 1)
+        assert rc == 0
+
+    te = time_it(enc, args.steps, ctx)
+    td = time_it(dec, args.steps, ctx)
+    stored = 0
+    return {"config": "cfg3 framed synthetic text", "gib": round(n / GIB, 3),
+            "chunks": index.numel() - 1, "ratio": round(flen / n, 4),
+            "frame_encode_gibs": round(n / GIB / te, 2),
+            "frame_decode_gibs": round(n / GIB / td, 2),
+            "encode_ms": round(te * 1e3, 2), "decode_ms": round(td * 1e3, 2),
+            "decode_uses_side_index": True}
+
+
+def cfg5(args, ctx, dev):
+    from rust_snappy_amd import batch, raw
+    import oracle_lib as O
+    jpg = (O.CORPUS / "fireworks.jpeg").read_bytes()
+    reps = max(1, int(args.gib * GIB / len(jpg)))
+    stride = (len(jpg) + 15) // 16 * 16
+    one = np.zeros(stride, dtype=np.uint8)
+    one[:len(jpg)] = np.frombuffer(jpg, dtype=np.uint8)
+    data = torch.from_numpy(one).to(dev).repeat(reps)
+    offs = np.arange(reps, dtype=np.int64) * stride
+    lens = np.full(reps, len(jpg), dtype=np.int64)
+    src = batch.StreamBatch(data, offs, lens)
+    cap = raw.max_compress_len(len(jpg))
+    comp = batch.StreamBatch.empty(np.full(reps, cap, dtype=np.int64), dev)
+    clens = torch.zeros(reps, dtype=torch.int64, device=dev)
+    back = batch.StreamBatch.empty(lens, dev)
+    blens = torch.zeros(reps, dtype=torch.int64, device=dev)
+
+    def enc():
+        raw.compress_batch(ctx, src.d_ptrs, src.d_lens, comp.d_ptrs,
+                           comp.d_lens, clens, None, host_in_lens=src.h_lens)
+
+    def dec():
+        raw.decompress_batch(ctx, comp.d_ptrs, clens, back.d_ptrs,
+                             back.d_lens, blens, None)
+
+    enc()
+    ctx.synchronize()
+    want = O.compress(jpg)
+    assert comp.stream_bytes(0, int(clens[0])) == want
+    assert comp.stream_bytes(reps - 1, int(clens[-1])) == want
+    te = time_it(enc, args.steps, ctx)
+    td = time_it(dec, args.steps, ctx)
+    assert back.stream_bytes(reps // 2) == jpg
+    n = reps * len(jpg)
+    c = reps * len(want)
+    return {"config": "cfg5 incompressible (fireworks.jpeg tiles)",
+            "gib": round(n / GIB, 3), "streams": reps,
+            "compress_gibs": round(n / GIB / te, 2),
+            "decompress_gibs": round(n / GIB / td, 2),
+            "compress_hbm_frac": round((n + c) / te / 8e12, 4),
+            "decompress_hbm_frac": round((n + c) / td / 8e12, 4),
+            "compress_ms": round(te * 1e3, 2),
+            "decompress_ms": round(td * 1e3, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gib", type=float, default=8.0)
+    ap.add_argument("--period-mib", type=float, default=256.0)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    import __graft_entry__ as g
+    g.build()
+    from rust_snappy_amd import raw
+    dev = torch.device("cuda", 0)
+    ctx = raw.Context(0)
+    for name, fn in (("cfg3", cfg3), ("cfg5", cfg5)):
+        if args.only and args.only != name:
+            continue
+        print(json.dumps(fn(args, ctx, dev)), flush=True)
+
+
+if __name__ == "__main__":
+    main()
