@@ -22,6 +22,13 @@
 
 using namespace snapmi;
 
+// waves per CU of the lane-per-block match finder (SNAPMI_LANE_WAVES)
+static const uint32_t kLaneWavesPerCU = [] {
+    const char *e = getenv("SNAPMI_LANE_WAVES");
+    int v = e ? atoi(e) : 4;
+    return (uint32_t)(v < 1 ? 1 : (v > 32 ? 32 : v));
+}();
+
 namespace {
 
 void set_err(snapmi_error *e, int kind, uint64_t a = 0, uint64_t b = 0,
@@ -88,6 +95,8 @@ int snapmi_ctx_create(int device, void *hip_stream, snapmi_ctx **out)
             return SNAPMI_E_DEVICE;
         }
         ctx->num_cus = prop.multiProcessorCount;
+        if (const char *m = getenv("SNAPMI_COMPRESS"))
+            ctx->compress_mode = strcmp(m, "waves") == 0 ? 0 : 1;
     }
     if (hip_stream) {
         ctx->stream = (hipStream_t)hip_stream;
@@ -120,7 +129,9 @@ void snapmi_ctx_destroy(snapmi_ctx *ctx)
                       &ctx->blk_off, &ctx->slots, &ctx->st_in, &ctx->st_out,
                       &ctx->st_desc, &ctx->st_prof, &ctx->ticket,
                       &ctx->order, &ctx->fr_tables, &ctx->fr_desc,
-                      &ctx->fr_meta, &ctx->fr_scan, &ctx->fr_slots})
+                      &ctx->fr_meta, &ctx->fr_scan, &ctx->fr_slots,
+                      &ctx->tokens, &ctx->ntok, &ctx->lane_tables,
+                      &ctx->lane_epochs})
         if (b->p)
             (void)hipFree(b->p);
     for (auto &ev : ctx->ev)
@@ -258,6 +269,44 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     a.host_blocks = (uint32_t)blocks;
     a.host_slots = (uint32_t)slots;
     a.ticket = (uint32_t *)ctx->ticket.p;
+    a.tokens = nullptr;
+    a.ntok = nullptr;
+    a.lane_tables = nullptr;
+    a.lane_epochs = nullptr;
+    a.n_lanes = 0;
+    const bool lanes_mode = ctx->compress_mode == 1 && blocks > 0;
+    if (lanes_mode) {
+        // waves of the lane-per-block match finder: enough chains in flight
+        // to saturate the memory system (2 per CU measured), never more
+        // lanes than blocks
+        uint64_t waves = (uint64_t)ctx->num_cus * kLaneWavesPerCU;
+        const uint64_t need = (blocks + 63) / 64;
+        if (waves > need)
+            waves = need;
+        const uint32_t lanes = (uint32_t)waves * 64;
+        if (lanes > ctx->n_lanes) { // tables must start zeroed (epoch 0)
+            if ((rc = reserve(ctx, ctx->lane_tables,
+                              (size_t)lanes * kMaxTable * sizeof(uint32_t))) ||
+                (rc = reserve(ctx, ctx->lane_epochs,
+                              (size_t)lanes * sizeof(uint32_t))))
+                return rc;
+            HIP_TRY(ctx, hipMemsetAsync(ctx->lane_tables.p, 0,
+                                        (size_t)lanes * kMaxTable * 4,
+                                        ctx->stream));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->lane_epochs.p, 0,
+                                        (size_t)lanes * 4, ctx->stream));
+            ctx->n_lanes = lanes;
+        }
+        if ((rc = reserve(ctx, ctx->tokens,
+                          (size_t)blocks * kMaxTokens * sizeof(uint64_t))) ||
+            (rc = reserve(ctx, ctx->ntok, (size_t)blocks * sizeof(uint32_t))))
+            return rc;
+        a.tokens = (unsigned long long *)ctx->tokens.p;
+        a.ntok = (uint32_t *)ctx->ntok.p;
+        a.lane_tables = (uint32_t *)ctx->lane_tables.p;
+        a.lane_epochs = (uint32_t *)ctx->lane_epochs.p;
+        a.n_lanes = lanes;
+    }
     a.prof = nullptr;
 #ifdef SNAPMI_PROFILE
     if ((rc = reserve(ctx, ctx->st_prof, 16 * sizeof(uint64_t))))
@@ -272,7 +321,13 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], s));
     hipLaunchKernelGGL(k_plan_compress, dim3(1), dim3(1024), 0, s, a);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], s));
-    if (blocks) {
+    if (lanes_mode) {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->ticket.p, 0, 64, s));
+        hipLaunchKernelGGL(k_match_blocks, dim3(a.n_lanes / 64), dim3(64), 0,
+                           s, a);
+        hipLaunchKernelGGL(k_encode_tokens, dim3((uint32_t)blocks), dim3(64),
+                           0, s, a);
+    } else if (blocks) {
         // persistent: one 5-wave workgroup per CU (all of its LDS), each
         // wavefront pulls blocks from the ticket counter
         const uint64_t want = (blocks + kCompressWaves - 1) / kCompressWaves;

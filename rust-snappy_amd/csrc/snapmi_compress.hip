@@ -617,6 +617,267 @@ __global__ __launch_bounds__(kCompressWaves * 64) void k_compress_blocks(
 }
 
 // ---------------------------------------------------------------------
+// K1b: lane-per-block match finder.
+//
+// The wavefront-per-block kernel above is bound by a dependent chain per
+// emitted copy and by "five tables per CU".  This kernel turns the problem
+// around: every LANE runs the reference's sequential parse (src/compress.rs:
+// 195-317) on its own block, with its own hash table in HBM, and a wave
+// advances 64 independent chains per instruction.  Each step is two
+// dependent random accesses (table, candidate), but with tens of thousands
+// of chains in flight the memory system, not the latency, sets the rate
+// (measured on MI355X: ~1.6e10 lane-steps/s, tests/hw/random_rmw.hip).
+//   * table entries are (epoch << 16 | position): a table is never zeroed,
+//     an entry of another epoch reads as 0 (= the reference's fresh table);
+//     epochs persist in the context across launches;
+//   * a lane that finishes its block takes the next one from the ticket
+//     counter, so lanes stay busy whatever the mix of block costs;
+//   * the lane only records tokens (literal length, copy length, offset);
+//     k_encode_tokens below turns them into Snappy elements, one wavefront
+//     per block, 64 tokens at a time.
+// ---------------------------------------------------------------------
+__device__ __forceinline__ uint32_t ld32p(gcptr p)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+__device__ __forceinline__ uint64_t ld64p(gcptr p)
+{
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+
+__global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
+{
+    const uint32_t g = blockIdx.x * 64 + threadIdx.x; // lane id in the grid
+    typedef __attribute__((address_space(1))) uint32_t g_u32;
+    typedef __attribute__((address_space(1))) unsigned long long g_u64;
+    g_u32 *const tab = (g_u32 *)a.lane_tables + (uint64_t)g * kMaxTable;
+    uint32_t epoch = a.lane_epochs[g];
+    uint32_t nblocks = a.blk_first[a.n_streams];
+    if (nblocks > a.host_blocks)
+        nblocks = a.host_blocks;
+
+    // per-lane block state
+    bool have = false, out_of_work = false;
+    uint32_t b = 0, n = 0, s_limit = 0, shift = 0;
+    uint32_t s = 0, s_next = 0, skip = 0, next_hash = 0, next_emit = 0;
+    uint32_t ntok = 0;
+    bool chain = false;
+    gcptr src = nullptr;
+    g_u64 *tok = nullptr;
+
+    for (;;) {
+        if (!have && !out_of_work) {
+            b = atomicAdd(a.ticket, 1u);
+            if (b >= nblocks) {
+                out_of_work = true;
+            } else {
+                // stream lookup: blk_first[st] <= b < blk_first[st + 1]
+                uint32_t lo = 0, hi = a.n_streams;
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (a.blk_first[mid] <= b)
+                        lo = mid;
+                    else
+                        hi = mid;
+                }
+                const uint32_t k = b - a.blk_first[lo];
+                const uint64_t total = a.in_lens[lo];
+                const uint64_t boff = (uint64_t)k * kMaxBlock;
+                src = (gcptr)a.in_ptrs[lo] + boff;
+                n = total - boff < kMaxBlock ? (uint32_t)(total - boff)
+                                             : kMaxBlock;
+                tok = (g_u64 *)a.tokens + (uint64_t)b * kMaxTokens;
+                ntok = 0;
+                next_emit = 0;
+                have = true;
+                if (n < kMinNonLiteral) { // src/compress.rs:140-146
+                    tok[0] = (unsigned long long)n;
+                    a.ntok[b] = 1;
+                    have = false;
+                } else {
+                    // fresh table = new epoch (src/compress.rs:491-518)
+                    epoch = (epoch + 1) & 0xFFFFu;
+                    if (epoch == 0) { // wrapped: really clear this lane's table
+                        for (uint32_t i = 0; i < kMaxTable; i++)
+                            tab[i] = 0;
+                        epoch = 1;
+                    }
+                    shift = 32 - 8;
+                    uint32_t tsize = 256;
+                    while (tsize < kMaxTable && tsize < n) {
+                        shift--;
+                        tsize *= 2;
+                    }
+                    s_limit = n - kInputMargin;
+                    s_next = 1;
+                    skip = 32;
+                    next_hash = hash32(ld32p(src + 1), shift);
+                    chain = false;
+                }
+            }
+        }
+        if (__ballot(have) == 0) {
+            if (__ballot(!out_of_work) == 0)
+                break;
+            continue;
+        }
+        if (!have)
+            continue;
+
+        // ---- one table lookup of the reference's parse --------------------
+        uint32_t pos, cur32, hcur;
+        uint64_t x = 0;
+        bool finished = false;
+        if (chain) { // src/compress.rs:290-301
+            x = ld64p(src + s - 1);
+            tab[hash32((uint32_t)x, shift)] = (epoch << 16) | (s - 1);
+            cur32 = (uint32_t)(x >> 8);
+            hcur = hash32(cur32, shift);
+            pos = s;
+        } else { // src/compress.rs:207-226
+            s = s_next;
+            const uint32_t step = skip >> 5;
+            s_next = s + step;
+            skip += step;
+            pos = s;
+            if (s_next > s_limit) {
+                finished = true;
+                hcur = 0;
+                cur32 = 0;
+            } else {
+                hcur = next_hash;
+                cur32 = ld32p(src + s);
+                next_hash = hash32(ld32p(src + s_next), shift);
+            }
+        }
+        if (!finished) {
+            const uint32_t e = tab[hcur];
+            const uint32_t cand = (e >> 16) == epoch ? (e & 0xFFFFu) : 0;
+            tab[hcur] = (epoch << 16) | pos;
+            if (ld32p(src + cand) == cur32) {
+                // match: extend to the block end (src/compress.rs:378-412)
+                uint32_t p = pos + 4, c = cand + 4;
+                bool open = true;
+                while (open && p + 8 <= n) {
+                    const uint64_t z = ld64p(src + p) ^ ld64p(src + c);
+                    if (z) {
+                        p += (uint32_t)__builtin_ctzll(z) >> 3;
+                        open = false;
+                    } else {
+                        p += 8;
+                        c += 8;
+                    }
+                }
+                while (open && p < n && src[p] == src[c]) {
+                    p++;
+                    c++;
+                }
+                // token: literal next_emit..pos, copy (pos - cand, p - pos)
+                tok[ntok++] = (unsigned long long)(pos - next_emit) |
+                              ((unsigned long long)(p - pos) << 17) |
+                              ((unsigned long long)(pos - cand) << 33);
+                s = p;
+                next_emit = p;
+                chain = true;
+                if (s >= s_limit) // src/compress.rs:275-277
+                    finished = true;
+            } else if (chain) { // src/compress.rs:310-312
+                next_hash = hash32((uint32_t)(x >> 16), shift);
+                s_next = s + 1;
+                skip = 32;
+                chain = false;
+            }
+        }
+        if (finished) { // done(): src/compress.rs:417-426
+            if (next_emit < n)
+                tok[ntok++] = (unsigned long long)(n - next_emit);
+            a.ntok[b] = ntok;
+            have = false;
+        }
+    }
+    a.lane_epochs[g] = epoch;
+}
+
+// ---------------------------------------------------------------------
+// K1c: tokens -> Snappy elements, one wavefront per block, 64 tokens per
+// pass (TokenSink::flush: reference emit_literal / emit_copy).
+// ---------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_encode_tokens(CompressArgs a)
+{
+    const uint32_t lane = threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    uint32_t nblocks = a.blk_first[a.n_streams];
+    if (nblocks > a.host_blocks)
+        nblocks = a.host_blocks;
+    if (b >= nblocks)
+        return;
+    uint32_t lo = 0, hi = a.n_streams;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a.blk_first[mid] <= b)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const uint32_t st = lo;
+    const uint32_t k = b - a.blk_first[st];
+    const uint64_t total = a.in_lens[st];
+    const uint64_t boff = (uint64_t)k * kMaxBlock;
+    gcptr src = (gcptr)a.in_ptrs[st] + boff;
+    const uint32_t n =
+        total - boff < kMaxBlock ? (uint32_t)(total - boff) : kMaxBlock;
+    gptr dst;
+    if (k == 0) {
+        dst = (gptr)a.out_ptrs[st];
+        if (lane == 0) { // varint(total): src/compress.rs:128
+            uint64_t v = total;
+            uint32_t i = 0;
+            while (v >= 0x80) {
+                dst[i++] = (uint8_t)v | 0x80;
+                v >>= 7;
+            }
+            dst[i] = (uint8_t)v;
+        }
+        dst += varint_len(total);
+    } else {
+        const uint32_t slot = a.slot_first[st] + k - 1;
+        if (slot >= a.host_slots)
+            return;
+        dst = (gptr)a.scratch + (uint64_t)slot * kSlotBytes;
+    }
+    TokenSink out;
+    out.init(src, n, dst, lane);
+    typedef __attribute__((address_space(1))) unsigned long long g_u64;
+    const g_u64 *tok = (const g_u64 *)a.tokens + (uint64_t)b * kMaxTokens;
+    const uint32_t count = a.ntok[b];
+    uint32_t pos_base = 0;
+    for (uint32_t t0 = 0; t0 < count; t0 += kWave) {
+        const uint32_t m = count - t0 < kWave ? count - t0 : kWave;
+        uint32_t L = 0, C = 0, O = 0;
+        if (lane < m) {
+            const unsigned long long t = tok[t0 + lane];
+            L = (uint32_t)t & 0x1FFFFu;
+            C = (uint32_t)(t >> 17) & 0xFFFFu;
+            O = (uint32_t)(t >> 33) & 0xFFFFu;
+        }
+        const uint32_t span = L + C;
+        const uint32_t incl = wave_inclusive_scan(span);
+        const uint32_t P = pos_base + incl - span; // literal start
+        pos_base += rdlane(incl, kWave - 1);
+        out.a = (L & 0xFFFFu) | (O << 16);
+        out.b = C | (P << 16);
+        out.t = m;
+        out.flush();
+    }
+    if (lane == 0)
+        a.blk_size[b] = out.d;
+}
+
+// ---------------------------------------------------------------------
 // Plan: per-stream validation + block table.  One workgroup of 1024 threads
 // walks the streams 1024 at a time with a workgroup-wide exclusive scan.
 // Reference checks: src/compress.rs:104-125.

@@ -26,6 +26,10 @@ struct snapmi_ctx {
     std::string last_error;
     // grow-only device scratch of the raw codec
     snapmi::DevBuf blk_first, slot_first, blk_size, blk_off, slots;
+    // lane-per-block match finder: tokens, token counts, HBM hash tables
+    snapmi::DevBuf tokens, ntok, lane_tables, lane_epochs;
+    uint32_t n_lanes = 0;
+    int compress_mode = 1; // 1 = lanes (k_match_blocks), 0 = waves
     // staging for the host-pointer (scalar) entry points
     snapmi::DevBuf st_in, st_out, st_desc, st_prof, ticket, order;
     // frame layer scratch (snapmi_frame.hip)

@@ -26,6 +26,13 @@ struct CompressArgs {
     uint32_t host_blocks; // launch geometry computed from the host lengths
     uint32_t host_slots;
     uint32_t *ticket; // device-wide block ticket counter, zeroed per launch
+    // lane-per-block match finder (k_match_blocks): token stream per block,
+    // per-lane epoch-tagged hash tables in HBM
+    unsigned long long *tokens; // [blocks * kMaxTokens]
+    uint32_t *ntok;             // [blocks]
+    uint32_t *lane_tables;      // [lanes * kMaxTable] (epoch << 16 | position)
+    uint32_t *lane_epochs;      // [lanes]
+    uint32_t n_lanes;
     // experiment builds (-DSNAPMI_PROFILE) only: 16 u64 cycle counters
     unsigned long long *prof;
 };
@@ -33,6 +40,9 @@ struct CompressArgs {
 // wavefronts (= hash tables) per persistent compress workgroup: 5 x 32 KiB
 // is all of a CU's LDS
 constexpr uint32_t kCompressWaves = 5;
+// most tokens one block can produce: every token but the last ends in a copy
+// of >= 4 bytes
+constexpr uint32_t kMaxTokens = (1u << 16) / 4 + 1;
 
 // Batch of raw streams to decompress.
 struct DecompressArgs {
@@ -54,6 +64,8 @@ struct DecompressArgs {
 
 __global__ void k_plan_compress(CompressArgs a);
 __global__ void k_compress_blocks(CompressArgs a);
+__global__ void k_match_blocks(CompressArgs a);
+__global__ void k_encode_tokens(CompressArgs a);
 __global__ void k_scan_sizes(CompressArgs a);
 __global__ void k_compact(CompressArgs a);
 
