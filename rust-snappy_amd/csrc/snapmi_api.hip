@@ -25,8 +25,16 @@ using namespace snapmi;
 // waves per CU of the lane-per-block match finder (SNAPMI_LANE_WAVES)
 static const uint32_t kLaneWavesPerCU = [] {
     const char *e = getenv("SNAPMI_LANE_WAVES");
-    int v = e ? atoi(e) : 4;
+    int v = e ? atoi(e) : 12;
     return (uint32_t)(v < 1 ? 1 : (v > 32 ? 32 : v));
+}();
+
+// fraction of a large batch the lane kernel may claim up front when both
+// compress kernels run (SNAPMI_LANE_SHARE)
+static const double kLaneShare = [] {
+    const char *e = getenv("SNAPMI_LANE_SHARE");
+    double v = e ? atof(e) : 1.0;
+    return v < 0.05 ? 0.05 : (v > 1.0 ? 1.0 : v);
 }();
 
 namespace {
@@ -96,7 +104,9 @@ int snapmi_ctx_create(int device, void *hip_stream, snapmi_ctx **out)
         }
         ctx->num_cus = prop.multiProcessorCount;
         if (const char *m = getenv("SNAPMI_COMPRESS"))
-            ctx->compress_mode = strcmp(m, "waves") == 0 ? 0 : 1;
+            ctx->compress_mode = strcmp(m, "waves") == 0
+                                     ? 0
+                                     : (strcmp(m, "lanes") == 0 ? 1 : 2);
     }
     if (hip_stream) {
         ctx->stream = (hipStream_t)hip_stream;
@@ -113,6 +123,15 @@ int snapmi_ctx_create(int device, void *hip_stream, snapmi_ctx **out)
             snapmi_ctx_destroy(ctx);
             return SNAPMI_E_DEVICE;
         }
+    }
+    if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) !=
+            hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) !=
+            hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) !=
+            hipSuccess) {
+        snapmi_ctx_destroy(ctx);
+        return SNAPMI_E_DEVICE;
     }
     *out = ctx;
     return SNAPMI_OK;
@@ -137,6 +156,14 @@ void snapmi_ctx_destroy(snapmi_ctx *ctx)
     for (auto &ev : ctx->ev)
         if (ev)
             (void)hipEventDestroy(ev);
+    if (ctx->stream2) {
+        (void)hipStreamSynchronize(ctx->stream2);
+        (void)hipStreamDestroy(ctx->stream2);
+    }
+    if (ctx->ev_fork)
+        (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join)
+        (void)hipEventDestroy(ctx->ev_join);
     if (ctx->owns_stream && ctx->stream)
         (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -274,15 +301,26 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     a.lane_tables = nullptr;
     a.lane_epochs = nullptr;
     a.n_lanes = 0;
-    const bool lanes_mode = ctx->compress_mode == 1 && blocks > 0;
+    // Small batches are latency-bound: the wavefront kernel alone finishes a
+    // block in ~2 ms, a lane needs ~10x that.  Large batches run both
+    // kernels at once (they use disjoint resources: LDS + few waves vs.
+    // memory-level parallelism) on the two ends of the block list.
+    const bool big = blocks >= 4096;
+    const bool lanes_mode = blocks > 0 && ctx->compress_mode != 0 && big;
+    const bool waves_mode =
+        blocks > 0 && (ctx->compress_mode != 1 || !lanes_mode);
     if (lanes_mode) {
         // waves of the lane-per-block match finder: enough chains in flight
         // to saturate the memory system (2 per CU measured), never more
         // lanes than blocks
         uint64_t waves = (uint64_t)ctx->num_cus * kLaneWavesPerCU;
-        const uint64_t need = (blocks + 63) / 64;
+        // when the wavefront kernel runs beside it, leave it a share of the
+        // blocks: lanes claim a block each at once, so cap lanes below blocks
+        const uint64_t share =
+            waves_mode ? (uint64_t)(blocks * kLaneShare) : blocks;
+        const uint64_t need = (share + 63) / 64;
         if (waves > need)
-            waves = need;
+            waves = need ? need : 1;
         const uint32_t lanes = (uint32_t)waves * 64;
         if (lanes > ctx->n_lanes) { // tables must start zeroed (epoch 0)
             if ((rc = reserve(ctx, ctx->lane_tables,
@@ -321,25 +359,34 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], s));
     hipLaunchKernelGGL(k_plan_compress, dim3(1), dim3(1024), 0, s, a);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], s));
-    if (lanes_mode) {
+    if (blocks) {
         HIP_TRY(ctx, hipMemsetAsync(ctx->ticket.p, 0, 64, s));
-        hipLaunchKernelGGL(k_match_blocks, dim3(a.n_lanes / 64), dim3(64), 0,
-                           s, a);
-        hipLaunchKernelGGL(k_encode_tokens, dim3((uint32_t)blocks), dim3(64),
-                           0, s, a);
-    } else if (blocks) {
-        // persistent: one 5-wave workgroup per CU (all of its LDS), each
-        // wavefront pulls blocks from the ticket counter
-        const uint64_t want = (blocks + kCompressWaves - 1) / kCompressWaves;
-#ifdef SNAPMI_NOLOOP
-        const uint32_t wgs = (uint32_t)want;
-#else
-        const uint32_t wgs =
-            (uint32_t)(want < (uint64_t)ctx->num_cus ? want : ctx->num_cus);
-#endif
-        HIP_TRY(ctx, hipMemsetAsync(ctx->ticket.p, 0, 64, s));
-        hipLaunchKernelGGL(k_compress_blocks, dim3(wgs),
-                           dim3(kCompressWaves * 64), 0, s, a);
+        hipStream_t ws = s; // stream of the wavefront kernel
+        if (waves_mode && lanes_mode) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+            ws = ctx->stream2;
+        }
+        if (waves_mode) {
+            // persistent: one 5-wave workgroup per CU (all of its LDS), each
+            // wavefront pulls blocks from the back of the ticket
+            const uint64_t want =
+                (blocks + kCompressWaves - 1) / kCompressWaves;
+            const uint32_t wgs = (uint32_t)(
+                want < (uint64_t)ctx->num_cus ? want : ctx->num_cus);
+            hipLaunchKernelGGL(k_compress_blocks, dim3(wgs),
+                               dim3(kCompressWaves * 64), 0, ws, a);
+        }
+        if (lanes_mode) {
+            hipLaunchKernelGGL(k_match_blocks, dim3(a.n_lanes / 64), dim3(64),
+                               0, s, a);
+            if (waves_mode) {
+                HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+                HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+            }
+            hipLaunchKernelGGL(k_encode_tokens, dim3((uint32_t)blocks),
+                               dim3(64), 0, s, a);
+        }
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], s));
     if (blocks) {

@@ -561,13 +561,24 @@ __device__ __forceinline__ void compress_one_block(
 #endif
 }
 
-// Device-wide block ticket: lane 0 takes it, the wavefront shares it.
-__device__ __noinline__ uint32_t next_ticket(uint32_t *ticket, uint32_t lane)
+// Device-wide block ticket, one 64-bit word: low half = blocks claimed from
+// the front of the list (lane-per-block kernel), high half = blocks claimed
+// from the back (this wavefront-per-block kernel).  The two kernels run
+// concurrently and meet in the middle; a claim is valid while front + back
+// < nblocks.  Lane 0 takes the ticket, the wavefront shares it.  Returns the
+// block index or 0xFFFFFFFF.
+__device__ __noinline__ uint32_t next_ticket(uint32_t *ticket, uint32_t lane,
+                                             uint32_t nblocks)
 {
-    uint32_t tk = 0;
-    if (lane == 0)
-        tk = atomicAdd(ticket, 1u);
-    return uni(tk);
+    uint32_t blk = 0;
+    if (lane == 0) {
+        const unsigned long long old =
+            atomicAdd((unsigned long long *)ticket, 1ull << 32);
+        const uint32_t front = (uint32_t)old, back = (uint32_t)(old >> 32);
+        blk = (uint64_t)front + back < nblocks ? nblocks - 1 - back
+                                               : 0xFFFFFFFFu;
+    }
+    return uni(blk);
 }
 
 // ---------------------------------------------------------------------
@@ -608,10 +619,12 @@ __global__ __launch_bounds__(kCompressWaves * 64) void k_compress_blocks(
     // one ticket per wavefront per block
     // (the helper's result comes back in a VGPR: re-pin it to an SGPR so the
     // whole block state stays scalar)
-    uint32_t b = uni(next_ticket(a.ticket, lane));
-    while (b < nblocks) {
+    uint32_t b = uni(next_ticket(a.ticket, lane, nblocks));
+    while (b != 0xFFFFFFFFu) {
+        if (lane == 0 && a.ntok)
+            a.ntok[b] = 0xFFFFFFFFu; // encoded here, not by k_encode_tokens
         compress_one_block(a, b, lane, table, tbase, c2, c3, cB, cBn);
-        b = uni(next_ticket(a.ticket, lane));
+        b = uni(next_ticket(a.ticket, lane, nblocks));
     }
 #endif
 }
@@ -671,8 +684,10 @@ __global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
 
     for (;;) {
         if (!have && !out_of_work) {
-            b = atomicAdd(a.ticket, 1u);
-            if (b >= nblocks) {
+            const unsigned long long old =
+                atomicAdd((unsigned long long *)a.ticket, 1ull);
+            b = (uint32_t)old;
+            if ((uint64_t)b + (uint32_t)(old >> 32) >= nblocks) {
                 out_of_work = true;
             } else {
                 // stream lookup: blk_first[st] <= b < blk_first[st + 1]
@@ -815,6 +830,8 @@ __global__ __launch_bounds__(64) void k_encode_tokens(CompressArgs a)
         nblocks = a.host_blocks;
     if (b >= nblocks)
         return;
+    if (a.ntok[b] == 0xFFFFFFFFu)
+        return; // this block was encoded by k_compress_blocks
     uint32_t lo = 0, hi = a.n_streams;
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;

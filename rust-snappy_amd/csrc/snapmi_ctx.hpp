@@ -29,7 +29,13 @@ struct snapmi_ctx {
     // lane-per-block match finder: tokens, token counts, HBM hash tables
     snapmi::DevBuf tokens, ntok, lane_tables, lane_epochs;
     uint32_t n_lanes = 0;
-    int compress_mode = 1; // 1 = lanes (k_match_blocks), 0 = waves
+    // SNAPMI_COMPRESS=waves|lanes|both: 0 = wavefront kernel only, 1 = lane
+    // kernel (wavefront kernel for small batches), 2 = on large batches both
+    // kernels at once, sharing one two-ended ticket (measured 180 vs 204 ms
+    // at cfg2 against mode 1; small batches: wavefront kernel only)
+    int compress_mode = 2;
+    hipStream_t stream2 = nullptr; // the wavefront kernel's side stream
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // staging for the host-pointer (scalar) entry points
     snapmi::DevBuf st_in, st_out, st_desc, st_prof, ticket, order;
     // frame layer scratch (snapmi_frame.hip)
