@@ -108,6 +108,16 @@ const char *snapmi_last_error(const snapmi_ctx *ctx);
 void *snapmi_ctx_stream(const snapmi_ctx *ctx);
 /* "snapmi <version> gfx950" */
 const char *snapmi_version(void);
+/*
+ * Tuning knobs (results never depend on them, only speed):
+ *   "compress_mode"        0 wavefront-per-block kernel only, 1 lane-per-block
+ *                          kernel on large batches, 2 both at once (default)
+ *   "lane_min_blocks"      batches with at least this many 64 KiB blocks use
+ *                          the lane-per-block kernel (default 4096)
+ *   "lane_waves_per_cu"    lanes in flight = 64 x this x CUs (default 12)
+ * Returns SNAPMI_E_ARGUMENT for an unknown name.
+ */
+int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value);
 
 /* ------------------------------------------------------------------ */
 /* 2. Scalar mirrors of snap::raw (host buffers; H2D + kernels + D2H).  */
@@ -194,6 +204,9 @@ typedef struct snapmi_timing {
     float compact_ms;  /* compress only: gather of blocks 1.. into place   */
     float total_ms;    /* first event to last event                        */
     uint64_t codec_launches; /* launches of the dominant kernel            */
+    float dominant_ms; /* the single dominant kernel alone: k_match_blocks,
+                          k_compress_blocks or k_decompress_streams         */
+    float reserved;
 } snapmi_timing;
 int snapmi_last_timing(snapmi_ctx *ctx, snapmi_timing *out);
 

@@ -23,7 +23,8 @@ class SnapmiError(C.Structure):
 class SnapmiTiming(C.Structure):
     _fields_ = [("plan_ms", C.c_float), ("codec_ms", C.c_float),
                 ("compact_ms", C.c_float), ("total_ms", C.c_float),
-                ("codec_launches", C.c_uint64)]
+                ("codec_launches", C.c_uint64), ("dominant_ms", C.c_float),
+                ("reserved", C.c_float)]
 
 
 # every symbol include/snapmi.h declares: (name, restype, argtypes)
@@ -42,6 +43,7 @@ SYMBOLS = [
     ("snapmi_last_error", C.c_char_p, [_P]),
     ("snapmi_ctx_stream", _P, [_P]),
     ("snapmi_version", C.c_char_p, []),
+    ("snapmi_ctx_set_option", C.c_int, [_P, C.c_char_p, C.c_int64]),
     ("snapmi_max_compress_len", _SZ, [_SZ]),
     ("snapmi_decompress_len", C.c_int, [C.c_char_p, _SZ, _SZP, _ERRP]),
     ("snapmi_raw_compress", C.c_int,

@@ -22,12 +22,6 @@
 
 using namespace snapmi;
 
-// waves per CU of the lane-per-block match finder (SNAPMI_LANE_WAVES)
-static const uint32_t kLaneWavesPerCU = [] {
-    const char *e = getenv("SNAPMI_LANE_WAVES");
-    int v = e ? atoi(e) : 12;
-    return (uint32_t)(v < 1 ? 1 : (v > 32 ? 32 : v));
-}();
 
 // fraction of a large batch the lane kernel may claim up front when both
 // compress kernels run (SNAPMI_LANE_SHARE)
@@ -103,6 +97,10 @@ int snapmi_ctx_create(int device, void *hip_stream, snapmi_ctx **out)
             return SNAPMI_E_DEVICE;
         }
         ctx->num_cus = prop.multiProcessorCount;
+        if (const char *e = getenv("SNAPMI_LANE_WAVES")) {
+            const int v = atoi(e);
+            ctx->lane_waves_per_cu = (uint32_t)(v < 1 ? 1 : (v > 32 ? 32 : v));
+        }
         if (const char *m = getenv("SNAPMI_COMPRESS"))
             ctx->compress_mode = strcmp(m, "waves") == 0
                                      ? 0
@@ -167,6 +165,22 @@ void snapmi_ctx_destroy(snapmi_ctx *ctx)
     if (ctx->owns_stream && ctx->stream)
         (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value)
+{
+    if (!ctx || !name)
+        return SNAPMI_E_ARGUMENT;
+    if (strcmp(name, "compress_mode") == 0 && value >= 0 && value <= 2)
+        ctx->compress_mode = (int)value;
+    else if (strcmp(name, "lane_min_blocks") == 0 && value >= 1)
+        ctx->lane_min_blocks = (uint32_t)value;
+    else if (strcmp(name, "lane_waves_per_cu") == 0 && value >= 1 &&
+             value <= 32)
+        ctx->lane_waves_per_cu = (uint32_t)value;
+    else
+        return fail_ctx(ctx, SNAPMI_E_ARGUMENT, "unknown option %s", name);
+    return SNAPMI_OK;
 }
 
 const char *snapmi_last_error(const snapmi_ctx *ctx)
@@ -305,7 +319,7 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     // block in ~2 ms, a lane needs ~10x that.  Large batches run both
     // kernels at once (they use disjoint resources: LDS + few waves vs.
     // memory-level parallelism) on the two ends of the block list.
-    const bool big = blocks >= 4096;
+    const bool big = blocks >= ctx->lane_min_blocks;
     const bool lanes_mode = blocks > 0 && ctx->compress_mode != 0 && big;
     const bool waves_mode =
         blocks > 0 && (ctx->compress_mode != 1 || !lanes_mode);
@@ -313,7 +327,7 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
         // waves of the lane-per-block match finder: enough chains in flight
         // to saturate the memory system (2 per CU measured), never more
         // lanes than blocks
-        uint64_t waves = (uint64_t)ctx->num_cus * kLaneWavesPerCU;
+        uint64_t waves = (uint64_t)ctx->num_cus * ctx->lane_waves_per_cu;
         // when the wavefront kernel runs beside it, leave it a share of the
         // blocks: lanes claim a block each at once, so cap lanes below blocks
         const uint64_t share =
@@ -378,8 +392,10 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                                dim3(kCompressWaves * 64), 0, ws, a);
         }
         if (lanes_mode) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev[4], s));
             hipLaunchKernelGGL(k_match_blocks, dim3(a.n_lanes / 64), dim3(64),
                                0, s, a);
+            HIP_TRY(ctx, hipEventRecord(ctx->ev[5], s));
             if (waves_mode) {
                 HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
                 HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
@@ -398,6 +414,7 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     HIP_TRY(ctx, hipGetLastError());
     ctx->timing_valid = true;
     ctx->timing_is_compress = true;
+    ctx->dominant_split = lanes_mode;
     ctx->codec_launches = blocks ? 1 : 0;
     return SNAPMI_OK;
 }
@@ -447,6 +464,7 @@ int launch_decompress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     HIP_TRY(ctx, hipGetLastError());
     ctx->timing_valid = true;
     ctx->timing_is_compress = false;
+    ctx->dominant_split = false;
     ctx->codec_launches = 1;
     return SNAPMI_OK;
 }
@@ -531,6 +549,10 @@ int snapmi_last_timing(snapmi_ctx *ctx, snapmi_timing *out)
             hipEventElapsedTime(&out->compact_ms, ctx->ev[2], ctx->ev[3]));
     HIP_TRY(ctx, hipEventElapsedTime(&out->total_ms, ctx->ev[0], ctx->ev[3]));
     out->codec_launches = ctx->codec_launches;
+    out->dominant_ms = out->codec_ms;
+    if (ctx->dominant_split)
+        HIP_TRY(ctx, hipEventElapsedTime(&out->dominant_ms, ctx->ev[4],
+                                         ctx->ev[5]));
     return SNAPMI_OK;
 }
 

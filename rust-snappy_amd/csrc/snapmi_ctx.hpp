@@ -42,9 +42,12 @@ struct snapmi_ctx {
     snapmi::DevBuf fr_tables, fr_desc, fr_meta, fr_scan, fr_slots;
     bool fr_tables_ready = false;
     int num_cus = 0;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint32_t lane_min_blocks = 4096;
+    uint32_t lane_waves_per_cu = 12;
     bool timing_valid = false;
     bool timing_is_compress = false;
+    bool dominant_split = false; // ev[4]/ev[5] bracket k_match_blocks
     uint64_t codec_launches = 0;
 };
 

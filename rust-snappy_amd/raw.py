@@ -62,6 +62,13 @@ class Context:
     def __exit__(self, *a):
         self.close()
 
+    def set_option(self, name, value):
+        """snapmi_ctx_set_option: tuning knobs (never change results)."""
+        rc = _lib.load().snapmi_ctx_set_option(self._h, name.encode(),
+                                               int(value))
+        if rc:
+            _raise(self, rc)
+
     @property
     def stream(self):
         return _lib.load().snapmi_ctx_stream(self._h)
@@ -78,7 +85,8 @@ class Context:
             _raise(self, rc)
         return {"plan_ms": t.plan_ms, "codec_ms": t.codec_ms,
                 "compact_ms": t.compact_ms, "total_ms": t.total_ms,
-                "codec_launches": t.codec_launches}
+                "codec_launches": t.codec_launches,
+                "dominant_ms": t.dominant_ms}
 
 
 _default_ctx = None

@@ -45,7 +45,8 @@ def random_inputs(seed, count):
     return out
 
 
-def test_compress_corpus_bit_exact(ctx):
+def test_compress_corpus_bit_exact(cctx):
+    ctx = cctx
     rnd = O.corpus_round()
     got = gpu_compress(ctx, [d for _, d in rnd])
     for (bench_id, data), c in zip(rnd, got):
@@ -54,7 +55,8 @@ def test_compress_corpus_bit_exact(ctx):
         assert hashlib.sha256(c).hexdigest() == sha, bench_id
 
 
-def test_compress_golden_and_kats(ctx):
+def test_compress_golden_and_kats(cctx):
+    ctx = cctx
     txt = (O.CORPUS / "Mark.Twain-Tom.Sawyer.txt").read_bytes()
     snp = (O.CORPUS / "Mark.Twain-Tom.Sawyer.txt.rawsnappy").read_bytes()
     ins = [txt, b"a" * 120, b"", b"\x00", kats.RANDOM1, kats.RANDOM2,
@@ -67,21 +69,24 @@ def test_compress_golden_and_kats(ctx):
         assert c == O.compress(d)
 
 
-def test_compress_structured_bit_exact(ctx):
+def test_compress_structured_bit_exact(cctx):
+    ctx = cctx
     ins = kats.small_copy_inputs() + kats.small_regular_inputs()
     got = gpu_compress(ctx, ins)
     for d, c in zip(ins, got):
         assert c == O.compress(d), len(d)
 
 
-def test_compress_random_bit_exact(ctx):
+def test_compress_random_bit_exact(cctx):
+    ctx = cctx
     ins = random_inputs(7, 600)
     got = gpu_compress(ctx, ins)
     for d, c in zip(ins, got):
         assert c == O.compress(d), (len(d), d[:16])
 
 
-def test_compress_block_edges(ctx):
+def test_compress_block_edges(cctx):
+    ctx = cctx
     rng = random.Random(3)
     base = (O.CORPUS / "alice29.txt").read_bytes()
     ins = []
