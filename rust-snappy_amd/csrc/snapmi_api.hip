@@ -338,12 +338,12 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
         const uint32_t lanes = (uint32_t)waves * 64;
         if (lanes > ctx->n_lanes) { // tables must start zeroed (epoch 0)
             if ((rc = reserve(ctx, ctx->lane_tables,
-                              (size_t)lanes * kMaxTable * sizeof(uint32_t))) ||
+                              (size_t)lanes * kMaxTable * sizeof(uint64_t))) ||
                 (rc = reserve(ctx, ctx->lane_epochs,
                               (size_t)lanes * sizeof(uint32_t))))
                 return rc;
             HIP_TRY(ctx, hipMemsetAsync(ctx->lane_tables.p, 0,
-                                        (size_t)lanes * kMaxTable * 4,
+                                        (size_t)lanes * kMaxTable * 8,
                                         ctx->stream));
             HIP_TRY(ctx, hipMemsetAsync(ctx->lane_epochs.p, 0,
                                         (size_t)lanes * 4, ctx->stream));
@@ -355,7 +355,7 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
             return rc;
         a.tokens = (unsigned long long *)ctx->tokens.p;
         a.ntok = (uint32_t *)ctx->ntok.p;
-        a.lane_tables = (uint32_t *)ctx->lane_tables.p;
+        a.lane_tables = (unsigned long long *)ctx->lane_tables.p;
         a.lane_epochs = (uint32_t *)ctx->lane_epochs.p;
         a.n_lanes = lanes;
     }

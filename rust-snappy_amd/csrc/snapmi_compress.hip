@@ -640,9 +640,13 @@ __global__ __launch_bounds__(kCompressWaves * 64) void k_compress_blocks(
 // dependent random accesses (table, candidate), but with tens of thousands
 // of chains in flight the memory system, not the latency, sets the rate
 // (measured on MI355X: ~1.6e10 lane-steps/s, tests/hw/random_rmw.hip).
-//   * table entries are (epoch << 16 | position): a table is never zeroed,
-//     an entry of another epoch reads as 0 (= the reference's fresh table);
-//     epochs persist in the context across launches;
+//   * table entries are 8 bytes: epoch | position | the 4 input bytes at
+//     that position.  The epoch means a table is never zeroed (an entry of
+//     another epoch reads as position 0, the reference's fresh table;
+//     epochs persist in the context across launches).  The stored bytes
+//     mean a probe that does NOT match costs no second memory access: the
+//     kernel is bound by cache-line traffic (PMC: ~3 lines per step), and
+//     more than half of all lookups fail;
 //   * a lane that finishes its block takes the next one from the ticket
 //     counter, so lanes stay busy whatever the mix of block costs;
 //   * the lane only records tokens (literal length, copy length, offset);
@@ -665,10 +669,10 @@ __device__ __forceinline__ uint64_t ld64p(gcptr p)
 __global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
 {
     const uint32_t g = blockIdx.x * 64 + threadIdx.x; // lane id in the grid
-    typedef __attribute__((address_space(1))) uint32_t g_u32;
     typedef __attribute__((address_space(1))) unsigned long long g_u64;
-    g_u32 *const tab = (g_u32 *)a.lane_tables + (uint64_t)g * kMaxTable;
-    uint32_t epoch = a.lane_epochs[g];
+    g_u64 *const tab = (g_u64 *)a.lane_tables + (uint64_t)g * kMaxTable;
+    unsigned long long epoch = a.lane_epochs[g]; // 16 bits used
+    uint32_t first4 = 0; // the 4 bytes at block offset 0 (empty-entry match)
     uint32_t nblocks = a.blk_first[a.n_streams];
     if (nblocks > a.host_blocks)
         nblocks = a.host_blocks;
@@ -715,6 +719,7 @@ __global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
                     have = false;
                 } else {
                     // fresh table = new epoch (src/compress.rs:491-518)
+                    first4 = ld32p(src);
                     epoch = (epoch + 1) & 0xFFFFu;
                     if (epoch == 0) { // wrapped: really clear this lane's table
                         for (uint32_t i = 0; i < kMaxTable; i++)
@@ -749,7 +754,9 @@ __global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
         bool finished = false;
         if (chain) { // src/compress.rs:290-301
             x = ld64p(src + s - 1);
-            tab[hash32((uint32_t)x, shift)] = (epoch << 16) | (s - 1);
+            tab[hash32((uint32_t)x, shift)] =
+                (epoch << 48) | ((unsigned long long)(s - 1) << 32) |
+                (uint32_t)x;
             cur32 = (uint32_t)(x >> 8);
             hcur = hash32(cur32, shift);
             pos = s;
@@ -770,10 +777,12 @@ __global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
             }
         }
         if (!finished) {
-            const uint32_t e = tab[hcur];
-            const uint32_t cand = (e >> 16) == epoch ? (e & 0xFFFFu) : 0;
-            tab[hcur] = (epoch << 16) | pos;
-            if (ld32p(src + cand) == cur32) {
+            const unsigned long long e = tab[hcur];
+            const bool live = (e >> 48) == epoch;
+            const uint32_t cand = live ? (uint32_t)(e >> 32) & 0xFFFFu : 0;
+            const uint32_t cand4 = live ? (uint32_t)e : first4;
+            tab[hcur] = (epoch << 48) | ((unsigned long long)pos << 32) | cur32;
+            if (cand4 == cur32) {
                 // match: extend to the block end (src/compress.rs:378-412)
                 uint32_t p = pos + 4, c = cand + 4;
                 bool open = true;

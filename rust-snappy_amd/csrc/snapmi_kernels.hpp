@@ -30,7 +30,7 @@ struct CompressArgs {
     // per-lane epoch-tagged hash tables in HBM
     unsigned long long *tokens; // [blocks * kMaxTokens]
     uint32_t *ntok;             // [blocks]
-    uint32_t *lane_tables;      // [lanes * kMaxTable] (epoch << 16 | position)
+    unsigned long long *lane_tables; // [lanes * kMaxTable] epoch|pos|bytes
     uint32_t *lane_epochs;      // [lanes]
     uint32_t n_lanes;
     // experiment builds (-DSNAPMI_PROFILE) only: 16 u64 cycle counters
