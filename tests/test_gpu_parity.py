@@ -254,3 +254,17 @@ def test_tiled_corpus_properties(ctx):
             i = r * 12 + j
             assert errs[i][0] == 0
             assert out.stream_bytes(i, olens[i]) == rnd[j], (r, j)
+
+
+def test_hw_lds_atomic_lane_order(ctx):
+    """The wavefront-per-block compressor reproduces 64 sequential table
+    updates with ONE LDS atomic; that is exact only if gfx950 applies the
+    lanes of one DS atomic in ascending lane order.  Checked on the hardware
+    the tests run on (tests/hw/lds_atomic_order.hip)."""
+    import subprocess
+    from conftest import ROOT
+    exe = ROOT / "tests" / "hw" / "lds_atomic_order"
+    assert exe.exists(), "run __graft_entry__.build() first"
+    out = subprocess.run([str(exe)], capture_output=True, text=True,
+                         timeout=60).stdout
+    assert "PASS ascending-lane order" in out, out
