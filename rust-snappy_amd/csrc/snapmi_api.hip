@@ -338,12 +338,12 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
         const uint32_t lanes = (uint32_t)waves * 64;
         if (lanes > ctx->n_lanes) { // tables must start zeroed (epoch 0)
             if ((rc = reserve(ctx, ctx->lane_tables,
-                              (size_t)lanes * kMaxTable * sizeof(uint64_t))) ||
+                              (size_t)lanes * kMaxTable * 16)) ||
                 (rc = reserve(ctx, ctx->lane_epochs,
                               (size_t)lanes * sizeof(uint32_t))))
                 return rc;
             HIP_TRY(ctx, hipMemsetAsync(ctx->lane_tables.p, 0,
-                                        (size_t)lanes * kMaxTable * 8,
+                                        (size_t)lanes * kMaxTable * 16,
                                         ctx->stream));
             HIP_TRY(ctx, hipMemsetAsync(ctx->lane_epochs.p, 0,
                                         (size_t)lanes * 4, ctx->stream));

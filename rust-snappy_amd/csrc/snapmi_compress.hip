@@ -670,9 +670,14 @@ __global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
 {
     const uint32_t g = blockIdx.x * 64 + threadIdx.x; // lane id in the grid
     typedef __attribute__((address_space(1))) unsigned long long g_u64;
-    g_u64 *const tab = (g_u64 *)a.lane_tables + (uint64_t)g * kMaxTable;
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(1))) u64x2 g_entry;
+    // 16-byte entries: x = bytes 0..7 at the position, y = bytes 8..11 |
+    // position << 32 | epoch << 48
+    g_entry *const tab = (g_entry *)a.lane_tables + (uint64_t)g * kMaxTable;
     unsigned long long epoch = a.lane_epochs[g]; // 16 bits used
-    uint32_t first4 = 0; // the 4 bytes at block offset 0 (empty-entry match)
+    unsigned long long first8 = 0; // bytes 0..11 of the block (empty entry)
+    uint32_t first4b = 0;
     uint32_t nblocks = a.blk_first[a.n_streams];
     if (nblocks > a.host_blocks)
         nblocks = a.host_blocks;
@@ -719,11 +724,12 @@ __global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
                     have = false;
                 } else {
                     // fresh table = new epoch (src/compress.rs:491-518)
-                    first4 = ld32p(src);
+                    first8 = ld64p(src);
+                    first4b = ld32p(src + 8);
                     epoch = (epoch + 1) & 0xFFFFu;
                     if (epoch == 0) { // wrapped: really clear this lane's table
                         for (uint32_t i = 0; i < kMaxTable; i++)
-                            tab[i] = 0;
+                            tab[i] = (u64x2){0, 0};
                         epoch = 1;
                     }
                     shift = 32 - 8;
@@ -754,9 +760,9 @@ __global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
         bool finished = false;
         if (chain) { // src/compress.rs:290-301
             x = ld64p(src + s - 1);
-            tab[hash32((uint32_t)x, shift)] =
-                (epoch << 48) | ((unsigned long long)(s - 1) << 32) |
-                (uint32_t)x;
+            tab[hash32((uint32_t)x, shift)] = (u64x2){
+                x, (epoch << 48) | ((unsigned long long)(s - 1) << 32) |
+                       ld32p(src + s + 7)};
             cur32 = (uint32_t)(x >> 8);
             hcur = hash32(cur32, shift);
             pos = s;
@@ -777,15 +783,28 @@ __global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
             }
         }
         if (!finished) {
-            const unsigned long long e = tab[hcur];
-            const bool live = (e >> 48) == epoch;
-            const uint32_t cand = live ? (uint32_t)(e >> 32) & 0xFFFFu : 0;
-            const uint32_t cand4 = live ? (uint32_t)e : first4;
-            tab[hcur] = (epoch << 48) | ((unsigned long long)pos << 32) | cur32;
-            if (cand4 == cur32) {
-                // match: extend to the block end (src/compress.rs:378-412)
-                uint32_t p = pos + 4, c = cand + 4;
-                bool open = true;
+            const u64x2 e = tab[hcur];
+            const bool live = (e.y >> 48) == epoch;
+            const uint32_t cand = live ? (uint32_t)(e.y >> 32) & 0xFFFFu : 0;
+            const unsigned long long c8 = live ? e.x : first8;
+            const uint32_t c4 = live ? (uint32_t)e.y : first4b;
+            // the 12 bytes at pos (pos + 12 <= n for every probed position)
+            const unsigned long long p8 = ld64p(src + pos);
+            const uint32_t p4 = ld32p(src + pos + 8);
+            tab[hcur] = (u64x2){
+                p8, (epoch << 48) | ((unsigned long long)pos << 32) | p4};
+            if ((uint32_t)c8 == cur32) {
+                // match: the entry holds the candidate's first 12 bytes, so
+                // most matches are measured without touching the candidate's
+                // cache line; longer ones extend from memory to the block
+                // end (src/compress.rs:378-412)
+                const unsigned long long d8 = c8 ^ p8;
+                const uint32_t d4 = c4 ^ p4;
+                uint32_t m = d8 ? (uint32_t)__builtin_ctzll(d8) >> 3
+                                : 8 + (d4 ? (uint32_t)__builtin_ctz(d4) >> 3
+                                          : 4);
+                uint32_t p = pos + m, c = cand + m;
+                bool open = m == 12;
                 while (open && p + 8 <= n) {
                     const uint64_t z = ld64p(src + p) ^ ld64p(src + c);
                     if (z) {
