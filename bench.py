@@ -248,6 +248,10 @@ def main():
         t_dec += tc - tb
     barrier()
     elapsed = time.perf_counter() - t0
+    if rank == 0:
+        log("[bench] compress kernel ms per step: "
+            + " ".join(f"{x:.1f}/{y:.1f}" for x, y in zip(k_dom_ms, k_comp_ms))
+            + " | decompress: " + " ".join(f"{x:.1f}" for x in k_dec_ms))
     if world > 1:
         t = torch.tensor([elapsed, t_comp, t_dec], dtype=torch.float64,
                          device=dev)

@@ -111,10 +111,10 @@ const char *snapmi_version(void);
 /*
  * Tuning knobs (results never depend on them, only speed):
  *   "compress_mode"        0 wavefront-per-block kernel only, 1 lane-per-block
- *                          kernel on large batches, 2 both at once (default)
+ *                          kernel on large batches (default), 2 both at once
  *   "lane_min_blocks"      batches with at least this many 64 KiB blocks use
- *                          the lane-per-block kernel (default 4096)
- *   "lane_waves_per_cu"    lanes in flight = 64 x this x CUs (default 12)
+ *                          the lane-per-block kernel (default 8192)
+ *   "lane_waves_per_cu"    lanes in flight = 64 x this x CUs (default 6)
  * Returns SNAPMI_E_ARGUMENT for an unknown name.
  */
 int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value);

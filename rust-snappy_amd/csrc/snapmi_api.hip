@@ -101,6 +101,10 @@ int snapmi_ctx_create(int device, void *hip_stream, snapmi_ctx **out)
             const int v = atoi(e);
             ctx->lane_waves_per_cu = (uint32_t)(v < 1 ? 1 : (v > 32 ? 32 : v));
         }
+        if (const char *e = getenv("SNAPMI_LANE_MIN_BLOCKS")) {
+            const long v = atol(e);
+            ctx->lane_min_blocks = (uint32_t)(v < 1 ? 1 : v);
+        }
         if (const char *m = getenv("SNAPMI_COMPRESS"))
             ctx->compress_mode = strcmp(m, "waves") == 0
                                      ? 0
@@ -315,10 +319,9 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     a.lane_tables = nullptr;
     a.lane_epochs = nullptr;
     a.n_lanes = 0;
-    // Small batches are latency-bound: the wavefront kernel alone finishes a
-    // block in ~2 ms, a lane needs ~10x that.  Large batches run both
-    // kernels at once (they use disjoint resources: LDS + few waves vs.
-    // memory-level parallelism) on the two ends of the block list.
+    // Small batches are latency-bound: the wavefront kernel finishes a block
+    // in ~2 ms, a lane needs tens of ms.  Large batches are throughput-bound
+    // and go to the lane-per-block kernel.
     const bool big = blocks >= ctx->lane_min_blocks;
     const bool lanes_mode = blocks > 0 && ctx->compress_mode != 0 && big;
     const bool waves_mode =

@@ -636,17 +636,20 @@ __global__ __launch_bounds__(kCompressWaves * 64) void k_compress_blocks(
 // emitted copy and by "five tables per CU".  This kernel turns the problem
 // around: every LANE runs the reference's sequential parse (src/compress.rs:
 // 195-317) on its own block, with its own hash table in HBM, and a wave
-// advances 64 independent chains per instruction.  Each step is two
-// dependent random accesses (table, candidate), but with tens of thousands
-// of chains in flight the memory system, not the latency, sets the rate
-// (measured on MI355X: ~1.6e10 lane-steps/s, tests/hw/random_rmw.hip).
-//   * table entries are 8 bytes: epoch | position | the 4 input bytes at
-//     that position.  The epoch means a table is never zeroed (an entry of
-//     another epoch reads as position 0, the reference's fresh table;
-//     epochs persist in the context across launches).  The stored bytes
-//     mean a probe that does NOT match costs no second memory access: the
-//     kernel is bound by cache-line traffic (PMC: ~3 lines per step), and
-//     more than half of all lookups fail;
+// advances 64 independent chains per instruction.
+//   * table entries are 16 bytes: the 12 input bytes at the position, the
+//     position and an epoch.  The epoch means a table is never zeroed (an
+//     entry of another epoch reads as position 0, the reference's fresh
+//     table; epochs persist in the context across launches).  The stored
+//     bytes decide hit or miss and measure matches shorter than 12 bytes
+//     without touching the candidate's cache line;
+//   * the loop is organised in ROUNDS of one memory round trip: every lane
+//     issues the same three loads (16 B, 16 B, 4 B) whatever it is doing -
+//     probing the table, inserting after a copy, or extending a long match
+//     16 bytes further - then all lanes wait once and update their state
+//     with ALU work only.  A lane never waits for another lane's match
+//     extension, so the time of a wave is (rounds of its slowest lane) x
+//     (one round trip), not the sum of every lane's serial loops;
 //   * a lane that finishes its block takes the next one from the ticket
 //     counter, so lanes stay busy whatever the mix of block costs;
 //   * the lane only records tokens (literal length, copy length, offset);
@@ -665,9 +668,25 @@ __device__ __forceinline__ uint64_t ld64p(gcptr p)
     __builtin_memcpy(&v, p, 8);
     return v;
 }
-
+#ifdef SNAPMI_NT
+#define TAB_STORE(ptr, val) __builtin_nontemporal_store(val, ptr)
+#else
+#define TAB_STORE(ptr, val) (*(ptr) = (val))
+#endif
 __global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
 {
+    // per-lane input window: two 128-byte lines of the lane's block
+    __shared__ __attribute__((aligned(16))) uint32_t ring[64 * 64];
+    // per-lane token buffer: 16 tokens = one 128-byte line (every store of a
+    // lane is its own DRAM transaction, and those are what bounds the kernel)
+    __shared__ __attribute__((aligned(16))) unsigned long long tokbuf[64 * 16];
+    typedef __attribute__((address_space(3))) unsigned long long l_u64;
+    l_u64 *const tbuf = (l_u64 *)tokbuf + threadIdx.x * 16;
+    typedef __attribute__((address_space(3))) uint32_t l_u32;
+    typedef __attribute__((address_space(3))) u32x4 l_u32x4;
+    typedef __attribute__((address_space(1))) u32x4 g_u32x4;
+    l_u32 *const win = (l_u32 *)ring + threadIdx.x * 64;
+
     const uint32_t g = blockIdx.x * 64 + threadIdx.x; // lane id in the grid
     typedef __attribute__((address_space(1))) unsigned long long g_u64;
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
@@ -682,13 +701,23 @@ __global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
     if (nblocks > a.host_blocks)
         nblocks = a.host_blocks;
 
+    // what the lane does in the next round
+    enum : uint32_t {
+        kProbe = 0,  // look up position s (the skip loop, compress.rs:207-245)
+        kChain = 1,  // after a copy: insert s-1, look up s (compress.rs:290-312)
+        kExtend = 2, // compare 16 more bytes of an open match (compress.rs:378-412)
+    };
     // per-lane block state
     bool have = false, out_of_work = false;
     uint32_t b = 0, n = 0, s_limit = 0, shift = 0;
-    uint32_t s = 0, s_next = 0, skip = 0, next_hash = 0, next_emit = 0;
+    uint32_t mode = kProbe;
+    uint32_t s = 0, s_next = 0, skip = 0, next_emit = 0;
+    uint32_t mpos = 0, mcand = 0, p = 0, c = 0; // the open match
     uint32_t ntok = 0;
-    bool chain = false;
-    gcptr src = nullptr;
+    // input window: the bytes [hi - 256, hi) of the 128-byte aligned view of
+    // the block (src_al = src - mis) are in `win`, at their offset mod 256
+    uint32_t mis = 0, hi = 0;
+    gcptr src = nullptr, src_al = nullptr;
     g_u64 *tok = nullptr;
 
     for (;;) {
@@ -700,13 +729,13 @@ __global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
                 out_of_work = true;
             } else {
                 // stream lookup: blk_first[st] <= b < blk_first[st + 1]
-                uint32_t lo = 0, hi = a.n_streams;
-                while (hi - lo > 1) {
-                    const uint32_t mid = (lo + hi) >> 1;
+                uint32_t lo = 0, hi_st = a.n_streams;
+                while (hi_st - lo > 1) {
+                    const uint32_t mid = (lo + hi_st) >> 1;
                     if (a.blk_first[mid] <= b)
                         lo = mid;
                     else
-                        hi = mid;
+                        hi_st = mid;
                 }
                 const uint32_t k = b - a.blk_first[lo];
                 const uint64_t total = a.in_lens[lo];
@@ -738,11 +767,15 @@ __global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
                         shift--;
                         tsize *= 2;
                     }
-                    s_limit = n - kInputMargin;
-                    s_next = 1;
-                    skip = 32;
-                    next_hash = hash32(ld32p(src + 1), shift);
-                    chain = false;
+                    s_limit = n - kInputMargin; // >= 2
+                    // first trip of the skip loop: s = 1, s_next = 2
+                    s = 1;
+                    s_next = 2;
+                    skip = 33;
+                    mode = kProbe;
+                    mis = (uint32_t)(uintptr_t)src & 127u;
+                    src_al = src - mis;
+                    hi = 0;
                 }
             }
         }
@@ -754,86 +787,167 @@ __global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
         if (!have)
             continue;
 
-        // ---- one table lookup of the reference's parse --------------------
-        uint32_t pos, cur32, hcur;
-        uint64_t x = 0;
+        // ---- one round ----------------------------------------------------
+        // The 17 bytes at pos-1 come from the window (pos = s, or p while a
+        // match is open).  The next line is fetched while at least 64 bytes
+        // of look-ahead remain, in the same round as the table access; only
+        // a lane that jumped past its window (long match, large skip) has
+        // to sit a round out.
+        const uint32_t y0 = (mode == kExtend ? p : s) - 1 + mis;
+        if (y0 >= hi)
+            hi = y0 & ~127u; // jumped past the frontier: restart there
+        const bool stall = y0 + 17 > hi;
+        const bool fill = y0 + 81 > hi;
+        uint32_t q0, q1, q2, q3, r0, r1, r2, r3;
+        {
+            const uint32_t w0 = y0 >> 2, sh = y0 & 3;
+            const uint32_t d0 = win[w0 & 63], d1 = win[(w0 + 1) & 63],
+                           d2 = win[(w0 + 2) & 63], d3 = win[(w0 + 3) & 63],
+                           d4 = win[(w0 + 4) & 63];
+            q0 = __builtin_amdgcn_alignbyte(d1, d0, sh); // bytes at pos-1
+            q1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+            q2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
+            q3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
+            const uint32_t q4 = d4 >> (8 * sh);
+            r0 = __builtin_amdgcn_alignbyte(q1, q0, 1); // bytes at pos
+            r1 = __builtin_amdgcn_alignbyte(q2, q1, 1);
+            r2 = __builtin_amdgcn_alignbyte(q3, q2, 1);
+            r3 = __builtin_amdgcn_alignbyte(q4, q3, 1);
+        }
+        const uint32_t hprev = hash32(q0, shift), hcur = hash32(r0, shift);
+        // the one random access of the round: table entry or candidate bytes
+        gcptr pa = mode == kExtend ? src + c : (gcptr)(tab + hcur);
+        pa = stall ? src_al + hi : pa;
+        B16 A = ld128u(pa);
+        u32x4 f0, f1, f2, f3, f4, f5, f6, f7;
+        if (fill) {
+            const g_u32x4 *lp = (const g_u32x4 *)(src_al + hi);
+            f0 = lp[0]; f1 = lp[1]; f2 = lp[2]; f3 = lp[3];
+            f4 = lp[4]; f5 = lp[5]; f6 = lp[6]; f7 = lp[7];
+        }
+        // one wait for the whole round: keep the compiler from sinking a load
+        // into the branch that uses it
+        asm volatile("" : "+v"(A.w[0]), "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3),
+                          "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7));
+        if (fill) {
+            l_u32x4 *dst = (l_u32x4 *)(win + ((hi >> 2) & 63));
+            dst[0] = f0; dst[1] = f1; dst[2] = f2; dst[3] = f3;
+            dst[4] = f4; dst[5] = f5; dst[6] = f6; dst[7] = f7;
+            hi += 128;
+        }
+        if (stall)
+            continue;
+
+        bool matched = false;  // a copy ends in this round at mend
+        bool advance = false;  // next trip of the skip loop
+        bool tail = false;     // open match within 16 bytes of the block end
         bool finished = false;
-        if (chain) { // src/compress.rs:290-301
-            x = ld64p(src + s - 1);
-            tab[hash32((uint32_t)x, shift)] = (u64x2){
-                x, (epoch << 48) | ((unsigned long long)(s - 1) << 32) |
-                       ld32p(src + s + 7)};
-            cur32 = (uint32_t)(x >> 8);
-            hcur = hash32(cur32, shift);
-            pos = s;
-        } else { // src/compress.rs:207-226
+        uint32_t mend = 0;
+        if (mode <= kChain) {
+            if (mode == kChain) {
+                // src/compress.rs:290-297: insert s-1 first; the lookup of s
+                // must see it when both hash to the same slot
+                const unsigned long long b8 =
+                    ((unsigned long long)q1 << 32) | q0;
+                const unsigned long long by =
+                    (epoch << 48) | ((unsigned long long)(s - 1) << 32) | q2;
+                TAB_STORE(tab + hprev, ((u64x2){b8, by}));
+                if (hprev == hcur) {
+                    A.w[0] = q0;
+                    A.w[1] = q1;
+                    A.w[2] = q2;
+                    A.w[3] = (uint32_t)(by >> 32);
+                }
+            }
+            const unsigned long long p8 = ((unsigned long long)r1 << 32) | r0;
+            const uint32_t p4 = r2;
+            const bool live = (A.w[3] >> 16) == (uint32_t)epoch;
+            const uint32_t cand = live ? A.w[3] & 0xFFFFu : 0;
+            const unsigned long long c8 =
+                live ? ((unsigned long long)A.w[1] << 32) | A.w[0] : first8;
+            const uint32_t c4 = live ? A.w[2] : first4b;
+            TAB_STORE(tab + hcur,
+                      ((u64x2){p8, (epoch << 48) |
+                                       ((unsigned long long)s << 32) | p4}));
+            if ((uint32_t)c8 == r0) {
+                // the entry holds the candidate's first 12 bytes, so most
+                // matches are measured without touching the candidate's line
+                const unsigned long long d8 = c8 ^ p8;
+                const uint32_t d4 = c4 ^ p4;
+                const uint32_t m =
+                    d8 ? (uint32_t)__builtin_ctzll(d8) >> 3
+                       : 8 + (d4 ? (uint32_t)__builtin_ctz(d4) >> 3 : 4);
+                mpos = s;
+                mcand = cand;
+                if (m < 12) {
+                    matched = true;
+                    mend = s + m;
+                } else {
+                    p = s + 12;
+                    c = cand + 12;
+                    mode = kExtend;
+                    tail = p + 16 > n;
+                }
+            } else {
+                if (mode == kChain) { // src/compress.rs:310-312
+                    s_next = s + 1;
+                    skip = 32;
+                }
+                advance = true;
+            }
+        } else { // kExtend
+            B16 Bv;
+            Bv.w[0] = r0; Bv.w[1] = r1; Bv.w[2] = r2; Bv.w[3] = r3;
+            const uint32_t m = common16(A, Bv);
+            if (m < 16) {
+                matched = true;
+                mend = p + m;
+            } else {
+                p += 16;
+                c += 16;
+                tail = p + 16 > n;
+            }
+        }
+        if (tail) { // rare: finish the match bytewise up to the block end
+            while (p < n && src[p] == src[c]) {
+                p++;
+                c++;
+            }
+            matched = true;
+            mend = p;
+        }
+        bool flush = false;
+        if (matched) {
+            // token: literal next_emit..mpos, copy (mpos - mcand, mend - mpos)
+            tbuf[ntok & 15] = (unsigned long long)(mpos - next_emit) |
+                              ((unsigned long long)(mend - mpos) << 17) |
+                              ((unsigned long long)(mpos - mcand) << 33);
+            ntok++;
+            flush = (ntok & 15) == 0;
+            s = mend;
+            next_emit = mend;
+            mode = kChain;
+            if (s >= s_limit) // src/compress.rs:275-277
+                finished = true;
+        }
+        if (advance) { // src/compress.rs:207-216
             s = s_next;
             const uint32_t step = skip >> 5;
             s_next = s + step;
             skip += step;
-            pos = s;
-            if (s_next > s_limit) {
+            mode = kProbe;
+            if (s_next > s_limit)
                 finished = true;
-                hcur = 0;
-                cur32 = 0;
-            } else {
-                hcur = next_hash;
-                cur32 = ld32p(src + s);
-                next_hash = hash32(ld32p(src + s_next), shift);
-            }
         }
-        if (!finished) {
-            const u64x2 e = tab[hcur];
-            const bool live = (e.y >> 48) == epoch;
-            const uint32_t cand = live ? (uint32_t)(e.y >> 32) & 0xFFFFu : 0;
-            const unsigned long long c8 = live ? e.x : first8;
-            const uint32_t c4 = live ? (uint32_t)e.y : first4b;
-            // the 12 bytes at pos (pos + 12 <= n for every probed position)
-            const unsigned long long p8 = ld64p(src + pos);
-            const uint32_t p4 = ld32p(src + pos + 8);
-            tab[hcur] = (u64x2){
-                p8, (epoch << 48) | ((unsigned long long)pos << 32) | p4};
-            if ((uint32_t)c8 == cur32) {
-                // match: the entry holds the candidate's first 12 bytes, so
-                // most matches are measured without touching the candidate's
-                // cache line; longer ones extend from memory to the block
-                // end (src/compress.rs:378-412)
-                const unsigned long long d8 = c8 ^ p8;
-                const uint32_t d4 = c4 ^ p4;
-                uint32_t m = d8 ? (uint32_t)__builtin_ctzll(d8) >> 3
-                                : 8 + (d4 ? (uint32_t)__builtin_ctz(d4) >> 3
-                                          : 4);
-                uint32_t p = pos + m, c = cand + m;
-                bool open = m == 12;
-                while (open && p + 8 <= n) {
-                    const uint64_t z = ld64p(src + p) ^ ld64p(src + c);
-                    if (z) {
-                        p += (uint32_t)__builtin_ctzll(z) >> 3;
-                        open = false;
-                    } else {
-                        p += 8;
-                        c += 8;
-                    }
-                }
-                while (open && p < n && src[p] == src[c]) {
-                    p++;
-                    c++;
-                }
-                // token: literal next_emit..pos, copy (pos - cand, p - pos)
-                tok[ntok++] = (unsigned long long)(pos - next_emit) |
-                              ((unsigned long long)(p - pos) << 17) |
-                              ((unsigned long long)(pos - cand) << 33);
-                s = p;
-                next_emit = p;
-                chain = true;
-                if (s >= s_limit) // src/compress.rs:275-277
-                    finished = true;
-            } else if (chain) { // src/compress.rs:310-312
-                next_hash = hash32((uint32_t)(x >> 16), shift);
-                s_next = s + 1;
-                skip = 32;
-                chain = false;
-            }
+        if (finished)
+            flush = flush || (ntok & 15) != 0;
+        if (flush) { // the token group that holds token ntok-1
+            g_u32x4 *to = (g_u32x4 *)(tok + ((ntok - 1) & ~15u));
+            const l_u32x4 *from = (const l_u32x4 *)tbuf;
+            const u32x4 t0 = from[0], t1 = from[1], t2 = from[2], t3 = from[3],
+                        t4 = from[4], t5 = from[5], t6 = from[6], t7 = from[7];
+            to[0] = t0; to[1] = t1; to[2] = t2; to[3] = t3;
+            to[4] = t4; to[5] = t5; to[6] = t6; to[7] = t7;
         }
         if (finished) { // done(): src/compress.rs:417-426
             if (next_emit < n)

@@ -30,10 +30,11 @@ struct snapmi_ctx {
     snapmi::DevBuf tokens, ntok, lane_tables, lane_epochs;
     uint32_t n_lanes = 0;
     // SNAPMI_COMPRESS=waves|lanes|both: 0 = wavefront kernel only, 1 = lane
-    // kernel (wavefront kernel for small batches), 2 = on large batches both
-    // kernels at once, sharing one two-ended ticket (measured 180 vs 204 ms
-    // at cfg2 against mode 1; small batches: wavefront kernel only)
-    int compress_mode = 2;
+    // kernel on large batches and the wavefront kernel on small ones
+    // (default), 2 = on large batches both kernels at once, sharing one
+    // two-ended ticket (no faster: the wavefront kernel takes whole CUs' LDS
+    // away from the lanes' input windows; kept as a cross-check)
+    int compress_mode = 1;
     hipStream_t stream2 = nullptr; // the wavefront kernel's side stream
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // staging for the host-pointer (scalar) entry points
@@ -43,8 +44,8 @@ struct snapmi_ctx {
     bool fr_tables_ready = false;
     int num_cus = 0;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    uint32_t lane_min_blocks = 4096;
-    uint32_t lane_waves_per_cu = 12;
+    uint32_t lane_min_blocks = 8192; // measured crossover ~0.5 GiB
+    uint32_t lane_waves_per_cu = 6; // 24 KiB of LDS per wave
     bool timing_valid = false;
     bool timing_is_compress = false;
     bool dominant_split = false; // ev[4]/ev[5] bracket k_match_blocks

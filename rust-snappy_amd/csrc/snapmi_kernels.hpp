@@ -40,9 +40,10 @@ struct CompressArgs {
 // wavefronts (= hash tables) per persistent compress workgroup: 5 x 32 KiB
 // is all of a CU's LDS
 constexpr uint32_t kCompressWaves = 5;
-// most tokens one block can produce: every token but the last ends in a copy
-// of >= 4 bytes
-constexpr uint32_t kMaxTokens = (1u << 16) / 4 + 1;
+// token slots per block: at most 16385 tokens (every token but the last ends
+// in a copy of >= 4 bytes), rounded up to whole 128-byte groups of 16 so a
+// lane can write its tokens a full cache line at a time
+constexpr uint32_t kMaxTokens = 16400;
 
 // Batch of raw streams to decompress.
 struct DecompressArgs {
