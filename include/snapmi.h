@@ -115,6 +115,8 @@ const char *snapmi_version(void);
  *   "lane_min_blocks"      batches with at least this many 64 KiB blocks use
  *                          the lane-per-block kernel (default 8192)
  *   "lane_waves_per_cu"    lanes in flight = 64 x this x CUs (default 6)
+ *   "lane_segment_blocks"  blocks per lane-kernel launch (default 262144 =
+ *                          16 GiB of input; bounds the token scratch)
  * Returns SNAPMI_E_ARGUMENT for an unknown name.
  */
 int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value);

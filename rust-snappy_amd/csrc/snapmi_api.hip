@@ -101,6 +101,10 @@ int snapmi_ctx_create(int device, void *hip_stream, snapmi_ctx **out)
             const int v = atoi(e);
             ctx->lane_waves_per_cu = (uint32_t)(v < 1 ? 1 : (v > 32 ? 32 : v));
         }
+        if (const char *e = getenv("SNAPMI_LANE_SEGMENT_BLOCKS")) {
+            const long v = atol(e);
+            ctx->lane_segment_blocks = (uint32_t)(v < 64 ? 64 : v);
+        }
         if (const char *e = getenv("SNAPMI_LANE_MIN_BLOCKS")) {
             const long v = atol(e);
             ctx->lane_min_blocks = (uint32_t)(v < 1 ? 1 : v);
@@ -179,6 +183,9 @@ int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value)
         ctx->compress_mode = (int)value;
     else if (strcmp(name, "lane_min_blocks") == 0 && value >= 1)
         ctx->lane_min_blocks = (uint32_t)value;
+    else if (strcmp(name, "lane_segment_blocks") == 0 && value >= 64 &&
+             value <= 0x7FFFFFFF)
+        ctx->lane_segment_blocks = (uint32_t)value;
     else if (strcmp(name, "lane_waves_per_cu") == 0 && value >= 1 &&
              value <= 32)
         ctx->lane_waves_per_cu = (uint32_t)value;
@@ -324,18 +331,21 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     // and go to the lane-per-block kernel.
     const bool big = blocks >= ctx->lane_min_blocks;
     const bool lanes_mode = blocks > 0 && ctx->compress_mode != 0 && big;
+    // the lane kernel runs over segments of the block list so that the token
+    // scratch (128 KiB per block) stays bounded; "both at once" needs the
+    // whole list in one segment
+    const uint64_t seg_blocks =
+        blocks < ctx->lane_segment_blocks ? blocks : ctx->lane_segment_blocks;
     const bool waves_mode =
-        blocks > 0 && (ctx->compress_mode != 1 || !lanes_mode);
+        blocks > 0 && (!lanes_mode || ctx->compress_mode == 0 ||
+                       (ctx->compress_mode == 2 && seg_blocks == blocks));
+    a.blk_lo = 0;
+    a.blk_hi = (uint32_t)blocks;
     if (lanes_mode) {
-        // waves of the lane-per-block match finder: enough chains in flight
-        // to saturate the memory system (2 per CU measured), never more
-        // lanes than blocks
+        // waves of the lane-per-block match finder: a few per CU saturate
+        // the random-access rate of HBM; never more lanes than blocks
         uint64_t waves = (uint64_t)ctx->num_cus * ctx->lane_waves_per_cu;
-        // when the wavefront kernel runs beside it, leave it a share of the
-        // blocks: lanes claim a block each at once, so cap lanes below blocks
-        const uint64_t share =
-            waves_mode ? (uint64_t)(blocks * kLaneShare) : blocks;
-        const uint64_t need = (share + 63) / 64;
+        const uint64_t need = (seg_blocks + 63) / 64;
         if (waves > need)
             waves = need ? need : 1;
         const uint32_t lanes = (uint32_t)waves * 64;
@@ -352,8 +362,8 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                                         (size_t)lanes * 4, ctx->stream));
             ctx->n_lanes = lanes;
         }
-        if ((rc = reserve(ctx, ctx->tokens,
-                          (size_t)blocks * kMaxTokens * sizeof(uint64_t))) ||
+        if ((rc = reserve(ctx, ctx->tokens, (size_t)seg_blocks * kMaxTokens *
+                                                sizeof(uint64_t))) ||
             (rc = reserve(ctx, ctx->ntok, (size_t)blocks * sizeof(uint32_t))))
             return rc;
         a.tokens = (unsigned long long *)ctx->tokens.p;
@@ -377,14 +387,15 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     hipLaunchKernelGGL(k_plan_compress, dim3(1), dim3(1024), 0, s, a);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], s));
     if (blocks) {
-        HIP_TRY(ctx, hipMemsetAsync(ctx->ticket.p, 0, 64, s));
         hipStream_t ws = s; // stream of the wavefront kernel
-        if (waves_mode && lanes_mode) {
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-            ws = ctx->stream2;
-        }
         if (waves_mode) {
+            HIP_TRY(ctx, hipMemsetAsync(ctx->ticket.p, 0, 64, s));
+            if (lanes_mode) {
+                HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
+                HIP_TRY(ctx,
+                        hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+                ws = ctx->stream2;
+            }
             // persistent: one 5-wave workgroup per CU (all of its LDS), each
             // wavefront pulls blocks from the back of the ticket
             const uint64_t want =
@@ -396,15 +407,26 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
         }
         if (lanes_mode) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev[4], s));
-            hipLaunchKernelGGL(k_match_blocks, dim3(a.n_lanes / 64), dim3(64),
-                               0, s, a);
-            HIP_TRY(ctx, hipEventRecord(ctx->ev[5], s));
-            if (waves_mode) {
-                HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
-                HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+            for (uint64_t lo = 0; lo < blocks; lo += seg_blocks) {
+                const uint64_t hi =
+                    lo + seg_blocks < blocks ? lo + seg_blocks : blocks;
+                a.blk_lo = (uint32_t)lo;
+                a.blk_hi = (uint32_t)hi;
+                if (!waves_mode) // (shared with the wavefront kernel if on)
+                    HIP_TRY(ctx, hipMemsetAsync(ctx->ticket.p, 0, 64, s));
+                hipLaunchKernelGGL(k_match_blocks, dim3(a.n_lanes / 64),
+                                   dim3(64), 0, s, a);
+                if (hi == blocks) // dominant_ms: first match start .. last end
+                    HIP_TRY(ctx, hipEventRecord(ctx->ev[5], s));
+                if (waves_mode) {
+                    HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+                    HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+                }
+                hipLaunchKernelGGL(k_encode_tokens, dim3((uint32_t)(hi - lo)),
+                                   dim3(64), 0, s, a);
             }
-            hipLaunchKernelGGL(k_encode_tokens, dim3((uint32_t)blocks),
-                               dim3(64), 0, s, a);
+            a.blk_lo = 0;
+            a.blk_hi = (uint32_t)blocks;
         }
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], s));

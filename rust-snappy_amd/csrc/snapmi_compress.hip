@@ -700,6 +700,8 @@ __global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
     uint32_t nblocks = a.blk_first[a.n_streams];
     if (nblocks > a.host_blocks)
         nblocks = a.host_blocks;
+    if (nblocks > a.blk_hi)
+        nblocks = a.blk_hi; // this launch covers blocks [blk_lo, blk_hi)
 
     // what the lane does in the next round
     enum : uint32_t {
@@ -724,7 +726,7 @@ __global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
         if (!have && !out_of_work) {
             const unsigned long long old =
                 atomicAdd((unsigned long long *)a.ticket, 1ull);
-            b = (uint32_t)old;
+            b = a.blk_lo + (uint32_t)old;
             if ((uint64_t)b + (uint32_t)(old >> 32) >= nblocks) {
                 out_of_work = true;
             } else {
@@ -743,7 +745,7 @@ __global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
                 src = (gcptr)a.in_ptrs[lo] + boff;
                 n = total - boff < kMaxBlock ? (uint32_t)(total - boff)
                                              : kMaxBlock;
-                tok = (g_u64 *)a.tokens + (uint64_t)b * kMaxTokens;
+                tok = (g_u64 *)a.tokens + (uint64_t)(b - a.blk_lo) * kMaxTokens;
                 ntok = 0;
                 next_emit = 0;
                 have = true;
@@ -966,10 +968,12 @@ __global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
 __global__ __launch_bounds__(64) void k_encode_tokens(CompressArgs a)
 {
     const uint32_t lane = threadIdx.x;
-    const uint32_t b = blockIdx.x;
+    const uint32_t b = a.blk_lo + blockIdx.x;
     uint32_t nblocks = a.blk_first[a.n_streams];
     if (nblocks > a.host_blocks)
         nblocks = a.host_blocks;
+    if (nblocks > a.blk_hi)
+        nblocks = a.blk_hi;
     if (b >= nblocks)
         return;
     if (a.ntok[b] == 0xFFFFFFFFu)
@@ -1011,7 +1015,8 @@ __global__ __launch_bounds__(64) void k_encode_tokens(CompressArgs a)
     TokenSink out;
     out.init(src, n, dst, lane);
     typedef __attribute__((address_space(1))) unsigned long long g_u64;
-    const g_u64 *tok = (const g_u64 *)a.tokens + (uint64_t)b * kMaxTokens;
+    const g_u64 *tok =
+        (const g_u64 *)a.tokens + (uint64_t)(b - a.blk_lo) * kMaxTokens;
     const uint32_t count = a.ntok[b];
     uint32_t pos_base = 0;
     for (uint32_t t0 = 0; t0 < count; t0 += kWave) {

@@ -45,6 +45,8 @@ struct snapmi_ctx {
     int num_cus = 0;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t lane_min_blocks = 8192; // measured crossover ~0.5 GiB
+    // blocks per lane-kernel launch: bounds the token scratch (34 GB here)
+    uint32_t lane_segment_blocks = 262144;
     uint32_t lane_waves_per_cu = 6; // 24 KiB of LDS per wave
     bool timing_valid = false;
     bool timing_is_compress = false;

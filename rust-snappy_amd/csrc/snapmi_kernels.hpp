@@ -28,9 +28,10 @@ struct CompressArgs {
     uint32_t *ticket; // device-wide block ticket counter, zeroed per launch
     // lane-per-block match finder (k_match_blocks): token stream per block,
     // per-lane epoch-tagged hash tables in HBM
-    unsigned long long *tokens; // [blocks * kMaxTokens]
+    unsigned long long *tokens; // [(blk_hi - blk_lo) * kMaxTokens]
     uint32_t *ntok;             // [blocks]
-    unsigned long long *lane_tables; // [lanes * kMaxTable] epoch|pos|bytes
+    uint32_t blk_lo, blk_hi;    // blocks this lane/encode launch covers
+    unsigned long long *lane_tables; // [lanes * kMaxTable * 2] 16-byte entries
     uint32_t *lane_epochs;      // [lanes]
     uint32_t n_lanes;
     // experiment builds (-DSNAPMI_PROFILE) only: 16 u64 cycle counters

@@ -30,18 +30,23 @@ def ctx(built):
     c.close()
 
 
-@pytest.fixture(scope="session", params=["waves", "lanes", "both"])
+@pytest.fixture(scope="session",
+                params=["waves", "lanes", "lanes_segmented", "both"])
 def cctx(request, built):
     """A context per compressor kernel: the wavefront-per-block kernel, the
-    lane-per-block kernel and both at once, each forced for every batch size,
-    so every parity test of the encoder runs through all of them."""
+    lane-per-block kernel (one launch, and split into segments of 64 blocks)
+    and both at once, each forced for every batch size, so every parity test
+    of the encoder runs through all of them."""
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import rust_snappy_amd as R
     c = R.raw.Context(0)
-    c.set_option("compress_mode", {"waves": 0, "lanes": 1, "both": 2}[
+    c.set_option("compress_mode", {"waves": 0, "lanes": 1,
+                                   "lanes_segmented": 1, "both": 2}[
         request.param])
     c.set_option("lane_min_blocks", 1)
+    if request.param == "lanes_segmented":
+        c.set_option("lane_segment_blocks", 64)
     yield c
     c.close()

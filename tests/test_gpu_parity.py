@@ -55,6 +55,20 @@ def test_compress_corpus_bit_exact(cctx):
         assert hashlib.sha256(c).hexdigest() == sha, bench_id
 
 
+def test_compress_corpus_tiled_batch(cctx):
+    """200 blocks in one batch: several lane-kernel segments, lanes that take
+    more than one block, multi-block streams next to one-block streams."""
+    ctx = cctx
+    rnd = O.corpus_round()
+    streams = [d for _, d in rnd] * 4
+    got = gpu_compress(ctx, streams)
+    for i, c in enumerate(got):
+        bench_id = rnd[i % len(rnd)][0]
+        n_in, n_out, sha = kats.CORPUS_SHA256[bench_id]
+        assert len(c) == n_out, (i, bench_id)
+        assert hashlib.sha256(c).hexdigest() == sha, (i, bench_id)
+
+
 def test_compress_golden_and_kats(cctx):
     ctx = cctx
     txt = (O.CORPUS / "Mark.Twain-Tom.Sawyer.txt").read_bytes()
