@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Secondary benchmarks: BASELINE.json configs 3 and 5 (bench.py is the
-headline config 2).  One JSON line per config on stdout.
+headline config 2), the per-file rates of the reference's bench list and the
+PCIe-inclusive rate of the host-buffer entry points.  One JSON line per
+config on stdout; --only picks one.
 
   cfg3  FrameEncoder/FrameDecoder (framing + CRC32C kernel) on seeded
         synthetic English-like text, device resident.  Text: tokens of the
@@ -86,8 +88,6 @@ def cfg3(args, ctx, dev):
     k = (4 << 20) // 65536
     cut = int(index[k].item())
     assert out[:cut].cpu().numpy().tobytes() == want[:cut], "framed bytes differ"
-    back, m = frame.decompress_device(ctx, out, flen, index=index, out_cap=n)
-    assert m == n and bool((back[:n] == data).all()), "frame round trip"
     import ctypes as C
     from rust_snappy_amd import _lib, raw
     L = _lib.load()
@@ -102,6 +102,14 @@ def cfg3(args, ctx, dev):
                                      C.c_void_p(index.data_ptr()))
         assert rc == 0
 
+    te = time_it(enc, args.steps, ctx)
+    # the input is not needed any more (64 GiB + 75 GiB of output capacity +
+    # 64 GiB of decoded output would not leave room for the scratch)
+    del data
+    torch.cuda.empty_cache()
+    back, m = frame.decompress_device(ctx, out, flen, index=index, out_cap=n)
+    assert m == n, "frame round trip length"
+
     def dec():
         rc = L.snapmi_frame_decompress(ctx._h, C.c_void_p(out.data_ptr()),
                                        flen, C.c_void_p(back.data_ptr()), n,
@@ -111,9 +119,11 @@ def cfg3(args, ctx, dev):
                                        index.numel() - 1)
         assert rc == 0
 
-    te = time_it(enc, args.steps, ctx)
     td = time_it(dec, args.steps, ctx)
-    stored = 0
+    # round trip of the timed decode against the generator's period
+    per = back[:reps * period.numel()].view(reps, period.numel())
+    for r in range(reps):
+        assert torch.equal(per[r], period), "frame round trip (timed)"
     return {"config": "cfg3 framed synthetic text", "gib": round(n / GIB, 3),
             "chunks": index.numel() - 1, "ratio": round(flen / n, 4),
             "frame_encode_gibs": round(n / GIB / te, 2),
@@ -122,19 +132,19 @@ def cfg3(args, ctx, dev):
             "decode_uses_side_index": True}
 
 
-def cfg5(args, ctx, dev):
+def raw_tiles(ctx, dev, blob, gib, steps, want=None):
+    """`blob` as independent raw streams tiled to `gib`: compress and
+    decompress rates, first/last stream checked against `want`."""
     from rust_snappy_amd import batch, raw
-    import oracle_lib as O
-    jpg = (O.CORPUS / "fireworks.jpeg").read_bytes()
-    reps = max(1, int(args.gib * GIB / len(jpg)))
-    stride = (len(jpg) + 15) // 16 * 16
+    reps = max(1, int(gib * GIB / max(1, len(blob))))
+    stride = (len(blob) + 15) // 16 * 16
     one = np.zeros(stride, dtype=np.uint8)
-    one[:len(jpg)] = np.frombuffer(jpg, dtype=np.uint8)
+    one[:len(blob)] = np.frombuffer(blob, dtype=np.uint8)
     data = torch.from_numpy(one).to(dev).repeat(reps)
     offs = np.arange(reps, dtype=np.int64) * stride
-    lens = np.full(reps, len(jpg), dtype=np.int64)
+    lens = np.full(reps, len(blob), dtype=np.int64)
     src = batch.StreamBatch(data, offs, lens)
-    cap = raw.max_compress_len(len(jpg))
+    cap = raw.max_compress_len(len(blob))
     comp = batch.StreamBatch.empty(np.full(reps, cap, dtype=np.int64), dev)
     clens = torch.zeros(reps, dtype=torch.int64, device=dev)
     back = batch.StreamBatch.empty(lens, dev)
@@ -150,14 +160,22 @@ def cfg5(args, ctx, dev):
 
     enc()
     ctx.synchronize()
-    want = O.compress(jpg)
-    assert comp.stream_bytes(0, int(clens[0])) == want
-    assert comp.stream_bytes(reps - 1, int(clens[-1])) == want
-    te = time_it(enc, args.steps, ctx)
-    td = time_it(dec, args.steps, ctx)
-    assert back.stream_bytes(reps // 2) == jpg
-    n = reps * len(jpg)
-    c = reps * len(want)
+    if want is not None:
+        assert comp.stream_bytes(0, int(clens[0])) == want
+        assert comp.stream_bytes(reps - 1, int(clens[-1])) == want
+    te = time_it(enc, steps, ctx)
+    td = time_it(dec, steps, ctx)
+    assert back.stream_bytes(reps // 2) == blob
+    n = reps * len(blob)
+    c = int(clens.sum().item())
+    return n, c, reps, te, td
+
+
+def cfg5(args, ctx, dev):
+    import oracle_lib as O
+    jpg = (O.CORPUS / "fireworks.jpeg").read_bytes()
+    n, c, reps, te, td = raw_tiles(ctx, dev, jpg, args.gib, args.steps,
+                                   O.compress(jpg))
     return {"config": "cfg5 incompressible (fireworks.jpeg tiles)",
             "gib": round(n / GIB, 3), "streams": reps,
             "compress_gibs": round(n / GIB / te, 2),
@@ -166,6 +184,85 @@ def cfg5(args, ctx, dev):
             "decompress_hbm_frac": round((n + c) / td / 8e12, 4),
             "compress_ms": round(te * 1e3, 2),
             "decompress_ms": round(td * 1e3, 2)}
+
+
+def files(args, ctx, dev):
+    """The 12 inputs of the reference's bench list one at a time
+    (bench/src/bench.rs:83-114; README.md:135-158 quotes them per file),
+    each tiled to --gib as independent raw streams."""
+    import oracle_lib as O
+    rows = {}
+    for bench_id, blob in O.corpus_round():
+        n, c, reps, te, td = raw_tiles(ctx, dev, blob, args.gib, args.steps,
+                                       O.compress(blob))
+        rows[bench_id] = {"bytes": len(blob), "ratio": round(c / n, 4),
+                          "streams": reps,
+                          "compress_gibs": round(n / GIB / te, 2),
+                          "decompress_gibs": round(n / GIB / td, 2)}
+    return {"config": f"per-file rates, each tiled to {args.gib} GiB",
+            "files": rows}
+
+
+def pcie(args, ctx, dev):
+    """Host to host through the frame layer: pinned host buffer -> H2D ->
+    snapmi_frame_compress -> D2H of the framed bytes, and the inverse (the
+    decoder walks the chunk headers itself, no side index).  This is what a
+    host-side FrameEncoder / FrameDecoder pays per batch; bench.py's `value`
+    is device resident."""
+    import ctypes as C
+    import oracle_lib as O
+    from rust_snappy_amd import _lib, frame
+    L = _lib.load()
+    blob = b"".join(d for _, d in O.corpus_round())
+    reps = max(1, int(min(args.gib, 4.0) * GIB / len(blob)))
+    n = reps * len(blob)
+    h_in = torch.empty(n, dtype=torch.uint8).pin_memory()
+    h_in.view(reps, len(blob))[:] = torch.frombuffer(bytearray(blob),
+                                                     dtype=torch.uint8)
+    cap = frame.frame_max_len(n)
+    d_in = torch.empty(n, dtype=torch.uint8, device=dev)
+    d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    d_back = torch.empty(n, dtype=torch.uint8, device=dev)
+    h_out = torch.empty(cap, dtype=torch.uint8).pin_memory()
+    h_back = torch.empty(n, dtype=torch.uint8).pin_memory()
+    out_len = torch.zeros(1, dtype=torch.int64, device=dev)
+    err = torch.zeros(32, dtype=torch.uint8, device=dev)
+    flen = 0
+
+    def enc():
+        nonlocal flen
+        d_in.copy_(h_in, non_blocking=True)
+        torch.cuda.synchronize()
+        rc = L.snapmi_frame_compress(ctx._h, C.c_void_p(d_in.data_ptr()), n,
+                                     C.c_void_p(d_out.data_ptr()), cap,
+                                     C.c_void_p(out_len.data_ptr()), None)
+        assert rc == 0
+        ctx.synchronize()
+        flen = int(out_len.item())
+        h_out[:flen].copy_(d_out[:flen], non_blocking=True)
+        torch.cuda.synchronize()
+
+    def dec():
+        d_out[:flen].copy_(h_out[:flen], non_blocking=True)
+        torch.cuda.synchronize()
+        rc = L.snapmi_frame_decompress(ctx._h, C.c_void_p(d_out.data_ptr()),
+                                       flen, C.c_void_p(d_back.data_ptr()), n,
+                                       C.c_void_p(out_len.data_ptr()),
+                                       C.c_void_p(err.data_ptr()), None, 0)
+        assert rc == 0
+        ctx.synchronize()
+        h_back.copy_(d_back, non_blocking=True)
+        torch.cuda.synchronize()
+
+    te = time_it(enc, args.steps, ctx)
+    td = time_it(dec, args.steps, ctx)
+    assert bool((h_back == h_in).all()), "host round trip"
+    return {"config": "host to host through the frame layer (pinned memory, "
+                      "H2D + kernels + D2H, no overlap)",
+            "gib": round(n / GIB, 3), "ratio": round(flen / n, 4),
+            "frame_encode_gibs": round(n / GIB / te, 2),
+            "frame_decode_gibs": round(n / GIB / td, 2),
+            "encode_ms": round(te * 1e3, 2), "decode_ms": round(td * 1e3, 2)}
 
 
 def main():
@@ -180,7 +277,8 @@ def main():
     from rust_snappy_amd import raw
     dev = torch.device("cuda", 0)
     ctx = raw.Context(0)
-    for name, fn in (("cfg3", cfg3), ("cfg5", cfg5)):
+    for name, fn in (("cfg3", cfg3), ("cfg5", cfg5), ("files", files),
+                     ("pcie", pcie)):
         if args.only and args.only != name:
             continue
         print(json.dumps(fn(args, ctx, dev)), flush=True)

@@ -799,7 +799,9 @@ __global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
         if (y0 >= hi)
             hi = y0 & ~127u; // jumped past the frontier: restart there
         const bool stall = y0 + 17 > hi;
-        const bool fill = y0 + 81 > hi;
+        // (never fetch past the block's own last line: the next line may be
+        // the first one behind the caller's allocation)
+        const bool fill = y0 + 81 > hi && hi < ((n + mis + 127u) & ~127u);
         uint32_t q0, q1, q2, q3, r0, r1, r2, r3;
         {
             const uint32_t w0 = y0 >> 2, sh = y0 & 3;

@@ -134,7 +134,12 @@ struct FrameCompressArgs {
     uint64_t out_cap;
     uint64_t *out_len;       // [1]
     uint64_t *chunk_offsets; // optional [n+1]
-    uint32_t n;              // chunks
+    uint32_t n;              // chunks of the whole stream
+    // The stream is processed in segments of `cnt` chunks starting at chunk
+    // `lo`, so the per-chunk scratch (one 76 KiB slot each) stays bounded;
+    // the arrays below are per segment, `base` carries the output offset.
+    uint32_t lo, cnt;
+    uint64_t *base; // [1] payload bytes emitted by earlier segments
     // scratch
     const void **in_ptrs;
     uint64_t *in_lens;
@@ -149,9 +154,9 @@ struct FrameCompressArgs {
 __global__ void k_frame_chunks(FrameCompressArgs a)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n)
+    if (i >= a.cnt)
         return;
-    const uint64_t off = (uint64_t)i * kMaxBlock;
+    const uint64_t off = (uint64_t)(a.lo + i) * kMaxBlock;
     const uint64_t len =
         a.in_len - off < kMaxBlock ? a.in_len - off : kMaxBlock;
     a.in_ptrs[i] = a.in + off;
@@ -163,7 +168,7 @@ __global__ void k_frame_chunks(FrameCompressArgs a)
 __global__ void k_frame_sizes(FrameCompressArgs a)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n)
+    if (i >= a.cnt)
         return;
     const uint64_t len = a.in_lens[i];
     const uint64_t clen = a.clens[i];
@@ -209,14 +214,15 @@ __global__ __launch_bounds__(1024) void k_scan_u64(const uint64_t *in,
 // one workgroup per chunk: header (src/frame.rs:91-93) + payload
 __global__ __launch_bounds__(256) void k_frame_emit(FrameCompressArgs a)
 {
-    const uint32_t i = blockIdx.x;
+    const uint32_t i = blockIdx.x;   // chunk of this segment
+    const uint32_t gi = a.lo + i;    // chunk of the stream
     const uint64_t len = a.in_lens[i];
     const uint64_t clen = a.clens[i];
     const bool stored = clen >= len - len / 8;
     const uint64_t payload = stored ? len : clen;
-    const uint64_t at = 10 + a.offs[i];
+    const uint64_t at = 10 + a.base[0] + a.offs[i];
     gptr o = (gptr)a.out + at;
-    if (i == 0 && threadIdx.x < 10) {
+    if (gi == 0 && threadIdx.x < 10) {
         const uint8_t ident[10] = {0xFF, 0x06, 0x00, 0x00, 's',
                                    'N',  'a',  'P',  'p',  'Y'};
         ((gptr)a.out)[threadIdx.x] = ident[threadIdx.x];
@@ -232,13 +238,14 @@ __global__ __launch_bounds__(256) void k_frame_emit(FrameCompressArgs a)
         o[5] = (uint8_t)(crc >> 8);
         o[6] = (uint8_t)(crc >> 16);
         o[7] = (uint8_t)(crc >> 24);
+        const uint64_t end = 10 + a.base[0] + a.offs[a.cnt];
         if (a.chunk_offsets) {
-            a.chunk_offsets[i] = at;
-            if (i + 1 == a.n)
-                a.chunk_offsets[a.n] = 10 + a.offs[a.n];
+            a.chunk_offsets[gi] = at;
+            if (gi + 1 == a.n)
+                a.chunk_offsets[a.n] = end;
         }
-        if (i + 1 == a.n)
-            a.out_len[0] = 10 + a.offs[a.n];
+        if (gi + 1 == a.n)
+            a.out_len[0] = end;
     }
     gcptr from = stored ? (gcptr)a.in_ptrs[i]
                         : (gcptr)(a.slots + (uint64_t)i * kFrameSlot);
@@ -248,6 +255,12 @@ __global__ __launch_bounds__(256) void k_frame_emit(FrameCompressArgs a)
     const uint64_t t = payload & ~3ull;
     if (threadIdx.x < (payload & 3))
         to[t + threadIdx.x] = from[t + threadIdx.x];
+}
+
+// after a segment's emit: carry its bytes into the next segment's offsets
+__global__ void k_frame_advance(FrameCompressArgs a)
+{
+    a.base[0] += a.offs[a.cnt];
 }
 
 // ---------------------------------------------------------------------
@@ -684,10 +697,15 @@ int snapmi_frame_compress(snapmi_ctx *ctx, const void *d_in, uint64_t in_len,
     int rc = ensure_tables(ctx);
     if (rc)
         return rc;
+    // segments of at most lane_segment_blocks chunks (16 GiB of input by
+    // default): 76 KiB of slot + 128 KiB of tokens per chunk of a segment
+    const uint32_t seg = n < ctx->lane_segment_blocks
+                             ? n
+                             : ctx->lane_segment_blocks;
     const size_t desc_bytes =
-        (size_t)n * (8 + 8 + 8 + 8 + 4 + 8 + 8) + 8 + 16 * 8;
+        (size_t)seg * (8 + 8 + 8 + 8 + 4 + 8 + 8) + 8 + 16 * 8;
     if ((rc = reserve(ctx, ctx->fr_desc, desc_bytes)) ||
-        (rc = reserve(ctx, ctx->fr_slots, (size_t)n * kFrameSlot)))
+        (rc = reserve(ctx, ctx->fr_slots, (size_t)seg * kFrameSlot)))
         return rc;
     FrameCompressArgs a;
     uint8_t *p = (uint8_t *)ctx->fr_desc.p;
@@ -698,29 +716,37 @@ int snapmi_frame_compress(snapmi_ctx *ctx, const void *d_in, uint64_t in_len,
     a.out_len = d_out_len;
     a.chunk_offsets = d_chunk_offsets;
     a.n = n;
-    a.in_ptrs = carve<const void *>(p, n);
-    a.in_lens = carve<uint64_t>(p, n);
-    a.slot_ptrs = carve<void *>(p, n);
-    a.clens = carve<uint64_t>(p, n);
-    a.sizes = carve<uint64_t>(p, n);
-    a.offs = carve<uint64_t>(p, n + 1);
-    a.crcs = carve<uint32_t>(p, n);
+    a.base = carve<uint64_t>(p, 1);
+    a.in_ptrs = carve<const void *>(p, seg);
+    a.in_lens = carve<uint64_t>(p, seg);
+    a.slot_ptrs = carve<void *>(p, seg);
+    a.clens = carve<uint64_t>(p, seg);
+    a.sizes = carve<uint64_t>(p, seg);
+    a.offs = carve<uint64_t>(p, seg + 1);
+    a.crcs = carve<uint32_t>(p, seg);
     a.slots = (uint8_t *)ctx->fr_slots.p;
 
-    const uint32_t tb = 256, gb = (n + tb - 1) / tb;
-    hipLaunchKernelGGL(k_frame_chunks, dim3(gb), dim3(tb), 0, s, a);
-    // every chunk is a one-block raw stream: n blocks, no scratch slots
-    rc = launch_compress(ctx, a.in_ptrs, a.in_lens, a.slot_ptrs, nullptr,
-                         a.clens, nullptr, n, n, 0);
-    if (rc)
-        return rc;
-    hipLaunchKernelGGL(k_crc32c, dim3(n), dim3(64), 0, s, a.in_ptrs,
-                       a.in_lens, a.crcs, n,
-                       (const CrcTables *)ctx->fr_tables.p);
-    hipLaunchKernelGGL(k_frame_sizes, dim3(gb), dim3(tb), 0, s, a);
-    hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, s, a.sizes, a.offs,
-                       n);
-    hipLaunchKernelGGL(k_frame_emit, dim3(n), dim3(256), 0, s, a);
+    HIP_TRY(ctx, hipMemsetAsync(a.base, 0, sizeof(uint64_t), s));
+    for (uint32_t lo = 0; lo < n; lo += seg) {
+        const uint32_t cnt = n - lo < seg ? n - lo : seg;
+        a.lo = lo;
+        a.cnt = cnt;
+        const uint32_t tb = 256, gb = (cnt + tb - 1) / tb;
+        hipLaunchKernelGGL(k_frame_chunks, dim3(gb), dim3(tb), 0, s, a);
+        // every chunk is a one-block raw stream: cnt blocks, no scratch slots
+        rc = launch_compress(ctx, a.in_ptrs, a.in_lens, a.slot_ptrs, nullptr,
+                             a.clens, nullptr, cnt, cnt, 0);
+        if (rc)
+            return rc;
+        hipLaunchKernelGGL(k_crc32c, dim3(cnt), dim3(64), 0, s, a.in_ptrs,
+                           a.in_lens, a.crcs, cnt,
+                           (const CrcTables *)ctx->fr_tables.p);
+        hipLaunchKernelGGL(k_frame_sizes, dim3(gb), dim3(tb), 0, s, a);
+        hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, s, a.sizes,
+                           a.offs, cnt);
+        hipLaunchKernelGGL(k_frame_emit, dim3(cnt), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_frame_advance, dim3(1), dim3(1), 0, s, a);
+    }
     HIP_TRY(ctx, hipGetLastError());
     return SNAPMI_OK;
 }

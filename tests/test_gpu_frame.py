@@ -165,3 +165,30 @@ def test_frame_flush_boundaries(ctx):
     want = O.frame_compress(a) + O.frame_compress(b)[10:]
     assert sink.getvalue() == want
     assert frame.FrameDecoder(io.BytesIO(want), ctx).read_to_end() == a + b
+
+
+def test_frame_compress_in_segments(built):
+    """A stream longer than the encoder's segment (64 chunks here, 262 144 by
+    default) is framed segment by segment; bytes and side index must not
+    depend on the segmentation."""
+    import numpy as np
+    import rust_snappy_amd as R
+    from rust_snappy_amd import frame
+    data = b"".join(d for _, d in O.corpus_round()) * 4   # 179 chunks
+    want = O.frame_compress(data)
+    for mode in (0, 1):
+        c = R.raw.Context(0)
+        c.set_option("compress_mode", mode)
+        c.set_option("lane_min_blocks", 1)
+        c.set_option("lane_segment_blocks", 64)
+        d = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+        out, flen, index = frame.compress_device(c, d, want_index=True)
+        got = out[:flen].cpu().numpy().tobytes()
+        assert got == want, mode
+        idx = index.cpu().numpy()
+        assert idx[0] == 10 and idx[-1] == len(want)
+        back, m = frame.decompress_device(c, out, flen, index=index,
+                                          out_cap=len(data))
+        assert m == len(data)
+        assert back[:m].cpu().numpy().tobytes() == data
+        c.close()

@@ -282,3 +282,23 @@ def test_hw_lds_atomic_lane_order(ctx):
     out = subprocess.run([str(exe)], capture_output=True, text=True,
                          timeout=60).stdout
     assert "PASS ascending-lane order" in out, out
+
+
+def test_compress_stream_at_end_of_allocation(cctx):
+    """The input ends exactly where its device allocation ends: the kernels
+    may read whole cache lines, but never a line that starts behind the
+    stream (memory safety of the lane kernel's input window)."""
+    import torch
+    from rust_snappy_amd import batch
+    ctx = cctx
+    n = 8 << 20  # its own allocator segment: the stream ends at its end
+    rnd = O.corpus_round()
+    blob = (b"".join(d for _, d in rnd) * 4)[:n]
+    assert len(blob) == n
+    torch.cuda.empty_cache()
+    data = torch.frombuffer(bytearray(blob), dtype=torch.uint8).cuda()
+    src = batch.StreamBatch(data, np.array([0], dtype=np.int64),
+                            np.array([n], dtype=np.int64))
+    dst, lens, errs = batch.compress(ctx, src)
+    assert errs[0][0] == 0
+    assert dst.stream_bytes(0, lens[0]) == O.compress(blob)
