@@ -117,8 +117,8 @@ def cpu_baseline(rnd, seconds=8.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--gib", type=float, default=8.0,
                     help="uncompressed GiB per GPU (BASELINE cfg2: 8)")
     ap.add_argument("--no-cpu", action="store_true",
@@ -320,6 +320,13 @@ def main():
                 "unit": "GB/s", "frac": round(ach_d / HBM_PEAK_GBS, 5),
                 "traffic": traffic_d, "alg_bytes_per_launch": alg,
                 "avg_launch_ms": round(kd * 1e3, 3)},
+            # median and min over the timed steps (HIP events)
+            "kernel_ms_median": {
+                "compress": round(float(np.median(k_comp_ms)), 3),
+                "decompress": round(float(np.median(k_dec_ms)), 3)},
+            "kernel_ms_min": {
+                "compress": round(float(np.min(k_comp_ms)), 3),
+                "decompress": round(float(np.min(k_dec_ms)), 3)},
             "kernel_ms": {"plan": round(float(np.mean(plan_ms)), 3),
                           "compress": round(kc * 1e3, 3),
                           "compress_dominant": round(kdom * 1e3, 3),

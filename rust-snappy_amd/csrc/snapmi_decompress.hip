@@ -347,8 +347,13 @@ __global__ __launch_bounds__(1024) void k_plan_decompress(DecompressArgs a)
 __global__ __launch_bounds__(64) void k_decompress_streams(DecompressArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t ring[kRing];
+    // one bit per output byte of the current window (at most 64 elements of
+    // at most 64 bytes): set where an element starts
+    __shared__ __attribute__((aligned(8))) uint32_t starts[kWave * kWave / 32];
 
     const uint32_t lane = threadIdx.x;
+    starts[lane] = 0;
+    starts[lane + kWave] = 0;
     const uint64_t st = a.order[blockIdx.x];
     gcptr in = (gcptr)a.in_ptrs[st];
     const uint64_t in_len = a.in_lens[st];
@@ -507,6 +512,8 @@ __global__ __launch_bounds__(64) void k_decompress_streams(DecompressArgs a)
         }
         const uint32_t f_info = e_olen | (e_lit ? 0x80000000u : 0);
         const uint32_t f_key = xkey;
+        if (is_elem) // element-start bits of this window (cleared pass by pass)
+            atomicOr(&starts[f_rel >> 5], 1u << (f_rel & 31));
         TICK(4);
 #ifdef SNAPMI_PROFILE
         n_elem += E;
@@ -524,12 +531,9 @@ __global__ __launch_bounds__(64) void k_decompress_streams(DecompressArgs a)
             const uint32_t r = c0 + lane;
             const bool act = r < W;
             // element of each byte: starts inside this pass as a bit mask
-            const uint32_t erel = f_rel - c0;
-            const bool in_pass = is_elem && erel < kWave;
-            const uint32_t blo = (in_pass && erel < 32) ? (1u << erel) : 0;
-            const uint32_t bhi =
-                (in_pass && erel >= 32) ? (1u << (erel - 32)) : 0;
-            const uint64_t M = ((uint64_t)wave_or(bhi) << 32) | wave_or(blo);
+            const uint64_t M = uni64(*(const uint64_t *)&starts[c0 >> 5]);
+            if (lane == 0)
+                *(uint64_t *)&starts[c0 >> 5] = 0;
             const uint32_t nbefore = (uint32_t)__builtin_popcountll(
                 __ballot(is_elem && f_rel < c0));
             const uint32_t idx = nbefore - 1 + popc_below(M) +
@@ -548,7 +552,7 @@ __global__ __launch_bounds__(64) void k_decompress_streams(DecompressArgs a)
             // where the byte comes from
             const uint32_t off = e_key;
             uint32_t back = off; // copy: distance from this byte to its source
-            if (off < elen) {
+            if (__ballot(off < elen) != 0 && off < elen) {
                 // overlapping copy: pattern index k mod off (exact for
                 // k, off < 64); the source lies before the element start
                 const uint32_t q = (uint32_t)(

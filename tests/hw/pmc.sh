@@ -1,9 +1,10 @@
 #!/bin/bash
-# usage: pmc.sh <variant> <lane waves> <tag> "<counter group 1>" "<counter group 2>" ...
+# usage: pmc.sh <variant|-> <lane waves|-> <tag> "<counter group 1>" "<counter group 2>" ...
 # one rocprofv3 --pmc pass per counter group; prints per-kernel sums for k_match_blocks
 v=$1; w=$2; tag=$3; shift 3
 R=$PWD
-export SNAPMI_LANE_SHARE=1.0 SNAPMI_LIB=$R/rust-snappy_amd/variants/$v.so SNAPMI_LANE_WAVES=$w
+[ "$v" != "-" ] && export SNAPMI_LIB=$R/rust-snappy_amd/variants/$v.so
+[ "$w" != "-" ] && export SNAPMI_LANE_WAVES=$w
 cd /tmp && export TMPDIR=/tmp
 i=0
 for grp in "$@"; do
@@ -18,7 +19,7 @@ f, tag = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(float)
 for r in csv.DictReader(open(f)):
     k = r["Kernel_Name"]
-    if "k_match_blocks" in k or "k_compress_blocks" in k:
+    if "snapmi::" in k and "k_plan" not in k and "k_scan" not in k:
         acc[(k.split("(")[0][-16:], r["Counter_Name"])] += float(r["Counter_Value"])
 for (k, c), v in sorted(acc.items()):
     print(f"{tag} {k} {c} {v:.4g}")
