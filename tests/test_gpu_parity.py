@@ -302,3 +302,36 @@ def test_compress_stream_at_end_of_allocation(cctx):
     dst, lens, errs = batch.compress(ctx, src)
     assert errs[0][0] == 0
     assert dst.stream_bytes(0, lens[0]) == O.compress(blob)
+
+
+def test_decompress_foreign_encoder_streams(ctx):
+    """Streams this encoder never writes: copy-4 elements,
+    offsets beyond 64 KiB, overlapping copies, 4-byte literal lengths; also
+    truncated and corrupted variants of them against the oracle's errors."""
+    import foreign
+    cases = foreign.cases()
+    got, errs = gpu_decompress(ctx, [s for s, _ in cases])
+    for i, ((s, want), g) in enumerate(zip(cases, got)):
+        assert errs[i][0] == 0, (i, errs[i])
+        assert g == want, i
+    rng = random.Random(9)
+    muts, caps = [], []
+    for s, want in cases:
+        for _ in range(12):
+            b = bytearray(s)
+            for _ in range(rng.randrange(1, 3)):
+                b[rng.randrange(len(b))] = rng.randrange(256)
+            if rng.random() < 0.3:
+                b = b[:rng.randrange(1, len(b))]
+            muts.append(bytes(b))
+            try:
+                caps.append(min(O.decompress_len(muts[-1]), 1 << 22))
+            except O.SnapError:
+                caps.append(1024)
+    got, errs = gpu_decompress(ctx, muts, caps)
+    for m, cap, g, e in zip(muts, caps, got, errs):
+        try:
+            w = O.decompress(m, cap)
+            assert e[0] == 0 and g == w
+        except O.SnapError as oe:
+            assert (oe.kind, oe.a, oe.b, oe.c) == e, (e, oe)

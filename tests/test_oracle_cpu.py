@@ -124,3 +124,14 @@ def test_frame_structure_and_roundtrip():
     with pytest.raises(O.SnapError) as ei:   # test/tests.rs:536-545
         O.frame_decompress(b"123")
     assert ei.value.kind == -1
+
+
+def test_foreign_encoder_streams():
+    """copy-4, offsets beyond 64 KiB, overlapping copies, non-minimal literal
+    length forms: oracle == element-level model == libsnappy."""
+    import foreign
+    for stream, want in foreign.cases():
+        assert O.decompress_len(stream) == len(want)
+        assert O.decompress(stream, len(want)) == want
+        if O.libsnappy() is not None:
+            assert O.libsnappy_uncompress(stream) == want
