@@ -119,6 +119,14 @@ def cfg3(args, ctx, dev):
                                        index.numel() - 1)
         assert rc == 0
 
+    def dec_walk():  # no side index: the device walks the chunk headers
+        rc = L.snapmi_frame_decompress(ctx._h, C.c_void_p(out.data_ptr()),
+                                       flen, C.c_void_p(back.data_ptr()), n,
+                                       C.c_void_p(out_len.data_ptr()),
+                                       C.c_void_p(err.data_ptr()), None, 0)
+        assert rc == 0
+
+    tw = time_it(dec_walk, 1, ctx)
     td = time_it(dec, args.steps, ctx)
     # round trip of the timed decode against the generator's period
     per = back[:reps * period.numel()].view(reps, period.numel())
@@ -129,7 +137,9 @@ def cfg3(args, ctx, dev):
             "frame_encode_gibs": round(n / GIB / te, 2),
             "frame_decode_gibs": round(n / GIB / td, 2),
             "encode_ms": round(te * 1e3, 2), "decode_ms": round(td * 1e3, 2),
-            "decode_uses_side_index": True}
+            "decode_uses_side_index": True,
+            "frame_decode_no_index_gibs": round(n / GIB / tw, 2),
+            "decode_no_index_ms": round(tw * 1e3, 2)}
 
 
 def raw_tiles(ctx, dev, blob, gib, steps, want=None):
@@ -205,8 +215,8 @@ def files(args, ctx, dev):
 
 def pcie(args, ctx, dev):
     """Host to host through the frame layer: pinned host buffer -> H2D ->
-    snapmi_frame_compress -> D2H of the framed bytes, and the inverse (the
-    decoder walks the chunk headers itself, no side index).  This is what a
+    snapmi_frame_compress -> D2H of the framed bytes, and the inverse (chunk
+    headers scanned on the host, snapmi_frame_index_host, during the H2D).  This is what a
     host-side FrameEncoder / FrameDecoder pays per batch; bench.py's `value`
     is device resident."""
     import ctypes as C
@@ -244,11 +254,16 @@ def pcie(args, ctx, dev):
 
     def dec():
         d_out[:flen].copy_(h_out[:flen], non_blocking=True)
+        # chunk scan on the host while the copy is in flight
+        offs = frame.index_host(h_out[:flen])
+        d_idx = torch.from_numpy(offs).to(dev)
         torch.cuda.synchronize()
         rc = L.snapmi_frame_decompress(ctx._h, C.c_void_p(d_out.data_ptr()),
                                        flen, C.c_void_p(d_back.data_ptr()), n,
                                        C.c_void_p(out_len.data_ptr()),
-                                       C.c_void_p(err.data_ptr()), None, 0)
+                                       C.c_void_p(err.data_ptr()),
+                                       C.c_void_p(d_idx.data_ptr()),
+                                       len(offs) - 1)
         assert rc == 0
         ctx.synchronize()
         h_back.copy_(d_back, non_blocking=True)

@@ -256,6 +256,22 @@ int snapmi_frame_decompress(snapmi_ctx *ctx, const void *d_in,
                             const uint64_t *d_chunk_offsets,
                             uint64_t n_chunks);
 
+/* Host-side chunk scan of a framed stream that is still in HOST memory: the
+ * hops FrameDecoder::read makes while it reads (src/read.rs:105-172).  The
+ * format is a linked list of chunk headers; on the device every hop is a
+ * dependent HBM access (~0.7 us), on the host it is free while the bytes are
+ * being staged.  Writes the offsets of the DATA chunk headers (types 0x00 and
+ * 0x01) and, last, in_len: n + 1 values; copy them to the device and pass
+ * them as d_chunk_offsets.  h_offsets may be NULL to count only.
+ * Returns 0 and *n_chunks for a structurally regular stream (identifier
+ * first; data, skippable, padding and repeated identifier chunks; ends on a
+ * chunk boundary; every length within the format's limits), 1 otherwise or
+ * when `cap` < n + 1: decode such a stream WITHOUT an index and the device
+ * walk reports the reference's error.  No GPU work. */
+int snapmi_frame_index_host(const void *h_in, uint64_t in_len,
+                            uint64_t *h_offsets, uint64_t cap,
+                            uint64_t *n_chunks);
+
 /* Masked CRC32C (reference CheckSummer::crc32c_masked, src/crc32.rs:35-38)
  * of n buffers of at most 65536 bytes each. */
 int snapmi_crc32c_masked_batch(snapmi_ctx *ctx, const void *const *d_ptrs,

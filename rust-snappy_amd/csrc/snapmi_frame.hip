@@ -25,6 +25,7 @@
 //   k_frame_verify    CRC comparison, first error in stream order
 #include <hip/hip_runtime.h>
 
+#include <string.h>
 #include <vector>
 
 #include "snapmi.h"
@@ -749,6 +750,55 @@ int snapmi_frame_compress(snapmi_ctx *ctx, const void *d_in, uint64_t in_len,
     }
     HIP_TRY(ctx, hipGetLastError());
     return SNAPMI_OK;
+}
+
+int snapmi_frame_index_host(const void *h_in, uint64_t in_len,
+                            uint64_t *h_offsets, uint64_t cap,
+                            uint64_t *n_chunks)
+{
+    // the regular cases of k_frame_walk (reference src/read.rs:111-236);
+    // anything else is left to the device walk, which owns the error report
+    if (!n_chunks || (in_len && !h_in))
+        return 1;
+    const uint8_t *in = (const uint8_t *)h_in;
+    uint64_t r = 0, nd = 0;
+    bool seen_ident = false;
+    while (r != in_len) {
+        if (in_len - r < 4)
+            return 1;
+        const uint32_t ty = in[r];
+        const uint64_t len = (uint64_t)in[r + 1] | ((uint64_t)in[r + 2] << 8) |
+                             ((uint64_t)in[r + 3] << 16);
+        const uint64_t at = r;
+        r += 4;
+        if (!seen_ident && ty != 0xFF)
+            return 1;
+        seen_ident = true;
+        if (len > kMaxChunk || (ty >= 0x02 && ty <= 0x7F) ||
+            in_len - r < len)
+            return 1;
+        if (ty == 0xFF) {
+            if (len != 6 || memcmp(in + r, "sNaPpY", 6) != 0)
+                return 1;
+        } else if (ty <= 0x01) {
+            if (len < 4 || (ty == 0x01 && len - 4 > kMaxBlock))
+                return 1;
+            if (h_offsets) {
+                if (nd + 1 >= cap)
+                    return 1;
+                h_offsets[nd] = at;
+            }
+            nd++;
+        }
+        r += len;
+    }
+    if (h_offsets) {
+        if (nd + 1 > cap)
+            return 1;
+        h_offsets[nd] = in_len;
+    }
+    *n_chunks = nd;
+    return 0;
 }
 
 int snapmi_frame_decompress(snapmi_ctx *ctx, const void *d_in,

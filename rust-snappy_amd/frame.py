@@ -92,6 +92,28 @@ def decompress_device(ctx, d_in, n_in, index=None, out_cap=None):
     return out, int(out_len.item())
 
 
+def index_host(data):
+    """Chunk scan of a framed stream in host memory (the hops of
+    FrameDecoder::read, src/read.rs:105-172): int64 array of the data chunk
+    header offsets plus len(data), or None when the stream is not structurally
+    regular (decode it without an index: the device walk reports the error)."""
+    L = _lib.load()
+    if hasattr(data, "data_ptr"):  # a host (CPU) uint8 tensor, not copied
+        assert data.device.type == "cpu"
+        buf, size = C.c_void_p(data.data_ptr()), data.numel()
+    else:
+        data = bytes(data)
+        buf, size = data, len(data)
+    n = C.c_uint64(0)
+    if L.snapmi_frame_index_host(buf, size, None, 0, C.byref(n)):
+        return None
+    offs = np.zeros(n.value + 1, dtype=np.uint64)
+    if L.snapmi_frame_index_host(buf, size, offs.ctypes.data_as(
+            C.c_void_p), len(offs), C.byref(n)):
+        return None
+    return offs.astype(np.int64)
+
+
 def crc32c_masked(ctx, data):
     """CheckSummer::crc32c_masked (reference src/crc32.rs:35-38) of one
     buffer of at most 65536 bytes, on the device."""
@@ -181,7 +203,11 @@ class FrameDecoder:
             self._out = b""
             return
         d_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
-        out, n = decompress_device(self.ctx, d_in, len(data))
+        # the reader's bytes pass through the host anyway: scan the chunk
+        # headers here and spare the device its sequential walk
+        offs = index_host(data)
+        index = torch.from_numpy(offs).to(dev) if offs is not None else None
+        out, n = decompress_device(self.ctx, d_in, len(data), index=index)
         self._out = out[:n].cpu().numpy().tobytes()
 
     def read(self, size=-1):

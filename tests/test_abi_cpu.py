@@ -88,3 +88,31 @@ def test_product_never_touches_the_oracle():
             pkg.rglob("*.hpp")) + [ROOT / "include" / "snapmi.h"]:
         text = p.read_text()
         assert "oracle" not in text.lower() or p.name == "__init__.py", p
+
+
+def test_frame_index_host(built):
+    """snapmi_frame_index_host is host code (no GPU): data chunk offsets of a
+    regular stream, None for anything the device walk must report."""
+    import oracle_lib as O
+    from rust_snappy_amd import frame
+    data = b"".join(d for _, d in O.corpus_round()[:5])
+    f = O.frame_compress(data)
+    offs = frame.index_host(f)
+    assert offs[0] == 10 and offs[-1] == len(f)
+    assert len(offs) - 1 == (len(data) + 65535) // 65536
+    pos = 10
+    for o in offs[:-1]:  # headers chain exactly
+        assert o == pos and f[o] in (0, 1)
+        pos += 4 + int.from_bytes(f[o + 1:o + 4], "little")
+    assert pos == len(f)
+    first = int(offs[1] - offs[0])
+    g = (f[:10] + bytes([0x80, 3, 0, 0, 1, 2, 3]) + f[10:10 + first]
+         + bytes([0xFE, 2, 0, 0, 9, 9]) + f[:10] + f[10 + first:])
+    o2 = frame.index_host(g)
+    assert len(o2) == len(offs) and o2[0] == 17 and o2[-1] == len(g)
+    assert frame.index_host(b"") is not None and len(frame.index_host(b"")) == 1
+    for bad in (f[:-1], b"\x00" + f, f[:10] + bytes([0x02, 0, 0, 0]),
+                f[:10] + bytes([0x00, 3, 0, 0, 1, 2, 3]),
+                f[:4] + b"sNaPpX" + f[10:],
+                f[:10] + bytes([0x01, 0x05, 0x00, 0x01]) + bytes(65541)):
+        assert frame.index_host(bad) is None

@@ -192,3 +192,17 @@ def test_frame_compress_in_segments(built):
         assert m == len(data)
         assert back[:m].cpu().numpy().tobytes() == data
         c.close()
+
+
+def test_frame_decoder_host_index_with_other_chunk_types(ctx):
+    """FrameDecoder scans the chunk headers on the host; skippable, padding
+    and repeated identifier chunks between the data chunks do not matter."""
+    from rust_snappy_amd import frame
+    data = b"".join(d for _, d in O.corpus_round()[:4])
+    f = O.frame_compress(data)
+    offs = frame.index_host(f)
+    first = int(offs[1] - offs[0])
+    g = (f[:10] + bytes([0x80, 3, 0, 0, 1, 2, 3]) + f[10:10 + first]
+         + bytes([0xFE, 2, 0, 0, 9, 9]) + f[:10] + f[10 + first:])
+    assert frame.FrameDecoder(io.BytesIO(g), ctx).read_to_end() == data
+    assert frame.FrameDecoder(io.BytesIO(f), ctx).read_to_end() == data
