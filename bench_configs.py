@@ -280,6 +280,62 @@ def pcie(args, ctx, dev):
             "encode_ms": round(te * 1e3, 2), "decode_ms": round(td * 1e3, 2)}
 
 
+def stream(args, ctx, dev):
+    """ONE raw stream of --gib (the 12 corpus files repeated): compressed as
+    one Encoder::compress call (blocks in parallel), decoded by
+    snapmi_decompress_stream (many wavefronts) and, for comparison, as a
+    batch of one stream (a single wavefront, 1/16 of the data)."""
+    import oracle_lib as O
+    from rust_snappy_amd import batch, raw
+    blob = b"".join(d for _, d in O.corpus_round())
+    reps = max(1, int(min(args.gib, 3.0) * GIB / len(blob)))  # < 2^32 * 6/7
+    one = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+    data = one.repeat(reps)
+    n = data.numel()
+    src = batch.StreamBatch(data, np.array([0], dtype=np.int64),
+                            np.array([n], dtype=np.int64))
+    comp = batch.StreamBatch.empty(
+        np.array([raw.max_compress_len(n)], dtype=np.int64), dev)
+    clen = torch.zeros(1, dtype=torch.int64, device=dev)
+    raw.compress_batch(ctx, src.d_ptrs, src.d_lens, comp.d_ptrs, comp.d_lens,
+                       clen, None, host_in_lens=src.h_lens)
+    ctx.synchronize()
+    c = int(clen.item())
+    back = torch.empty(n, dtype=torch.uint8, device=dev)
+    out_len = torch.zeros(1, dtype=torch.int64, device=dev)
+    err = torch.zeros(32, dtype=torch.uint8, device=dev)
+
+    def dec():
+        raw.decompress_stream(ctx, comp.data, c, back, out_len, err)
+
+    td = time_it(dec, args.steps, ctx)
+    assert raw.stream_decode_path(ctx) == 0
+    assert int(out_len.item()) == n
+    per = back.view(reps, len(blob))
+    for r in range(0, reps, max(1, reps // 16)):
+        assert torch.equal(per[r], one), "stream round trip"
+    # a single wavefront on 1/16 of it
+    m = (reps // 16 or 1) * len(blob)
+    src1 = batch.StreamBatch(data, np.array([0], dtype=np.int64),
+                             np.array([m], dtype=np.int64))
+    raw.compress_batch(ctx, src1.d_ptrs, src1.d_lens, comp.d_ptrs,
+                       comp.d_lens, clen, None, host_in_lens=src1.h_lens)
+    ctx.synchronize()
+    cap1 = torch.tensor([m], dtype=torch.int64, device=dev)
+    optr = torch.tensor([back.data_ptr()], dtype=torch.int64, device=dev)
+
+    def dec1():
+        raw.decompress_batch(ctx, comp.d_ptrs, clen, optr, cap1, out_len, None)
+
+    t1 = time_it(dec1, 1, ctx)
+    return {"config": "one raw stream, device resident",
+            "gib": round(n / GIB, 3), "ratio": round(c / n, 4),
+            "decompress_stream_gibs": round(n / GIB / td, 2),
+            "decompress_stream_ms": round(td * 1e3, 2),
+            "one_wavefront_gibs": round(m / GIB / t1, 3),
+            "one_wavefront_gib": round(m / GIB, 3)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gib", type=float, default=8.0)
@@ -293,7 +349,7 @@ def main():
     dev = torch.device("cuda", 0)
     ctx = raw.Context(0)
     for name, fn in (("cfg3", cfg3), ("cfg5", cfg5), ("files", files),
-                     ("pcie", pcie)):
+                     ("pcie", pcie), ("stream", stream)):
         if args.only and args.only != name:
             continue
         print(json.dumps(fn(args, ctx, dev)), flush=True)

@@ -183,6 +183,29 @@ int snapmi_decompress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                             const uint64_t *d_out_caps, uint64_t *d_out_lens,
                             snapmi_error *d_errs, size_t n);
 
+/*
+ * ONE long raw stream, device resident, decoded by many wavefronts.
+ * A raw stream has no index (reference src/decompress.rs:130-148 walks it
+ * element by element) and snapmi_decompress_batch gives a stream to a single
+ * wavefront; here the element chain is first resolved by a hierarchical scan
+ * (4 KiB segments, 256 KiB super-segments, one short sequential pass), the
+ * stream is cut at the element boundaries next to every 64 KiB of output,
+ * and the pieces are decoded like independent streams.  Streams of this
+ * encoder, the reference and libsnappy (64 KiB blocks) always take that
+ * path; a stream whose pieces depend on each other (a copy reaching across a
+ * cut), or with any error, is decoded by the sequential path, so results and
+ * errors are those of snapmi_decompress_batch with n = 1.  Asynchronous on
+ * the context's stream; d_out_len[0] / d_err[0] as in the batch call.
+ * The scalar entry points use it for inputs of 256 KiB and more.
+ */
+int snapmi_decompress_stream(snapmi_ctx *ctx, const void *d_in,
+                             uint64_t in_len, void *d_out, uint64_t out_cap,
+                             uint64_t *d_out_len, snapmi_error *d_err);
+/* Which way the last snapmi_decompress_stream on this context went (waits
+ * for it): 0 = pieces on many wavefronts, 1 = the sequential path, -1 = no
+ * such call yet.  For tests and benchmarks. */
+int snapmi_stream_decode_path(snapmi_ctx *ctx);
+
 /* decompress_len for n streams on the device (reference
  * src/decompress.rs:30-35): d_out_lens[i] = header value, d_errs[i] as the
  * reference would return. */

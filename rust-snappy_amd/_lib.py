@@ -53,6 +53,9 @@ SYMBOLS = [
     ("snapmi_compress_batch", C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _SZ]),
     ("snapmi_decompress_batch", C.c_int, [_P, _P, _P, _P, _P, _P, _P, _SZ]),
     ("snapmi_decompress_len_batch", C.c_int, [_P, _P, _P, _P, _P, _SZ]),
+    ("snapmi_decompress_stream", C.c_int,
+     [_P, _P, C.c_uint64, _P, C.c_uint64, _P, _P]),
+    ("snapmi_stream_decode_path", C.c_int, [_P]),
     ("snapmi_ctx_synchronize", C.c_int, [_P]),
     ("snapmi_last_timing", C.c_int, [_P, C.POINTER(SnapmiTiming)]),
     ("snapmi_frame_max_len", _SZ, [_SZ]),

@@ -156,7 +156,7 @@ void snapmi_ctx_destroy(snapmi_ctx *ctx)
                       &ctx->order, &ctx->fr_tables, &ctx->fr_desc,
                       &ctx->fr_meta, &ctx->fr_scan, &ctx->fr_slots,
                       &ctx->tokens, &ctx->ntok, &ctx->lane_tables,
-                      &ctx->lane_epochs})
+                      &ctx->lane_epochs, &ctx->sd_tables, &ctx->sd_desc})
         if (b->p)
             (void)hipFree(b->p);
     for (auto &ev : ctx->ev)
@@ -447,10 +447,14 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
 int launch_decompress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                       const uint64_t *d_in_lens, void *const *d_out_ptrs,
                       const uint64_t *d_out_caps, uint64_t *d_out_lens,
-                      snapmi_error *d_errs, const uint8_t *d_modes, size_t n)
+                      snapmi_error *d_errs, const uint8_t *d_modes, size_t n,
+                      const unsigned long long *d_gate,
+                      unsigned long long gate_value)
 {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DecompressArgs a;
+    a.gate = d_gate;
+    a.gate_value = gate_value;
     a.in_ptrs = d_in_ptrs;
     a.in_lens = d_in_lens;
     a.out_ptrs = d_out_ptrs;
@@ -515,6 +519,156 @@ int snapmi_decompress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                              d_out_lens, d_errs, nullptr, n);
 }
 
+#define STREAM_CHECK(name)                                                    \
+    do {                                                                      \
+        hipError_t _e = hipGetLastError();                                    \
+        if (_e != hipSuccess)                                                 \
+            return fail_ctx(ctx, SNAPMI_E_DEVICE, "launch of " #name ": %s",  \
+                            hipGetErrorString(_e));                           \
+    } while (0)
+
+int snapmi_decompress_stream(snapmi_ctx *ctx, const void *d_in,
+                             uint64_t in_len, void *d_out, uint64_t out_cap,
+                             uint64_t *d_out_len, snapmi_error *d_err)
+{
+    if (!ctx || !d_out_len || !d_err || (in_len && !d_in) ||
+        (out_cap && !d_out))
+        return fail_ctx(ctx, SNAPMI_E_ARGUMENT, "decompress_stream: bad args");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    // pieces: one per 64 KiB of output; the output cannot exceed out_cap nor
+    // ~21.4x the input (a 3-byte copy element yields at most 64 bytes)
+    uint64_t bound = out_cap;
+    if (in_len < (1ull << 40) && in_len * 22 < bound)
+        bound = in_len * 22;
+    const uint64_t kmax64 = bound / kStreamChunk + 2;
+    const uint64_t nseg64 = (in_len + kSeg - 1) / kSeg + 1;
+    if (kmax64 > 0x3FFFFFFFu || nseg64 > 0x3FFFFFFFu)
+        return fail_ctx(ctx, SNAPMI_E_ARGUMENT, "decompress_stream: too long");
+    StreamArgs a;
+    a.in = (const uint8_t *)d_in;
+    a.in_len = in_len;
+    a.out = (uint8_t *)d_out;
+    a.out_cap = out_cap;
+    a.out_len = (unsigned long long *)d_out_len;
+    a.err = d_err;
+    a.nseg = (uint32_t)nseg64;
+    a.nsuper = (a.nseg + kSegPerSuper - 1) / kSegPerSuper;
+    a.nsuper3 = (a.nsuper + kSegPerSuper - 1) / kSegPerSuper;
+    a.kmax = (uint32_t)kmax64;
+    const size_t blocks = (size_t)a.nseg + a.nsuper + a.nsuper3;
+    const size_t rows = (size_t)a.nseg +
+                        ((size_t)a.nsuper + a.nsuper3) * kSegPerSuper;
+    const size_t t_bytes = 64 + rows * kWave * 16 + blocks * 16 +
+                           ((size_t)a.kmax + 1) * 16;
+    // descriptors: the pieces, then the whole stream as batch entry [kmax]
+    const size_t d_stride = 8 + 8 + 8 + 8 + 8 + sizeof(snapmi_error);
+    const size_t d_bytes = ((size_t)a.kmax + 1) * (d_stride + 1) + 64;
+    int rc;
+    if ((rc = reserve(ctx, ctx->sd_tables, t_bytes)) ||
+        (rc = reserve(ctx, ctx->sd_desc, d_bytes)))
+        return rc;
+    unsigned long long *t = (unsigned long long *)ctx->sd_tables.p;
+    a.meta = t;
+    t += 8;
+    a.s1 = t;
+    t += (size_t)a.nseg * kWave * 2;
+    a.s2 = t;
+    t += (size_t)a.nsuper * kSegPerSuper * kWave * 2;
+    a.s3 = t;
+    t += (size_t)a.nsuper3 * kSegPerSuper * kWave * 2;
+    a.e1 = t; // e1, e2, e3 contiguous: one memset
+    t += (size_t)a.nseg * 2;
+    a.e2 = t;
+    t += (size_t)a.nsuper * 2;
+    a.e3 = t;
+    t += (size_t)a.nsuper3 * 2;
+    a.cuts = t;
+    const size_t m = (size_t)a.kmax + 1;
+    uint8_t *q = (uint8_t *)ctx->sd_desc.p;
+    a.c_in = (const void **)q;
+    q += m * 8;
+    a.c_inlen = (unsigned long long *)q;
+    q += m * 8;
+    a.c_out = (void **)q;
+    q += m * 8;
+    a.c_cap = (unsigned long long *)q;
+    q += m * 8;
+    a.c_outlen = (unsigned long long *)q;
+    q += m * 8;
+    a.c_err = (snapmi_error *)q;
+    q += m * sizeof(snapmi_error);
+    a.c_mode = q;
+
+    // entry [kmax]: the stream itself, for the sequential decoder
+    struct {
+        const void *in;
+        uint64_t in_len;
+        void *out;
+        uint64_t cap;
+    } whole = {d_in, in_len, d_out, out_cap};
+    HIP_TRY(ctx, hipMemcpyAsync((void *)&a.c_in[a.kmax], &whole.in, 8,
+                                hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(&a.c_inlen[a.kmax], &whole.in_len, 8,
+                                hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(&a.c_out[a.kmax], &whole.out, 8,
+                                hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(&a.c_cap[a.kmax], &whole.cap, 8,
+                                hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemsetAsync(&a.c_mode[a.kmax], 0, 1, s));
+    HIP_TRY(ctx, hipMemsetAsync(a.e1, 0xFF, blocks * 16, s));
+
+    hipLaunchKernelGGL(k_stream_head, dim3(1), dim3(1), 0, s, a);
+    STREAM_CHECK(k_stream_head);
+    hipLaunchKernelGGL(k_stream_scan, dim3(a.nseg), dim3(64), 0, s, a);
+    STREAM_CHECK(k_stream_scan);
+    hipLaunchKernelGGL(k_stream_super, dim3(a.nsuper), dim3(64), 0, s, a);
+    STREAM_CHECK(k_stream_super);
+    hipLaunchKernelGGL(k_stream_super3, dim3(a.nsuper3), dim3(64), 0, s, a);
+    STREAM_CHECK(k_stream_super3);
+    hipLaunchKernelGGL(k_stream_chain, dim3(1), dim3(1), 0, s, a);
+    STREAM_CHECK(k_stream_chain);
+    hipLaunchKernelGGL(k_stream_spread3, dim3((a.nsuper3 + 63) / 64),
+                       dim3(64), 0, s, a);
+    STREAM_CHECK(k_stream_spread3);
+    hipLaunchKernelGGL(k_stream_spread2, dim3((a.nsuper + 63) / 64), dim3(64),
+                       0, s, a);
+    STREAM_CHECK(k_stream_spread2);
+    hipLaunchKernelGGL(k_stream_cuts, dim3((a.nseg + 63) / 64), dim3(64), 0,
+                       s, a);
+    STREAM_CHECK(k_stream_cuts);
+    hipLaunchKernelGGL(k_stream_pieces, dim3((a.kmax + 255) / 256), dim3(256),
+                       0, s, a);
+    STREAM_CHECK(k_stream_pieces);
+    // the pieces, unless the scan gave up (meta[2] == 1) ...
+    rc = launch_decompress(ctx, a.c_in, (const uint64_t *)a.c_inlen, a.c_out,
+                           (const uint64_t *)a.c_cap, (uint64_t *)a.c_outlen,
+                           a.c_err, a.c_mode, a.kmax, a.meta + 2, 0);
+    if (rc)
+        return rc;
+    hipLaunchKernelGGL(k_stream_finish, dim3(1), dim3(1024), 0, s, a);
+    // ... and the sequential decoder over the whole stream if anything was
+    // irregular: it owns the error report
+    return launch_decompress(ctx, a.c_in + a.kmax,
+                             (const uint64_t *)a.c_inlen + a.kmax,
+                             a.c_out + a.kmax,
+                             (const uint64_t *)a.c_cap + a.kmax, d_out_len,
+                             d_err, a.c_mode + a.kmax, 1, a.meta + 2, 1);
+}
+
+int snapmi_stream_decode_path(snapmi_ctx *ctx)
+{
+    if (!ctx || !ctx->sd_tables.p)
+        return -1;
+    unsigned long long meta[4];
+    if (hipSetDevice(ctx->device) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess ||
+        hipMemcpy(meta, ctx->sd_tables.p, sizeof meta,
+                  hipMemcpyDeviceToHost) != hipSuccess)
+        return -1;
+    return meta[2] ? 1 : 0;
+}
+
 int snapmi_decompress_len_batch(snapmi_ctx *ctx,
                                 const void *const *d_in_ptrs,
                                 const uint64_t *d_in_lens,
@@ -541,6 +695,8 @@ int snapmi_decompress_len_batch(snapmi_ctx *ctx,
     a.order = nullptr;
     a.bucket_pos = nullptr;
     a.prof = nullptr;
+    a.gate = nullptr;
+    a.gate_value = 0;
     hipLaunchKernelGGL(k_decompress_len, dim3((uint32_t)((n + 255) / 256)),
                        dim3(256), 0, ctx->stream, a);
     HIP_TRY(ctx, hipGetLastError());
@@ -596,6 +752,13 @@ struct OneDesc {
     snapmi_error err;
 };
 
+// compressed bytes from which the scalar decompress entry points use
+// snapmi_decompress_stream (SNAPMI_LONG_STREAM overrides)
+static const size_t kLongStream = [] {
+    const char *e = getenv("SNAPMI_LONG_STREAM");
+    return e ? (size_t)atoll(e) : (size_t)(256 << 10);
+}();
+
 int run_one(snapmi_ctx *ctx, bool compress, const uint8_t *input,
             size_t input_len, uint8_t *output, size_t output_cap,
             size_t *written, snapmi_error *err)
@@ -642,6 +805,12 @@ int run_one(snapmi_ctx *ctx, bool compress, const uint8_t *input,
         rc = snapmi_compress_batch(ctx, &d->in_ptr, &d->in_len, &hl,
                                    &d->out_ptr, &d->out_cap, &d->out_len,
                                    &d->err, 1);
+    } else if (input_len >= kLongStream) {
+        // one wavefront decodes ~50 MB/s: long streams go through the
+        // parallel single-stream path
+        rc = snapmi_decompress_stream(ctx, ctx->st_in.p, input_len,
+                                      ctx->st_out.p, output_cap, &d->out_len,
+                                      &d->err);
     } else {
         rc = snapmi_decompress_batch(ctx, &d->in_ptr, &d->in_len, &d->out_ptr,
                                      &d->out_cap, &d->out_len, &d->err, 1);

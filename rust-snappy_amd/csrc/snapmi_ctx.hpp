@@ -39,6 +39,8 @@ struct snapmi_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // staging for the host-pointer (scalar) entry points
     snapmi::DevBuf st_in, st_out, st_desc, st_prof, ticket, order;
+    // long-stream decode scratch (snapmi_decompress_stream)
+    snapmi::DevBuf sd_tables, sd_desc;
     // frame layer scratch (snapmi_frame.hip)
     snapmi::DevBuf fr_tables, fr_desc, fr_meta, fr_scan, fr_slots;
     bool fr_tables_ready = false;
@@ -107,5 +109,7 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
 int launch_decompress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                       const uint64_t *d_in_lens, void *const *d_out_ptrs,
                       const uint64_t *d_out_caps, uint64_t *d_out_lens,
-                      snapmi_error *d_errs, const uint8_t *d_modes, size_t n);
+                      snapmi_error *d_errs, const uint8_t *d_modes, size_t n,
+                      const unsigned long long *d_gate = nullptr,
+                      unsigned long long gate_value = 0);
 } // namespace snapmi

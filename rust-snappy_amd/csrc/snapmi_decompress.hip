@@ -316,6 +316,8 @@ __global__ __launch_bounds__(256) void k_decompress_len(DecompressArgs a)
 __global__ __launch_bounds__(1024) void k_plan_decompress(DecompressArgs a)
 {
     __shared__ uint32_t hist[64];
+    if (a.gate && *a.gate != a.gate_value)
+        return;
     if (threadIdx.x < 64)
         hist[threadIdx.x] = 0;
     __syncthreads();
@@ -352,13 +354,16 @@ __global__ __launch_bounds__(64) void k_decompress_streams(DecompressArgs a)
     __shared__ __attribute__((aligned(8))) uint32_t starts[kWave * kWave / 32];
 
     const uint32_t lane = threadIdx.x;
+    if (a.gate && uni64(*a.gate) != a.gate_value)
+        return;
     starts[lane] = 0;
     starts[lane + kWave] = 0;
     const uint64_t st = a.order[blockIdx.x];
     gcptr in = (gcptr)a.in_ptrs[st];
     const uint64_t in_len = a.in_lens[st];
+    const bool piece = a.modes && a.modes[st] == 2;
 
-    if (a.modes && a.modes[st]) {
+    if (a.modes && a.modes[st] == 1) {
         // stored frame chunk (reference src/read.rs:173-199): the payload is
         // the data; 256 bytes per instruction
         const uint64_t cap0 = a.out_caps[st];
@@ -377,11 +382,13 @@ __global__ __launch_bounds__(64) void k_decompress_streams(DecompressArgs a)
         return;
     }
     // reference Decoder::decompress, src/decompress.rs:75-95
-    if (in_len == 0)
-        SNAPMI_FAIL(SNAPMI_EMPTY, 0, 0, 0);
     uint32_t hdr = 0;
     uint64_t dst_len = 0;
-    {
+    if (piece) { // elements [in, in + in_len) produce exactly out_caps bytes
+        dst_len = a.out_caps[st];
+    } else {
+        if (in_len == 0)
+            SNAPMI_FAIL(SNAPMI_EMPTY, 0, 0, 0);
         snapmi_error *e = lane == 0 ? a.errs : nullptr;
         if (read_header(in, in_len, &hdr, &dst_len, e, st) != SNAPMI_OK) {
             if (lane == 0)
@@ -650,6 +657,358 @@ __global__ __launch_bounds__(64) void k_decompress_streams(DecompressArgs a)
     if (lane == 0) {
         set_error(a.errs, st, SNAPMI_OK, 0, 0, 0);
         a.out_lens[st] = dst_len;
+    }
+}
+
+// ---------------------------------------------------------------------
+// One long raw stream on many wavefronts (snapmi_decompress_stream).
+//
+// A raw stream has no index and its elements form a chain, but where the
+// chain goes is cheap to tabulate: a lane that starts at byte o of a 4 KiB
+// segment and hops from element to element leaves the segment at some
+// position, having produced some number of bytes.  Chains from neighbouring
+// offsets merge within a few elements, so the 64 lanes of a wave mostly read
+// the same bytes.  Segments -> super-segments (64 segments) -> one short
+// sequential pass over the super-segments -> the exact (src, dst) positions
+// of the element boundaries at every 64 KiB of output -> those pieces are
+// decoded by k_decompress_streams like independent streams.  Anything
+// irregular (an element the scan cannot follow, a piece that fails one of
+// the reference's checks - which includes a copy reaching back into another
+// piece) sets meta[2] and the whole stream is decoded by the sequential
+// path instead, which also produces the reference's exact error.
+// ---------------------------------------------------------------------
+namespace {
+constexpr unsigned long long kNone = ~0ull;
+
+typedef unsigned long long su64x2 __attribute__((ext_vector_type(2)));
+
+// hop over the element at p; false if it does not fit in the stream
+__device__ __forceinline__ bool elem_step(gcptr in, uint64_t in_len,
+                                          uint64_t &p, uint64_t &out)
+{
+    const uint32_t tag = in[p];
+    const uint32_t type = tag & 3;
+    if (type == 0) {
+        const uint32_t n6 = tag >> 2;
+        uint64_t len = n6 + 1, hd = 1;
+        if (n6 >= 60) {
+            const uint32_t nb = n6 - 59;
+            if (p + 1 + nb > in_len)
+                return false;
+            uint32_t v = 0;
+            for (uint32_t k = 0; k < nb; k++)
+                v |= (uint32_t)in[p + 1 + k] << (8 * k);
+            len = (uint64_t)v + 1;
+            hd = 1 + nb;
+        }
+        if (in_len - (p + hd) < len)
+            return false;
+        p += hd + len;
+        out += len;
+    } else {
+        const uint32_t cnb = type == 1 ? 1 : (type == 2 ? 2 : 4);
+        if (p + 1 + cnb > in_len)
+            return false;
+        p += 1 + cnb;
+        out += type == 1 ? 4 + ((tag >> 2) & 7) : 1 + (tag >> 2);
+    }
+    return true;
+}
+
+// level 1 = 4 KiB segments, 2 = 256 KiB, 3 = 16 MiB
+template <int L> __device__ __forceinline__ uint64_t level_bytes()
+{
+    return L == 1 ? (uint64_t)kSeg
+                  : (L == 2 ? (uint64_t)kSeg * kSegPerSuper
+                            : (uint64_t)kSeg * kSegPerSuper * kSegPerSuper);
+}
+template <int L>
+__device__ __forceinline__ su64x2 *level_table(const StreamArgs &a)
+{
+    return (su64x2 *)(L == 1 ? a.s1 : (L == 2 ? a.s2 : a.s3));
+}
+template <int L>
+__device__ __forceinline__ su64x2 *level_entry(const StreamArgs &a)
+{
+    return (su64x2 *)(L == 1 ? a.e1 : (L == 2 ? a.e2 : a.e3));
+}
+
+// Follow the chain from p to the end of the level-L block that contains p
+// (or of the stream).  Tables: level 1 [segment][o]: enter the segment at
+// offset o < 64; levels 2, 3 [block][child][o]: enter the block at offset
+// o < 64 of its child (a block of the level below).  A position deeper than
+// 64 bytes inside a child - the chain landed there after a long element - is
+// first taken to that child's end one level down.
+template <int L>
+__device__ __forceinline__ bool reach_end(const StreamArgs &a, uint64_t &p,
+                                          uint64_t &out);
+template <>
+__device__ __forceinline__ bool reach_end<1>(const StreamArgs &a, uint64_t &p,
+                                             uint64_t &out)
+{
+    const uint64_t seg = p / kSeg;
+    const uint64_t o = p - seg * kSeg;
+    if (o < kWave) {
+        const su64x2 e = level_table<1>(a)[seg * kWave + o];
+        if (e.x == kNone)
+            return false;
+        p = e.x;
+        out += e.y;
+        return true;
+    }
+    uint64_t end = (seg + 1) * kSeg;
+    if (end > a.in_len)
+        end = a.in_len;
+    while (p < end)
+        if (!elem_step((gcptr)a.in, a.in_len, p, out))
+            return false;
+    return true;
+}
+template <int L>
+__device__ __forceinline__ bool reach_end(const StreamArgs &a, uint64_t &p,
+                                          uint64_t &out)
+{
+    const uint64_t B = level_bytes<L>(), Bc = level_bytes<L - 1>();
+    const uint64_t blk = p / B;
+    uint64_t end = (blk + 1) * B;
+    if (end > a.in_len)
+        end = a.in_len;
+    while (p < end) {
+        const uint64_t rel = p - blk * B;
+        const uint64_t c = rel / Bc, o = rel - c * Bc;
+        if (o < kWave) {
+            const su64x2 e =
+                level_table<L>(a)[(blk * kSegPerSuper + c) * kWave + o];
+            if (e.x == kNone)
+                return false;
+            p = e.x;
+            out += e.y;
+            return true;
+        }
+        if (!reach_end<L - 1>(a, p, out))
+            return false;
+    }
+    return true;
+}
+
+// table of one level-L block (L = 2, 3), children right to left: entering at
+// child c continues, after that child, with an entry already tabulated
+template <int L> __device__ __forceinline__ void build_level(const StreamArgs &a)
+{
+    __shared__ su64x2 tab[kSegPerSuper * kWave]; // 64 KiB
+    if (a.meta[2])
+        return;
+    const uint64_t B = level_bytes<L>(), Bc = level_bytes<L - 1>();
+    const uint64_t blk = blockIdx.x;
+    uint64_t end = (blk + 1) * B;
+    if (end > a.in_len)
+        end = a.in_len;
+    for (int c = kSegPerSuper - 1; c >= 0; c--) {
+        uint64_t p = blk * B + (uint64_t)c * Bc + threadIdx.x, out = 0;
+        bool ok = p < a.in_len && reach_end<L - 1>(a, p, out);
+        while (ok && p < end) {
+            const uint64_t rel = p - blk * B;
+            const uint64_t c2 = rel / Bc, o2 = rel - c2 * Bc;
+            if (o2 < kWave) {
+                const su64x2 e = tab[c2 * kWave + o2]; // c2 > c: done before
+                ok = e.x != kNone;
+                p = e.x;
+                out += e.y;
+                break;
+            }
+            ok = reach_end<L - 1>(a, p, out);
+        }
+        tab[c * kWave + threadIdx.x] = (su64x2){ok ? p : kNone, out};
+        __syncthreads();
+    }
+    su64x2 *dst = level_table<L>(a) + blk * kSegPerSuper * kWave;
+    for (uint32_t i = threadIdx.x; i < kSegPerSuper * kWave; i += kWave)
+        dst[i] = tab[i];
+}
+
+// entries of level L-1 from the entries of level L: one lane per block of
+// level L walks its children
+template <int L> __device__ __forceinline__ void spread_level(const StreamArgs &a)
+{
+    if (a.meta[2])
+        return;
+    const uint64_t blk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t B = level_bytes<L>(), Bc = level_bytes<L - 1>();
+    if (blk * B >= a.in_len)
+        return;
+    const su64x2 e = level_entry<L>(a)[blk];
+    if (e.x == kNone)
+        return; // a long element spans this block
+    uint64_t p = e.x, out = e.y;
+    uint64_t end = (blk + 1) * B;
+    if (end > a.in_len)
+        end = a.in_len;
+    while (p < end) {
+        level_entry<L - 1>(a)[p / Bc] = (su64x2){p, out};
+        if (!reach_end<L - 1>(a, p, out)) {
+            a.meta[2] = 1;
+            return;
+        }
+    }
+}
+} // namespace
+
+__global__ void k_stream_head(StreamArgs a)
+{
+    // header checks of Decoder::decompress (src/decompress.rs:75-95); any
+    // failure is left to the sequential decoder, which reports it
+    uint32_t hdr = 0;
+    uint64_t dlen = 0;
+    a.meta[0] = 0;
+    a.meta[1] = 0;
+    a.meta[2] = 1;
+    a.meta[3] = 0;
+    if (a.in_len == 0)
+        return;
+    if (read_header((gcptr)a.in, a.in_len, &hdr, &dlen, nullptr, 0) !=
+        SNAPMI_OK)
+        return;
+    if (dlen > a.out_cap || (dlen + kStreamChunk - 1) / kStreamChunk > a.kmax)
+        return;
+    a.meta[0] = hdr;
+    a.meta[1] = dlen;
+    a.meta[2] = 0;
+    a.meta[3] = (dlen + kStreamChunk - 1) / kStreamChunk;
+}
+
+__global__ __launch_bounds__(64) void k_stream_scan(StreamArgs a)
+{
+    if (a.meta[2])
+        return;
+    const uint64_t seg = blockIdx.x;
+    uint64_t p = seg * kSeg + threadIdx.x, out = 0;
+    uint64_t end = (seg + 1) * kSeg;
+    if (end > a.in_len)
+        end = a.in_len;
+    bool ok = p < a.in_len;
+    // The exit is the first element start at or behind the segment's end
+    // that lies within 64 bytes of a segment boundary (or the end of the
+    // stream): whoever follows the tables therefore always lands on a
+    // tabulated offset, also behind a long element, and never has to hop
+    // through elements itself.
+    while (ok && p < a.in_len && (p < end || (p & (kSeg - 1)) >= kWave))
+        ok = elem_step((gcptr)a.in, a.in_len, p, out);
+    level_table<1>(a)[seg * kWave + threadIdx.x] = (su64x2){ok ? p : kNone, out};
+}
+__global__ __launch_bounds__(64) void k_stream_super(StreamArgs a)
+{
+    build_level<2>(a);
+}
+__global__ __launch_bounds__(64) void k_stream_super3(StreamArgs a)
+{
+    build_level<3>(a);
+}
+
+// the one sequential pass: a table lookup per 16 MiB of input
+__global__ void k_stream_chain(StreamArgs a)
+{
+    if (a.meta[2])
+        return;
+    uint64_t p = a.meta[0], out = 0;
+    bool ok = true;
+    while (ok && p < a.in_len) {
+        level_entry<3>(a)[p / level_bytes<3>()] = (su64x2){p, out};
+        ok = reach_end<3>(a, p, out);
+    }
+    // the elements must end with the stream and produce the announced
+    // length (src/decompress.rs:141-147)
+    if (!ok || p != a.in_len || out != a.meta[1])
+        a.meta[2] = 1;
+}
+__global__ void k_stream_spread3(StreamArgs a)
+{
+    spread_level<3>(a);
+}
+__global__ void k_stream_spread2(StreamArgs a)
+{
+    spread_level<2>(a);
+}
+
+// one lane per segment the chain enters: the element boundary at (or first
+// after) every 64 KiB of output that falls into its hop
+__global__ void k_stream_cuts(StreamArgs a)
+{
+    if (a.meta[2])
+        return;
+    const uint64_t seg = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (seg == 0) {
+        const uint64_t K = a.meta[3];
+        a.cuts[0] = a.meta[0];
+        a.cuts[1] = 0;
+        a.cuts[K * 2] = a.in_len;
+        a.cuts[K * 2 + 1] = a.meta[1];
+    }
+    if (seg * kSeg >= a.in_len)
+        return;
+    const su64x2 e = level_entry<1>(a)[seg];
+    if (e.x == kNone)
+        return;
+    const uint64_t p = e.x, out = e.y;
+    uint64_t np = p, nout = out;
+    if (!reach_end<1>(a, np, nout)) {
+        a.meta[2] = 1;
+        return;
+    }
+    // piece boundaries T = k * 64 KiB with out < T <= nout
+    uint64_t k = out / kStreamChunk + 1;
+    uint64_t q = p, qo = out;
+    while (k * kStreamChunk <= nout && k * kStreamChunk < a.meta[1]) {
+        while (qo < k * kStreamChunk)
+            if (!elem_step((gcptr)a.in, a.in_len, q, qo)) {
+                a.meta[2] = 1;
+                return;
+            }
+        // (a long element can cover several boundaries)
+        while (k * kStreamChunk <= qo && k * kStreamChunk < a.meta[1]) {
+            a.cuts[k * 2] = q;
+            a.cuts[k * 2 + 1] = qo;
+            k++;
+        }
+    }
+}
+
+__global__ void k_stream_pieces(StreamArgs a)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.kmax)
+        return;
+    const bool live = a.meta[2] == 0 && k < a.meta[3];
+    const uint64_t s0 = live ? a.cuts[k * 2] : 0,
+                   d0 = live ? a.cuts[k * 2 + 1] : 0;
+    const uint64_t s1 = live ? a.cuts[k * 2 + 2] : 0,
+                   d1 = live ? a.cuts[k * 2 + 3] : 0;
+    a.c_in[k] = a.in + s0;
+    a.c_inlen[k] = s1 - s0;
+    a.c_out[k] = a.out + d0;
+    a.c_cap[k] = d1 - d0;
+    a.c_mode[k] = 2;
+    a.c_outlen[k] = 0;
+    a.c_err[k].kind = SNAPMI_OK;
+}
+
+__global__ __launch_bounds__(1024) void k_stream_finish(StreamArgs a)
+{
+    __shared__ uint32_t bad;
+    if (threadIdx.x == 0)
+        bad = a.meta[2] != 0;
+    __syncthreads();
+    const uint64_t K = a.meta[3];
+    if (!bad)
+        for (uint64_t k = threadIdx.x; k < K; k += blockDim.x)
+            if (a.c_err[k].kind != SNAPMI_OK || a.c_outlen[k] != a.c_cap[k])
+                atomicOr(&bad, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a.meta[2] = bad; // 1: the sequential decoder runs next
+        if (!bad) {
+            a.out_len[0] = a.meta[1];
+            set_error(a.err, 0, SNAPMI_OK, 0, 0, 0);
+        }
     }
 }
 

@@ -54,8 +54,13 @@ struct DecompressArgs {
     const uint64_t *out_caps; // [n] or nullptr when out_ptrs is nullptr
     uint64_t *out_lens;
     snapmi_error *errs; // [n] or nullptr
-    // optional [n]: 1 = stored chunk (frame type 0x01): plain copy of the input
+    // optional [n]: 1 = stored chunk (frame type 0x01): plain copy of the
+    // input; 2 = headerless piece of a long stream (k_stream_*): elements only,
+    // out_caps[i] is the exact output length
     const uint8_t *modes;
+    // optional: the launch does nothing unless *gate == gate_value
+    const unsigned long long *gate;
+    unsigned long long gate_value;
     uint32_t n_streams;
     // [n] stream indices, longest compressed stream first (k_plan_decompress)
     uint32_t *order;
@@ -70,6 +75,55 @@ __global__ void k_match_blocks(CompressArgs a);
 __global__ void k_encode_tokens(CompressArgs a);
 __global__ void k_scan_sizes(CompressArgs a);
 __global__ void k_compact(CompressArgs a);
+
+// One long raw stream decoded by many wavefronts (snapmi_decompress_stream).
+// The element chain is sequential, so it is resolved hierarchically first:
+// per 4 KiB segment and per 256 KiB super-segment, "if an element starts at
+// offset o (< 64) of this piece, where does the chain leave it and how many
+// bytes has it produced".
+constexpr uint32_t kSeg = 4096;           // bytes of compressed input
+constexpr uint32_t kSegPerSuper = 64;
+constexpr uint32_t kStreamChunk = 65536;  // output bytes per piece: the
+                                          // encoders' block size, so pieces
+                                          // of their streams are independent
+struct StreamArgs {
+    const uint8_t *in;
+    unsigned long long in_len;
+    uint8_t *out;
+    unsigned long long out_cap;
+    unsigned long long *out_len; // [1]
+    snapmi_error *err;           // [1]
+    // meta[0] header bytes, [1] decoded length, [2] 0 = pieces decode it,
+    // 1 = the sequential decoder must (error, or a stream whose pieces are
+    // not independent), [3] pieces
+    unsigned long long *meta;
+    // per level (4 KiB, 256 KiB, 16 MiB blocks): tables of (exit, produced)
+    // per entry offset < 64 - level 1 [segments * 64], levels 2 and 3
+    // [blocks * 64 children * 64] - and entries [blocks] of (position,
+    // produced) where the chain enters each block (~0 = it does not)
+    unsigned long long *s1, *s2, *s3;
+    unsigned long long *e1, *e2, *e3;
+    unsigned long long *cuts;     // [(kmax + 1) * 2] (src, dst) of piece k
+    uint32_t nseg, nsuper, nsuper3, kmax;
+    // piece descriptors for k_decompress_streams
+    const void **c_in;
+    unsigned long long *c_inlen;
+    void **c_out;
+    unsigned long long *c_cap;
+    unsigned long long *c_outlen;
+    snapmi_error *c_err;
+    uint8_t *c_mode;
+};
+__global__ void k_stream_head(StreamArgs a);
+__global__ void k_stream_scan(StreamArgs a);
+__global__ void k_stream_super(StreamArgs a);
+__global__ void k_stream_super3(StreamArgs a);
+__global__ void k_stream_chain(StreamArgs a);
+__global__ void k_stream_spread3(StreamArgs a);
+__global__ void k_stream_spread2(StreamArgs a);
+__global__ void k_stream_cuts(StreamArgs a);
+__global__ void k_stream_pieces(StreamArgs a);
+__global__ void k_stream_finish(StreamArgs a);
 
 __global__ void k_plan_decompress(DecompressArgs a);
 __global__ void k_decompress_streams(DecompressArgs a);

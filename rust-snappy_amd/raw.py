@@ -203,6 +203,23 @@ def decompress_batch(ctx, in_ptrs, in_lens, out_ptrs, out_caps, out_lens,
         _raise(ctx, rc)
 
 
+def decompress_stream(ctx, d_in, n_in, d_out, out_len, err):
+    """ONE long raw stream (uint8 CUDA tensor d_in[:n_in]) decoded by many
+    wavefronts into d_out; out_len: int64[1], err: uint8[32] CUDA tensors.
+    Same results and errors as decompress_batch with one stream."""
+    rc = _lib.load().snapmi_decompress_stream(
+        ctx._h, _ptr(d_in), int(n_in), _ptr(d_out), d_out.numel(),
+        _ptr(out_len), _ptr(err))
+    if rc:
+        _raise(ctx, rc)
+
+
+def stream_decode_path(ctx):
+    """0 = the last decompress_stream ran as pieces on many wavefronts, 1 =
+    sequential path, -1 = none yet."""
+    return _lib.load().snapmi_stream_decode_path(ctx._h)
+
+
 def decompress_len_batch(ctx, in_ptrs, in_lens, out_lens, errs=None):
     n = in_ptrs.numel()
     rc = _lib.load().snapmi_decompress_len_batch(

@@ -335,3 +335,82 @@ def test_decompress_foreign_encoder_streams(ctx):
             assert e[0] == 0 and g == w
         except O.SnapError as oe:
             assert (oe.kind, oe.a, oe.b, oe.c) == e, (e, oe)
+
+
+def stream_decode(ctx, comp, cap):
+    """snapmi_decompress_stream on one device-resident stream."""
+    import torch
+    from rust_snappy_amd import raw
+    d_in = torch.frombuffer(bytearray(comp) or bytearray(1),
+                            dtype=torch.uint8).cuda()
+    d_out = torch.zeros(max(cap, 16), dtype=torch.uint8, device="cuda")[:cap]
+    out_len = torch.zeros(1, dtype=torch.int64, device="cuda")
+    err = torch.zeros(32, dtype=torch.uint8, device="cuda")
+    raw.decompress_stream(ctx, d_in, len(comp), d_out, out_len, err)
+    ctx.synchronize()
+    e = np.frombuffer(err.cpu().numpy().tobytes(), dtype=np.dtype(
+        [("kind", "<i4"), ("r", "<u4"), ("a", "<u8"), ("b", "<u8"),
+         ("c", "<u8")]))[0]
+    n = int(out_len.item())
+    return d_out[:n].cpu().numpy().tobytes(), (int(e["kind"]), int(e["a"]),
+                                               int(e["b"]), int(e["c"]))
+
+
+def test_long_stream_parallel_decode(ctx):
+    """One raw stream on many wavefronts: equal to the original, for streams
+    of this format's encoders (64 KiB blocks: pieces independent), for
+    foreign streams (copies across pieces: sequential path), tiny and empty
+    streams, and with the oracle's error on corrupted ones."""
+    import foreign
+    rnd = O.corpus_round()
+    big = b"".join(d for _, d in rnd) * 3            # 8.8 MB, 137 blocks
+    cases = [big, rnd[2][1] * 5, bytes(300000), b"", b"a", rnd[0][1],
+             bytes(range(256)) * 1000]
+    from rust_snappy_amd import raw
+    for i, data in enumerate(cases):
+        comp = O.compress(data)
+        got, e = stream_decode(ctx, comp, len(data))
+        assert e[0] == 0, (i, e)
+        assert got == data, i
+        # block-structured streams never need the sequential path
+        assert raw.stream_decode_path(ctx) == 0, i
+    paths = []
+    for i, (st, want) in enumerate(foreign.cases()):
+        got, e = stream_decode(ctx, st, len(want))
+        assert e[0] == 0 and got == want, (i, e)
+        paths.append(raw.stream_decode_path(ctx))
+    assert 1 in paths  # copies across pieces: sequential path exercised
+    # errors: same variant and fields as the oracle (= the reference)
+    rng = random.Random(21)
+    comp = O.compress(big[:3000000])
+    muts = [comp[:len(comp) // 2], comp[:-1], comp + b"\x00"]
+    for _ in range(10):
+        b = bytearray(comp)
+        for _ in range(rng.randrange(1, 3)):
+            b[rng.randrange(len(b))] = rng.randrange(256)
+        muts.append(bytes(b))
+    for m in muts:
+        try:
+            cap = min(O.decompress_len(m), 1 << 23)
+        except O.SnapError:
+            cap = 1024
+        got, e = stream_decode(ctx, m, cap)
+        try:
+            want = O.decompress(m, cap)
+            assert e[0] == 0 and got == want
+        except O.SnapError as oe:
+            assert (oe.kind, oe.a, oe.b, oe.c) == e, (e, oe)
+    # too small an output buffer
+    got, e = stream_decode(ctx, O.compress(big), len(big) - 1)
+    try:
+        O.decompress(O.compress(big), len(big) - 1)
+        raise AssertionError
+    except O.SnapError as oe:
+        assert (oe.kind, oe.a, oe.b, oe.c) == e
+
+
+def test_scalar_decompress_uses_long_stream_path(ctx):
+    import rust_snappy_amd as R
+    data = b"".join(d for _, d in O.corpus_round()) * 2
+    dec = R.raw.Decoder(ctx=ctx)
+    assert dec.decompress_vec(O.compress(data)) == data
