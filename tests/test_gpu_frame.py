@@ -206,3 +206,24 @@ def test_frame_decoder_host_index_with_other_chunk_types(ctx):
          + bytes([0xFE, 2, 0, 0, 9, 9]) + f[:10] + f[10 + first:])
     assert frame.FrameDecoder(io.BytesIO(g), ctx).read_to_end() == data
     assert frame.FrameDecoder(io.BytesIO(f), ctx).read_to_end() == data
+
+
+def test_read_frame_encoder_big_and_little_buffers(ctx):
+    """test/tests.rs:321-340: the framed bytes do not depend on how the
+    caller reads (1 MB reads vs 5-byte reads); same for FrameDecoder."""
+    from rust_snappy_amd import frame
+    data = (O.CORPUS / "alice29.txt").read_bytes()
+    want = O.frame_compress(data)
+
+    def drain(rd, step):
+        out = bytearray()
+        while True:
+            b = rd.read(step)
+            if not b:
+                return bytes(out)
+            out += b
+
+    assert drain(frame.ReadFrameEncoder(io.BytesIO(data), ctx), 1 << 20) == want
+    assert drain(frame.ReadFrameEncoder(io.BytesIO(data), ctx), 5) == want
+    assert drain(frame.FrameDecoder(io.BytesIO(want), ctx), 5) == data
+    assert drain(frame.FrameDecoder(io.BytesIO(want), ctx), 1 << 20) == data
