@@ -23,13 +23,6 @@
 using namespace snapmi;
 
 
-// fraction of a large batch the lane kernel may claim up front when both
-// compress kernels run (SNAPMI_LANE_SHARE)
-static const double kLaneShare = [] {
-    const char *e = getenv("SNAPMI_LANE_SHARE");
-    double v = e ? atof(e) : 1.0;
-    return v < 0.05 ? 0.05 : (v > 1.0 ? 1.0 : v);
-}();
 
 namespace {
 

@@ -668,11 +668,6 @@ __device__ __forceinline__ uint64_t ld64p(gcptr p)
     __builtin_memcpy(&v, p, 8);
     return v;
 }
-#ifdef SNAPMI_NT
-#define TAB_STORE(ptr, val) __builtin_nontemporal_store(val, ptr)
-#else
-#define TAB_STORE(ptr, val) (*(ptr) = (val))
-#endif
 __global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
 {
     // per-lane input window: two 128-byte lines of the lane's block
@@ -855,7 +850,7 @@ __global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
                     ((unsigned long long)q1 << 32) | q0;
                 const unsigned long long by =
                     (epoch << 48) | ((unsigned long long)(s - 1) << 32) | q2;
-                TAB_STORE(tab + hprev, ((u64x2){b8, by}));
+                tab[hprev] = (u64x2){b8, by};
                 if (hprev == hcur) {
                     A.w[0] = q0;
                     A.w[1] = q1;
@@ -870,9 +865,8 @@ __global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
             const unsigned long long c8 =
                 live ? ((unsigned long long)A.w[1] << 32) | A.w[0] : first8;
             const uint32_t c4 = live ? A.w[2] : first4b;
-            TAB_STORE(tab + hcur,
-                      ((u64x2){p8, (epoch << 48) |
-                                       ((unsigned long long)s << 32) | p4}));
+            tab[hcur] = (u64x2){
+                p8, (epoch << 48) | ((unsigned long long)s << 32) | p4};
             if ((uint32_t)c8 == r0) {
                 // the entry holds the candidate's first 12 bytes, so most
                 // matches are measured without touching the candidate's line
