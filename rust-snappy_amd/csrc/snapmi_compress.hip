@@ -3,7 +3,11 @@
 // What is computed is fixed by the reference (src/compress.rs: one greedy
 // LZ77 parse per <=64 KiB block with a 16-bit hash table, the skip heuristic
 // and the literal / copy-1 / copy-2 encoders) and must be bit-exact.  How it
-// is computed is CDNA4-native:
+// is computed is CDNA4-native.  Two match finders produce the same bytes:
+// k_match_blocks + k_encode_tokens (one LANE per block, hash tables in HBM:
+// the fast path for batches of thousands of blocks, described at its
+// definition below) and k_compress_blocks (one WAVEFRONT per block, hash
+// table in LDS: small batches, where the latency of a block matters):
 //
 //   * one wavefront owns one 64 KiB block at a time; blocks are independent
 //     (fresh zeroed table per block, offsets never leave the block:
