@@ -336,6 +336,70 @@ def stream(args, ctx, dev):
             "one_wavefront_gib": round(m / GIB, 3)}
 
 
+def cfg4(args, ctx, dev):
+    """BASELINE config 4: the framed text stream of cfg3 sharded over the
+    ranks of a torch.distributed job (launch with torch.distributed.run;
+    world 1 works too).  Rank r frames periods [r*P/N, (r+1)*P/N) of the
+    stream - a contiguous range of 64 KiB chunks, no exchange during compute -
+    and the framed parts are gathered on rank 0 (shard.gatherv: sizes first,
+    then grouped point-to-point into the root's buffer).  Parts after the
+    first drop their 10-byte stream identifier, so the gathered bytes are the
+    single-stream framing."""
+    import os
+    import torch.distributed as dist
+    from rust_snappy_amd import frame, shard
+    import oracle_lib as O
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    period = synth_text(dev, int(args.period_mib * (1 << 20)))
+    assert period.numel() % 65536 == 0
+    periods = max(world, int(args.gib * GIB / period.numel()))
+    lo, hi = periods * rank // world, periods * (rank + 1) // world
+    data = period.repeat(hi - lo)
+    n = data.numel()
+
+    def sync():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    out, flen, _ = frame.compress_device(ctx, data)          # warm-up
+    sync()
+    t0 = time.perf_counter()
+    out, flen, _ = frame.compress_device(ctx, data)
+    sync()
+    t_enc = time.perf_counter() - t0
+    part = out[:flen] if rank == 0 else out[10:flen]
+    del data
+    t0 = time.perf_counter()
+    whole = shard.gatherv(part, dst=0) if world > 1 else part
+    sync()
+    t_gather = time.perf_counter() - t0
+    res = None
+    if rank == 0:
+        # the head of the gathered stream against the oracle, chunk for chunk
+        head = period[:1 << 20].cpu().numpy().tobytes()
+        want = O.frame_compress(head)
+        got = whole[:len(want)].cpu().numpy().tobytes()
+        assert got == want, "gathered framed bytes differ"
+        total = periods * period.numel()
+        res = {"config": "cfg4 framed synthetic text sharded by chunk range",
+               "n_gpus": world, "gib": round(total / GIB, 3),
+               "framed_bytes": int(whole.numel()),
+               "frame_encode_gibs_no_gather": round(total / GIB / t_enc, 2),
+               "frame_encode_gibs_with_gather": round(
+                   total / GIB / (t_enc + t_gather), 2),
+               "encode_ms": round(t_enc * 1e3, 2),
+               "gather_ms": round(t_gather * 1e3, 2)}
+    if world > 1:
+        dist.barrier()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gib", type=float, default=8.0)
@@ -346,13 +410,18 @@ def main():
     import __graft_entry__ as g
     g.build()
     from rust_snappy_amd import raw
-    dev = torch.device("cuda", 0)
-    ctx = raw.Context(0)
+    import os
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    ctx = raw.Context(local)
     for name, fn in (("cfg3", cfg3), ("cfg5", cfg5), ("files", files),
-                     ("pcie", pcie), ("stream", stream)):
-        if args.only and args.only != name:
-            continue
-        print(json.dumps(fn(args, ctx, dev)), flush=True)
+                     ("pcie", pcie), ("stream", stream), ("cfg4", cfg4)):
+        if args.only != name and (args.only or name == "cfg4"):
+            continue  # cfg4 only on request (it is the multi-rank config)
+        res = fn(args, ctx, dev)
+        if res is not None:
+            print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":
