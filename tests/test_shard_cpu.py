@@ -49,6 +49,17 @@ def _worker(rank, world, port, tmp):
         want = b"".join(O.compress(d) for d in rnd)
         assert out.numpy().tobytes() == want
         # max-over-ranks timing reduction used by bench.py
+    # config 4: a framed stream sharded by chunk range; parts after the
+    # first drop their stream identifier and the gathered bytes are the
+    # single-stream framing (bench_configs.py cfg4)
+    stream = b"".join(rnd)[:40 * 65536]
+    chunks = len(stream) // 65536
+    lo, hi = chunks * rank // world, chunks * (rank + 1) // world
+    part = O.frame_compress(stream[lo * 65536:hi * 65536])
+    part = part if rank == 0 else part[10:]
+    out = gatherv(torch.frombuffer(bytearray(part), dtype=torch.uint8), dst=0)
+    if rank == 0:
+        assert out.numpy().tobytes() == O.frame_compress(stream)
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     assert t.item() == float(world)
