@@ -117,6 +117,10 @@ const char *snapmi_version(void);
  *   "lane_waves_per_cu"    lanes in flight = 64 x this x CUs (default 6)
  *   "lane_segment_blocks"  blocks per lane-kernel launch (default 262144 =
  *                          16 GiB of input; bounds the token scratch)
+ *   "lane_table_spread"    1 (default): the lane kernel's hash tables are
+ *                          spread over up to 4x their size, within a third of
+ *                          the free device memory (HBM sustains more random
+ *                          accesses that way); 0: packed (25 GB at most)
  * Returns SNAPMI_E_ARGUMENT for an unknown name.
  */
 int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value);

@@ -692,7 +692,7 @@ __global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
     typedef __attribute__((address_space(1))) u64x2 g_entry;
     // 16-byte entries: x = bytes 0..7 at the position, y = bytes 8..11 |
     // position << 32 | epoch << 48
-    g_entry *const tab = (g_entry *)a.lane_tables + (uint64_t)g * kMaxTable;
+    g_entry *const tab = (g_entry *)a.lane_tables + (uint64_t)g * a.lane_stride;
     unsigned long long epoch = a.lane_epochs[g]; // 16 bits used
     unsigned long long first8 = 0; // bytes 0..11 of the block (empty entry)
     uint32_t first4b = 0;

@@ -29,6 +29,8 @@ struct snapmi_ctx {
     // lane-per-block match finder: tokens, token counts, HBM hash tables
     snapmi::DevBuf tokens, ntok, lane_tables, lane_epochs;
     uint32_t n_lanes = 0;
+    uint64_t lane_stride = 0;      // 16-byte entries between two lanes' tables
+    bool lane_table_spread = true; // spread the tables over free memory
     // SNAPMI_COMPRESS=waves|lanes|both: 0 = wavefront kernel only, 1 = lane
     // kernel on large batches and the wavefront kernel on small ones
     // (default), 2 = on large batches both kernels at once, sharing one

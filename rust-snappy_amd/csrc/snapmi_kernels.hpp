@@ -31,7 +31,8 @@ struct CompressArgs {
     unsigned long long *tokens; // [(blk_hi - blk_lo) * kMaxTokens]
     uint32_t *ntok;             // [blocks]
     uint32_t blk_lo, blk_hi;    // blocks this lane/encode launch covers
-    unsigned long long *lane_tables; // [lanes * kMaxTable * 2] 16-byte entries
+    unsigned long long *lane_tables; // lane g: 16-byte entries from g * lane_stride
+    unsigned long long lane_stride;  // >= kMaxTable (tables are spread out)
     uint32_t *lane_epochs;      // [lanes]
     uint32_t n_lanes;
     // experiment builds (-DSNAPMI_PROFILE) only: 16 u64 cycle counters
