@@ -121,6 +121,14 @@ const char *snapmi_version(void);
  *                          spread over up to 4x their size, within a third of
  *                          the free device memory (HBM sustains more random
  *                          accesses that way); 0: packed (25 GB at most)
+ * Test knobs (results still never depend on them):
+ *   "lane_max_waves"       cap on the lane kernel's wavefronts (0 = none), so
+ *                          a small batch puts several blocks on one lane
+ *   "lane_epoch_preset"    0..65535: every lane's hash-table epoch is set to
+ *                          this before the next lane-kernel launch (reaches
+ *                          the 16-bit epoch wrap without 65 535 blocks/lane)
+ *   "lds_order_ok"         0: behave as if the LDS atomic order self-check of
+ *                          snapmi_ctx_create had failed (lane kernel only)
  * Returns SNAPMI_E_ARGUMENT for an unknown name.
  */
 int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value);
@@ -272,7 +280,8 @@ int snapmi_frame_compress(snapmi_ctx *ctx, const void *d_in, uint64_t in_len,
  *                         the headers are walked on the device, one after
  *                         the other (the format has no index)
  *   d_out == NULL       : only compute the decompressed length
- *   d_out_len[0]        : decompressed length, 0 on error
+ *   d_out_len[0]        : decompressed length; on an error the bytes in
+ *                         front of the failing chunk (see _ex below)
  *   d_err[0]            : first error in stream order (kind 0 = ok);
  *                         an io::ErrorKind::UnexpectedEof is reported as
  *                         SNAPMI_E_UNEXPECTED_EOF
@@ -282,6 +291,70 @@ int snapmi_frame_decompress(snapmi_ctx *ctx, const void *d_in,
                             uint64_t *d_out_len, snapmi_error *d_err,
                             const uint64_t *d_chunk_offsets,
                             uint64_t n_chunks);
+
+/* flags of the frame entry points below */
+#define SNAPMI_FRAME_NO_IDENT 1u     /* compress: do not emit the identifier */
+#define SNAPMI_FRAME_CONTINUATION 1u /* decode: identifier already seen      */
+
+/*
+ * write::FrameEncoder with the chunk boundaries chosen by the caller: the
+ * reference cuts a chunk wherever a flush, a direct write larger than its
+ * 64 KiB buffer, or a short read of read::FrameEncoder ends it
+ * (src/write.rs:123-192, src/read.rs:365-409), so chunks of a stream are not
+ * always 65536 bytes.  Chunk i is the next h_chunk_lens[i] (1..65536) bytes
+ * of d_in; each goes through compress_frame (src/frame.rs:62-104).  With
+ * SNAPMI_FRAME_NO_IDENT the 10-byte stream identifier is not written (a
+ * later batch of the same stream, src/write.rs:167-170).  out_cap >=
+ * 10 + sum(lens) + 8 n.  h_chunk_lens is host memory, read before the call
+ * returns; the rest is asynchronous like snapmi_frame_compress.
+ */
+int snapmi_frame_compress_chunks(snapmi_ctx *ctx, const void *d_in,
+                                 const uint32_t *h_chunk_lens, size_t n,
+                                 uint32_t flags, void *d_out, uint64_t out_cap,
+                                 uint64_t *d_out_len,
+                                 uint64_t *d_chunk_offsets);
+
+/*
+ * snapmi_frame_decompress for one BATCH of a stream a host reader delivers
+ * piecewise (read::FrameDecoder decodes chunk by chunk, src/read.rs:105-238):
+ *   flags    SNAPMI_FRAME_CONTINUATION: the stream identifier was seen in an
+ *            earlier batch (read.rs:123-128)
+ *   stale10  NULL, or the first 10 bytes of the reference reader's scratch
+ *            buffer as earlier batches left them (snapmi_frame_scan_host
+ *            maintains them): the reference parses a compressed chunk's
+ *            length header from that whole buffer (read.rs:216), so a payload
+ *            of fewer than 10 bytes without a varint terminator is judged
+ *            together with those bytes.  NULL = a fresh reader (zeros).
+ * On an error d_out_len[0] is the number of output bytes IN FRONT of the
+ * failing chunk: they are decoded and CRC-checked, and the reference's
+ * reader has returned them before it reports the error.  The side index is
+ * a hint: if it does not tile [identifier, in_len) with plain data chunks,
+ * or a chunk needs the stale-buffer rule, the headers are walked instead.
+ */
+int snapmi_frame_decompress_ex(snapmi_ctx *ctx, const void *d_in,
+                               uint64_t in_len, void *d_out, uint64_t out_cap,
+                               uint64_t *d_out_len, snapmi_error *d_err,
+                               const uint64_t *d_chunk_offsets,
+                               uint64_t n_chunks, uint32_t flags,
+                               const uint8_t *stale10);
+
+/*
+ * Host-side scan for a reader that delivers the stream piecewise: walks the
+ * chunk headers of h_in[0, in_len) as far as chunks are complete and
+ * well-formed.  *consumed = end of the last such chunk, *n_chunks = data
+ * chunks in front of it, h_offsets (optional, cap >= n + 1) = their header
+ * offsets followed by *consumed, stale10 (optional, 10 bytes, in/out) = the
+ * reference reader's src[0..10) after those chunks.  Returns 0 when
+ * consumed == in_len, 2 when the next chunk is cut off by in_len (read more,
+ * or at end of input hand the rest to the device: UnexpectedEof), 1 when the
+ * next chunk's header is one the decoder rejects (hand [consumed, ...) to
+ * the device without an index: it reports the reference's error), or
+ * SNAPMI_E_ARGUMENT.  No GPU work.
+ */
+int snapmi_frame_scan_host(const void *h_in, uint64_t in_len, uint32_t flags,
+                           uint8_t *stale10, uint64_t *h_offsets,
+                           uint64_t cap, uint64_t *n_chunks,
+                           uint64_t *consumed);
 
 /* Host-side chunk scan of a framed stream that is still in HOST memory: the
  * hops FrameDecoder::read makes while it reads (src/read.rs:105-172).  The

@@ -63,6 +63,14 @@ SYMBOLS = [
      [_P, _P, C.c_uint64, _P, C.c_uint64, _P, _P]),
     ("snapmi_frame_decompress", C.c_int,
      [_P, _P, C.c_uint64, _P, C.c_uint64, _P, _P, _P, C.c_uint64]),
+    ("snapmi_frame_compress_chunks", C.c_int,
+     [_P, _P, _P, _SZ, C.c_uint32, _P, C.c_uint64, _P, _P]),
+    ("snapmi_frame_decompress_ex", C.c_int,
+     [_P, _P, C.c_uint64, _P, C.c_uint64, _P, _P, _P, C.c_uint64,
+      C.c_uint32, _P]),
+    ("snapmi_frame_scan_host", C.c_int,
+     [_P, C.c_uint64, C.c_uint32, _P, _P, C.c_uint64,
+      C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("snapmi_frame_index_host", C.c_int,
      [_P, C.c_uint64, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("snapmi_crc32c_masked_batch", C.c_int, [_P, _P, _P, _P, _SZ]),

@@ -134,6 +134,34 @@ int snapmi_ctx_create(int device, void *hip_stream, snapmi_ctx **out)
         snapmi_ctx_destroy(ctx);
         return SNAPMI_E_DEVICE;
     }
+    // Hardware self-check the wavefront-per-block compressor rests on (one
+    // tiny kernel): without the ascending-lane order of DS atomics that
+    // kernel would silently emit non-reference streams, so a context on such
+    // a device compresses with the lane-per-block kernel only.
+    {
+        uint32_t bad = 1;
+        if (reserve(ctx, ctx->ticket, 64) != SNAPMI_OK ||
+            hipMemsetAsync(ctx->ticket.p, 0, 64, ctx->stream) != hipSuccess) {
+            snapmi_ctx_destroy(ctx);
+            return SNAPMI_E_DEVICE;
+        }
+        hipLaunchKernelGGL(k_probe_lds_order, dim3(1), dim3(64), 0,
+                           ctx->stream, (uint32_t *)ctx->ticket.p);
+        if (hipMemcpyAsync(&bad, ctx->ticket.p, 4, hipMemcpyDeviceToHost,
+                           ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            fprintf(stderr, "snapmi: LDS order self-check did not run: %s\n",
+                    hipGetErrorString(hipGetLastError()));
+            snapmi_ctx_destroy(ctx);
+            return SNAPMI_E_DEVICE;
+        }
+        ctx->lds_order_ok = ctx->lds_order_hw = bad == 0;
+        if (!ctx->lds_order_ok)
+            fprintf(stderr,
+                    "snapmi: this device does not apply the lanes of one DS "
+                    "atomic in ascending lane order; the wavefront-per-block "
+                    "compressor is disabled (lane-per-block kernel only)\n");
+    }
     *out = ctx;
     return SNAPMI_OK;
 }
@@ -150,6 +178,7 @@ void snapmi_ctx_destroy(snapmi_ctx *ctx)
                       &ctx->st_desc, &ctx->st_prof, &ctx->ticket,
                       &ctx->order, &ctx->fr_tables, &ctx->fr_desc,
                       &ctx->fr_meta, &ctx->fr_scan, &ctx->fr_slots,
+                      &ctx->fr_chunk_off,
                       &ctx->tokens, &ctx->ntok, &ctx->lane_tables,
                       &ctx->lane_epochs, &ctx->sd_tables, &ctx->sd_desc})
         if (b->p)
@@ -187,6 +216,14 @@ int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value)
     else if (strcmp(name, "lane_waves_per_cu") == 0 && value >= 1 &&
              value <= 32)
         ctx->lane_waves_per_cu = (uint32_t)value;
+    else if (strcmp(name, "lane_max_waves") == 0 && value >= 0 &&
+             value <= 0x7FFFFFFF)
+        ctx->lane_max_waves = (uint32_t)value;
+    else if (strcmp(name, "lane_epoch_preset") == 0 && value >= -1 &&
+             value <= 0xFFFF)
+        ctx->lane_epoch_preset = value;
+    else if (strcmp(name, "lds_order_ok") == 0 && value >= 0 && value <= 1)
+        ctx->lds_order_ok = ctx->lds_order_hw && value != 0; // can only lower
     else
         return fail_ctx(ctx, SNAPMI_E_ARGUMENT, "unknown option %s", name);
     return SNAPMI_OK;
@@ -329,15 +366,19 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     // in ~2 ms, a lane needs tens of ms.  Large batches are throughput-bound
     // and go to the lane-per-block kernel.
     const bool big = blocks >= ctx->lane_min_blocks;
-    const bool lanes_mode = blocks > 0 && ctx->compress_mode != 0 && big;
+    // (a device that failed the LDS order self-check only has the lane kernel)
+    const bool lanes_mode =
+        blocks > 0 &&
+        (!ctx->lds_order_ok || (ctx->compress_mode != 0 && big));
     // the lane kernel runs over segments of the block list so that the token
     // scratch (128 KiB per block) stays bounded; "both at once" needs the
     // whole list in one segment
     const uint64_t seg_blocks =
         blocks < ctx->lane_segment_blocks ? blocks : ctx->lane_segment_blocks;
     const bool waves_mode =
-        blocks > 0 && (!lanes_mode || ctx->compress_mode == 0 ||
-                       (ctx->compress_mode == 2 && seg_blocks == blocks));
+        blocks > 0 && ctx->lds_order_ok &&
+        (!lanes_mode || ctx->compress_mode == 0 ||
+         (ctx->compress_mode == 2 && seg_blocks == blocks));
     a.blk_lo = 0;
     a.blk_hi = (uint32_t)blocks;
     if (lanes_mode) {
@@ -347,6 +388,8 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
         const uint64_t need = (seg_blocks + 63) / 64;
         if (waves > need)
             waves = need ? need : 1;
+        if (ctx->lane_max_waves && waves > ctx->lane_max_waves)
+            waves = ctx->lane_max_waves;
         const uint32_t lanes = (uint32_t)waves * 64;
         if (lanes > ctx->n_lanes) { // tables must start zeroed (epoch 0)
             // The tables are spread over more memory than they fill: HBM
@@ -391,6 +434,12 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                                                 sizeof(uint64_t))) ||
             (rc = reserve(ctx, ctx->ntok, (size_t)blocks * sizeof(uint32_t))))
             return rc;
+        if (ctx->lane_epoch_preset >= 0) { // test knob, see snapmi_ctx.hpp
+            HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->lane_epochs.p,
+                                           (int)ctx->lane_epoch_preset,
+                                           ctx->n_lanes, ctx->stream));
+            ctx->lane_epoch_preset = -1;
+        }
         a.tokens = (unsigned long long *)ctx->tokens.p;
         a.ntok = (uint32_t *)ctx->ntok.p;
         a.lane_tables = (unsigned long long *)ctx->lane_tables.p;
@@ -929,8 +978,8 @@ snappy_status snappy_compress(const char *input, size_t input_length,
         return SNAPPY_BUFFER_TOO_SMALL;
     std::lock_guard<std::mutex> lock(g_mu);
     snapmi_ctx *ctx = global_ctx();
-    if (!ctx)
-        return (snappy_status)SNAPMI_E_DEVICE; // loud: not a snappy status
+    if (!ctx) // (snapmi_ctx_create has printed why)
+        return SNAPPY_INVALID_INPUT;
     size_t written = 0;
     snapmi_error err;
     int rc = snapmi_raw_compress(ctx, (const uint8_t *)input, input_length,
@@ -939,9 +988,11 @@ snappy_status snappy_compress(const char *input, size_t input_length,
     if (rc == SNAPMI_BUFFER_TOO_SMALL)
         return SNAPPY_BUFFER_TOO_SMALL;
     if (rc >= SNAPMI_E_DEVICE) {
+        // snappy_status has no "device" value: the failure is printed and
+        // reported as the one status a caller cannot mistake for success
         fprintf(stderr, "snapmi: snappy_compress: %s\n",
                 snapmi_last_error(ctx));
-        return (snappy_status)rc;
+        return SNAPPY_INVALID_INPUT;
     }
     if (rc != SNAPMI_OK)
         return SNAPPY_INVALID_INPUT;
@@ -964,7 +1015,7 @@ snappy_status snappy_uncompress(const char *compressed,
     std::lock_guard<std::mutex> lock(g_mu);
     snapmi_ctx *ctx = global_ctx();
     if (!ctx)
-        return (snappy_status)SNAPMI_E_DEVICE;
+        return SNAPPY_INVALID_INPUT;
     size_t written = 0;
     snapmi_error err;
     int rc = snapmi_raw_decompress(ctx, (const uint8_t *)compressed,
@@ -973,7 +1024,7 @@ snappy_status snappy_uncompress(const char *compressed,
     if (rc >= SNAPMI_E_DEVICE) {
         fprintf(stderr, "snapmi: snappy_uncompress: %s\n",
                 snapmi_last_error(ctx));
-        return (snappy_status)rc;
+        return SNAPPY_INVALID_INPUT;
     }
     if (rc != SNAPMI_OK)
         return SNAPPY_INVALID_INPUT;

@@ -27,8 +27,10 @@
 //     by ONE LDS atomic: ds_mskor_rtn_b32 replaces the 16-bit field and
 //     returns the old dword, and gfx950 applies the lanes of one DS atomic
 //     that hit the same address in ascending lane order (checked on hardware
-//     by tests/hw/lds_atomic_order.hip and at context creation).  Entries
-//     written by lanes past the first hit are rolled back;
+//     by k_probe_lds_order below at every context creation - a context on a
+//     device where it does not hold never launches this kernel - and, more
+//     broadly, by tests/hw/lds_atomic_order.hip).  Entries written by lanes
+//     past the first hit are rolled back;
 //   * every lane compares 16 bytes at its candidate, so the first hit also
 //     has its match length (reference extend_match, src/compress.rs:378-412);
 //     longer matches continue 256 bytes per wave instruction;
@@ -490,7 +492,10 @@ __device__ __forceinline__ void compress_one_block(
         const B16 y = ld128u(src + cand);
         TICK(3);
         const uint32_t m = common16(x, y);
-        const uint64_t hits = __ballot(valid && probe && m >= 4);
+        // (cand < p always holds when the DS atomic applies lanes in ascending
+        // order, which snapmi_ctx_create verifies; the test keeps the output
+        // a valid stream even if that ever failed)
+        const uint64_t hits = __ballot(valid && probe && m >= 4 && cand < p);
         if (hits == 0) {
             if (__ballot(active && !valid) != 0)
                 break; // ran into s_limit: done
@@ -583,6 +588,56 @@ __device__ __noinline__ uint32_t next_ticket(uint32_t *ticket, uint32_t lane,
                                                : 0xFFFFFFFFu;
     }
     return uni(blk);
+}
+
+// ---------------------------------------------------------------------
+// Self-check run once per context (snapmi_ctx_create): k_compress_blocks
+// needs one wave64 ds_mskor_rtn_b32 to apply lanes that hit the same address
+// in ascending lane order - every lane must get back the value left by the
+// nearest lower lane with the same slot, and the highest lane's value must
+// be the one that stays.  256 patterns (all lanes one slot, heavy, some and
+// rare duplicates), slots from a counter-based hash.  *bad != 0 afterwards
+// means the property does not hold on this device: the context then never
+// uses k_compress_blocks (the lane kernel does not depend on it).
+// ---------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_probe_lds_order(uint32_t *bad)
+{
+    __shared__ uint16_t tab[2048];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t tbase = (uint32_t)(uintptr_t)(lptr16)&tab[0];
+    uint32_t fails = 0;
+    for (uint32_t t = 0; t < 256; t++) {
+        for (uint32_t i = lane; i < 2048; i += 64)
+            tab[i] = (uint16_t)(0x8000u + i);
+        __builtin_amdgcn_wave_barrier(); // one wave: its LDS ops are in order
+        uint32_t r = (t * 64 + lane) * 2654435761u + 0x9E3779B9u;
+        r ^= r >> 15;
+        r *= 0x2C1B3C6Du;
+        r ^= r >> 12;
+        const uint32_t mode = t & 3;
+        const uint32_t slot =
+            mode == 0 ? 5u : (mode == 1 ? r % 8 : (mode == 2 ? r % 64 : r % 2048));
+        const uint32_t sh = (slot & 1) * 16;
+        const uint32_t old = lds_mskor_rtn(tbase + (slot >> 1) * 4,
+                                           0xFFFFu << sh, (lane + 1) << sh);
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t fin = tab[slot];
+        uint32_t want = 0x8000u + slot, want_fin = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 64; j++) {
+            const uint32_t sj = rdlane(slot, j);
+            if (sj == slot) {
+                if (j < lane)
+                    want = j + 1;
+                want_fin = j + 1;
+            }
+        }
+        fails += ((old >> sh) & 0xFFFFu) != want;
+        fails += fin != want_fin;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (__ballot(fails != 0) != 0 && lane == 0)
+        *bad = 1;
 }
 
 // ---------------------------------------------------------------------

@@ -44,7 +44,7 @@ struct snapmi_ctx {
     // long-stream decode scratch (snapmi_decompress_stream)
     snapmi::DevBuf sd_tables, sd_desc;
     // frame layer scratch (snapmi_frame.hip)
-    snapmi::DevBuf fr_tables, fr_desc, fr_meta, fr_scan, fr_slots;
+    snapmi::DevBuf fr_tables, fr_desc, fr_meta, fr_scan, fr_slots, fr_chunk_off;
     bool fr_tables_ready = false;
     int num_cus = 0;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -52,6 +52,16 @@ struct snapmi_ctx {
     // blocks per lane-kernel launch: bounds the token scratch (34 GB here)
     uint32_t lane_segment_blocks = 262144;
     uint32_t lane_waves_per_cu = 6; // 24 KiB of LDS per wave
+    uint32_t lane_max_waves = 0;    // test knob: cap on lane-kernel waves (0 = none)
+    // test knob: every lane's table epoch is set to this value before the
+    // next lane-kernel launch (-1 = leave the epochs alone); lets a test
+    // reach the 16-bit epoch wrap without 65 535 blocks per lane
+    int64_t lane_epoch_preset = -1;
+    // ds_mskor_rtn_b32 applies same-address lanes in ascending lane order on
+    // this device (checked by k_probe_lds_order at context creation); the
+    // wavefront-per-block kernel is only used when this holds
+    bool lds_order_ok = false;
+    bool lds_order_hw = false; // what the self-check found (the option can only lower it)
     bool timing_valid = false;
     bool timing_is_compress = false;
     bool dominant_split = false; // ev[4]/ev[5] bracket k_match_blocks

@@ -679,6 +679,10 @@ __global__ __launch_bounds__(64) void k_decompress_streams(DecompressArgs a)
 // ---------------------------------------------------------------------
 namespace {
 constexpr unsigned long long kNone = ~0ull;
+// k_stream_scan follows a chain at most this far behind its segment's end;
+// streams of the usual encoders land on a tabulated offset within a few
+// elements (a literal is at most 65536 bytes in their output)
+constexpr uint64_t kScanOverrun = 4 * 65536 + 2 * kSeg;
 
 typedef unsigned long long su64x2 __attribute__((ext_vector_type(2)));
 
@@ -891,8 +895,19 @@ __global__ __launch_bounds__(64) void k_stream_scan(StreamArgs a)
     // stream): whoever follows the tables therefore always lands on a
     // tabulated offset, also behind a long element, and never has to hop
     // through elements itself.
-    while (ok && p < a.in_len && (p < end || (p & (kSeg - 1)) >= kWave))
+    // The walk past the segment's end is bounded (a crafted stream whose
+    // elements all end 64+ bytes off a segment boundary would otherwise make
+    // every thread walk to the end of the input): past kScanOverrun bytes the
+    // entry is left as "cannot follow", and whoever needs it sets meta[2] -
+    // the sequential decoder then owns the stream.
+    const uint64_t giveup = end + kScanOverrun;
+    while (ok && p < a.in_len && (p < end || (p & (kSeg - 1)) >= kWave)) {
+        if (p >= giveup) {
+            ok = false;
+            break;
+        }
         ok = elem_step((gcptr)a.in, a.in_len, p, out);
+    }
     level_table<1>(a)[seg * kWave + threadIdx.x] = (su64x2){ok ? p : kNone, out};
 }
 __global__ __launch_bounds__(64) void k_stream_super(StreamArgs a)

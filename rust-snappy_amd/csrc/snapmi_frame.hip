@@ -141,6 +141,10 @@ struct FrameCompressArgs {
     // the arrays below are per segment, `base` carries the output offset.
     uint32_t lo, cnt;
     uint64_t *base; // [1] payload bytes emitted by earlier segments
+    // optional [n+1]: input offset of every chunk (snapmi_frame_compress_chunks:
+    // the caller decides where chunks end); nullptr = 65536-byte multiples
+    const uint64_t *chunk_in_off;
+    uint32_t ident; // 10 when the stream identifier is written, 0 when not
     // scratch
     const void **in_ptrs;
     uint64_t *in_lens;
@@ -157,9 +161,14 @@ __global__ void k_frame_chunks(FrameCompressArgs a)
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.cnt)
         return;
-    const uint64_t off = (uint64_t)(a.lo + i) * kMaxBlock;
-    const uint64_t len =
-        a.in_len - off < kMaxBlock ? a.in_len - off : kMaxBlock;
+    uint64_t off, len;
+    if (a.chunk_in_off) {
+        off = a.chunk_in_off[a.lo + i];
+        len = a.chunk_in_off[a.lo + i + 1] - off;
+    } else {
+        off = (uint64_t)(a.lo + i) * kMaxBlock;
+        len = a.in_len - off < kMaxBlock ? a.in_len - off : kMaxBlock;
+    }
     a.in_ptrs[i] = a.in + off;
     a.in_lens[i] = len;
     a.slot_ptrs[i] = a.slots + (uint64_t)i * kFrameSlot;
@@ -221,9 +230,9 @@ __global__ __launch_bounds__(256) void k_frame_emit(FrameCompressArgs a)
     const uint64_t clen = a.clens[i];
     const bool stored = clen >= len - len / 8;
     const uint64_t payload = stored ? len : clen;
-    const uint64_t at = 10 + a.base[0] + a.offs[i];
+    const uint64_t at = a.ident + a.base[0] + a.offs[i];
     gptr o = (gptr)a.out + at;
-    if (gi == 0 && threadIdx.x < 10) {
+    if (gi == 0 && a.ident && threadIdx.x < 10) {
         const uint8_t ident[10] = {0xFF, 0x06, 0x00, 0x00, 's',
                                    'N',  'a',  'P',  'p',  'Y'};
         ((gptr)a.out)[threadIdx.x] = ident[threadIdx.x];
@@ -239,7 +248,7 @@ __global__ __launch_bounds__(256) void k_frame_emit(FrameCompressArgs a)
         o[5] = (uint8_t)(crc >> 8);
         o[6] = (uint8_t)(crc >> 16);
         o[7] = (uint8_t)(crc >> 24);
-        const uint64_t end = 10 + a.base[0] + a.offs[a.cnt];
+        const uint64_t end = a.ident + a.base[0] + a.offs[a.cnt];
         if (a.chunk_offsets) {
             a.chunk_offsets[gi] = at;
             if (gi + 1 == a.n)
@@ -277,11 +286,16 @@ struct FrameDecodeArgs {
     const uint64_t *index; // optional chunk header offsets
     uint32_t n_index;
     uint32_t cap_chunks; // capacity of chunks[]
+    uint32_t flags;      // SNAPMI_FRAME_CONTINUATION: identifier already seen
+    // first 10 bytes of the reference decoder's `src` scratch buffer when
+    // this call starts (all zero for a fresh decoder): see frame_short_varint
+    uint8_t stale[10];
     // scratch
     FrameChunk *chunks;
     uint32_t *meta;      // [0] data chunks found, [1] overflow flag,
                          // [2] index of the data chunk a structural error
-                         //     precedes (0xFFFFFFFF = none)
+                         //     precedes (0xFFFFFFFF = none), [3] the side
+                         //     index met a chunk only the walk can judge
     snapmi_error *serr;  // [1] structural error of the walk
     uint64_t *dlens;     // [n] decompressed length per data chunk
     uint64_t *offs;      // [n+1]
@@ -307,6 +321,81 @@ __device__ inline void walk_fail(const FrameDecodeArgs &a, uint32_t n_data,
     a.meta[2] = n_data;
 }
 
+// A compressed chunk whose payload is shorter than 10 bytes and holds no
+// varint terminator (every byte >= 0x80; an empty payload too).  The
+// reference calls decompress_len on its WHOLE 76 490-byte scratch buffer
+// `src` (src/read.rs:216), so the varint continues into whatever earlier
+// reads left there: this chunk's own 4 header bytes at src[0..4) (read.rs:118),
+// and the bodies of earlier stream-identifier / skippable / padding /
+// compressed chunks (read.rs:151,157,168,214; stored chunks go to `dst`).
+// The outcome then is TooBig, UnsupportedChunkLength, or - when the phantom
+// length is acceptable - whatever Decoder::decompress says about the real
+// payload: Empty or Header (src/decompress.rs:80-83).  Rare and always an
+// error, so the model of src[0..10) is rebuilt here by walking the stream
+// again from its start up to `stop` (the offset of this chunk's header).
+__device__ inline void frame_short_varint(const FrameDecodeArgs &a,
+                                          uint64_t stop, uint32_t n_data)
+{
+    gcptr in = (gcptr)a.in;
+    uint8_t m[10];
+    for (int k = 0; k < 10; k++)
+        m[k] = a.stale[k];
+    uint64_t r = 0;
+    for (;;) { // every chunk before `stop` was accepted by the walk
+        const uint32_t hd = ld32u(in + r);
+        for (int k = 0; k < 4; k++)
+            m[k] = (uint8_t)(hd >> (8 * k));
+        const uint32_t ty = hd & 0xFF;
+        const uint64_t len = hd >> 8;
+        uint64_t body = r + 4, blen = len; // bytes read into src[0..blen)
+        if (ty == 0x00) {
+            body = r + 8;
+            blen = len - 4;
+        } else if (ty == 0x01) {
+            blen = 0;
+        }
+        for (uint64_t k = 0; k < blen && k < 10; k++)
+            m[k] = in[body + k];
+        if (r == stop)
+            break;
+        r += 4 + len;
+    }
+    // decompress_len(&src): read_varu64 (src/bytes.rs:73-90) over m[0..10)
+    uint64_t v = 0;
+    uint32_t shift = 0;
+    bool ok = false;
+    for (int k = 0; k < 10; k++) {
+        const uint64_t b = m[k];
+        if (b < 0x80) {
+            v |= b << shift;
+            ok = true;
+            break;
+        }
+        v |= (b & 0x7F) << shift;
+        shift += 7;
+    }
+    const uint64_t sn = (ld32u(in + stop) >> 8) - 4;
+    if (!ok)
+        walk_fail(a, n_data, SNAPMI_HEADER, 0, 0);
+    else if (v > kMaxInput)
+        walk_fail(a, n_data, SNAPMI_TOO_BIG, v, kMaxInput);
+    else if (v > kMaxBlock) // read.rs:217-222
+        walk_fail(a, n_data, SNAPMI_UNSUPPORTED_CHUNK_LENGTH, v, 0);
+    else // Decoder::decompress(&src[0..sn]), src/decompress.rs:80-83
+        walk_fail(a, n_data, sn == 0 ? SNAPMI_EMPTY : SNAPMI_HEADER, 0, 0);
+}
+
+// true when the payload [p, p + pl) needs frame_short_varint
+__device__ inline bool short_varint(gcptr p, uint64_t pl)
+{
+    if (pl >= 10)
+        return false;
+    for (uint64_t k = 0; k < pl; k++)
+        if (p[k] < 0x80)
+            return false;
+    return true;
+}
+
 // Sequential walk over the chunk headers: reference FrameDecoder::read,
 // src/read.rs:111-236 (checks in the reference's order).  One thread: every
 // hop depends on the previous header.
@@ -317,9 +406,10 @@ __global__ void k_frame_walk(FrameDecodeArgs a)
     gcptr in = (gcptr)a.in;
     uint64_t r = 0;
     uint32_t nd = 0;
-    bool seen_ident = false;
+    bool seen_ident = (a.flags & SNAPMI_FRAME_CONTINUATION) != 0;
     a.meta[1] = 0;
     a.meta[2] = 0xFFFFFFFFu;
+    a.meta[3] = 0;
     a.serr[0].kind = SNAPMI_OK;
     for (;;) {
         if (r == a.in_len)
@@ -395,6 +485,10 @@ __global__ void k_frame_walk(FrameDecodeArgs a)
                 walk_fail(a, nd, SNAPMI_E_UNEXPECTED_EOF, 0, 0);
                 return;
             }
+            if (ty == 0x00 && short_varint(in + r, pl)) { // read.rs:216
+                frame_short_varint(a, r - 8, nd);
+                return;
+            }
             if (nd < a.cap_chunks) {
                 FrameChunk c;
                 c.payload_off = r;
@@ -420,42 +514,51 @@ __global__ void k_frame_index(FrameDecodeArgs a)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     gcptr in = (gcptr)a.in;
-    if (i == 0) {
-        a.meta[0] = a.n_index;
-        a.meta[1] = 0;
-        a.meta[2] = 0xFFFFFFFFu;
-        a.serr[0].kind = SNAPMI_OK;
+    // (meta[] and serr are cleared by the host before this launch)
+    if (i == 0 && !(a.flags & SNAPMI_FRAME_CONTINUATION)) {
         const uint8_t ident[10] = {0xFF, 0x06, 0x00, 0x00, 's',
                                    'N',  'a',  'P',  'p',  'Y'};
         bool ok = a.in_len >= 10;
         for (int k = 0; ok && k < 10; k++)
             ok = in[k] == ident[k];
         if (!ok)
-            walk_fail(a, 0, SNAPMI_STREAM_HEADER,
-                      a.in_len ? (uint64_t)in[0] : 0, 0);
+            a.meta[3] = 1; // the walk reports what is wrong with the start
     }
     if (i >= a.n_index)
         return;
     const uint64_t r = a.index[i];
     FrameChunk c;
-    c.type = 0xFF; // not a data chunk: rejected by k_frame_lens
+    c.type = 0xFF;
     c.payload_len = 0;
     c.crc = 0;
     c.payload_off = 0;
     c.pad = 0;
-    if (r + 8 <= a.in_len) {
+    // The index is the caller's: it is taken as a hint, never trusted.  A
+    // header that is not an in-bounds data chunk ending exactly at the next
+    // index entry (the entries must tile the stream from the identifier to
+    // its end: other chunk types in between are the walk's business), or a
+    // chunk only the walk can judge (frame_short_varint), sends the whole
+    // stream to the walk, which owns every error report.
+    bool good = a.in_len >= 8 && r <= a.in_len - 8;
+    if (good) {
         const uint32_t hd = ld32u(in + r);
         const uint32_t ty = hd & 0xFF, len = hd >> 8;
-        if (ty <= 1 && len >= 4 && len <= kMaxChunk &&
-            r + 4 + len <= a.in_len && !(ty == 1 && len - 4 > kMaxBlock)) {
+        good = ty <= 1 && len >= 4 && len <= kMaxChunk &&
+               len <= a.in_len - r - 4 && !(ty == 1 && len - 4 > kMaxBlock) &&
+               a.index[i + 1] == r + 4 + len && // nothing unseen in between
+               (i + 1 < a.n_index || a.index[i + 1] == a.in_len) &&
+               (i > 0 ||
+                r == ((a.flags & SNAPMI_FRAME_CONTINUATION) ? 0u : 10u)) &&
+               !(ty == 0 && short_varint(in + r + 8, len - 4));
+        if (good) {
             c.type = ty;
             c.payload_len = len - 4;
             c.crc = ld32u(in + r + 4);
             c.payload_off = r + 8;
-        } else {
-            c.pad = ty; // for the error report
         }
     }
+    if (!good)
+        a.meta[3] = 1;
     a.chunks[i] = c;
 }
 
@@ -586,7 +689,16 @@ __global__ __launch_bounds__(1024) void k_frame_verify(FrameDecodeArgs a,
             e.b = a.offs[n];
         }
         a.err[0] = e;
-        a.out_len[0] = e.kind == SNAPMI_OK ? a.offs[n] : 0;
+        // On an error the chunks in front of the failing one are decoded and
+        // checked: the reference's reader has handed them out by then
+        // (src/read.rs:112-118), so their byte count is reported.
+        uint32_t upto = n;
+        if (e.kind != SNAPMI_OK) {
+            upto = first_bad < sidx ? first_bad : (sidx < n ? sidx : n);
+            if (!decoded)
+                upto = 0;
+        }
+        a.out_len[0] = a.offs[upto];
     }
 }
 
@@ -674,27 +786,18 @@ int snapmi_crc32c_masked_batch(snapmi_ctx *ctx, const void *const *d_ptrs,
     return SNAPMI_OK;
 }
 
-int snapmi_frame_compress(snapmi_ctx *ctx, const void *d_in, uint64_t in_len,
-                          void *d_out, uint64_t out_cap, uint64_t *d_out_len,
-                          uint64_t *d_chunk_offsets)
+} // extern "C"
+
+namespace snapmi {
+// n chunks of d_in: at 65536-byte multiples (d_chunk_in_off == nullptr) or at
+// the given input offsets ([n+1], device); shared by the two entry points
+static int frame_compress_impl(snapmi_ctx *ctx, const void *d_in,
+                               uint64_t in_len, uint32_t n,
+                               const uint64_t *d_chunk_in_off, bool ident,
+                               void *d_out, uint64_t *d_out_len,
+                               uint64_t *d_chunk_offsets)
 {
-    if (!ctx || !d_out_len || (in_len && (!d_in || !d_out)))
-        return SNAPMI_E_ARGUMENT;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    if (in_len == 0) { // the identifier is written lazily: src/write.rs:154-170
-        HIP_TRY(ctx, hipMemsetAsync(d_out_len, 0, sizeof(uint64_t), s));
-        return SNAPMI_OK;
-    }
-    if (out_cap < snapmi_frame_max_len(in_len))
-        return fail_ctx(ctx, SNAPMI_E_ARGUMENT,
-                        "frame_compress: out_cap %llu < frame_max_len %zu",
-                        (unsigned long long)out_cap,
-                        snapmi_frame_max_len(in_len));
-    const uint64_t n64 = (in_len + kMaxBlock - 1) / kMaxBlock;
-    if (n64 > 0x7FFFFFFFu)
-        return fail_ctx(ctx, SNAPMI_E_ARGUMENT, "frame_compress: too long");
-    const uint32_t n = (uint32_t)n64;
     int rc = ensure_tables(ctx);
     if (rc)
         return rc;
@@ -713,10 +816,12 @@ int snapmi_frame_compress(snapmi_ctx *ctx, const void *d_in, uint64_t in_len,
     a.in = (const uint8_t *)d_in;
     a.in_len = in_len;
     a.out = (uint8_t *)d_out;
-    a.out_cap = out_cap;
+    a.out_cap = 0;
     a.out_len = d_out_len;
     a.chunk_offsets = d_chunk_offsets;
     a.n = n;
+    a.chunk_in_off = d_chunk_in_off;
+    a.ident = ident ? 10 : 0;
     a.base = carve<uint64_t>(p, 1);
     a.in_ptrs = carve<const void *>(p, seg);
     a.in_lens = carve<uint64_t>(p, seg);
@@ -750,6 +855,76 @@ int snapmi_frame_compress(snapmi_ctx *ctx, const void *d_in, uint64_t in_len,
     }
     HIP_TRY(ctx, hipGetLastError());
     return SNAPMI_OK;
+}
+} // namespace snapmi
+
+extern "C" {
+
+int snapmi_frame_compress(snapmi_ctx *ctx, const void *d_in, uint64_t in_len,
+                          void *d_out, uint64_t out_cap, uint64_t *d_out_len,
+                          uint64_t *d_chunk_offsets)
+{
+    if (!ctx || !d_out_len || (in_len && (!d_in || !d_out)))
+        return SNAPMI_E_ARGUMENT;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    if (in_len == 0) { // the identifier is written lazily: src/write.rs:154-170
+        HIP_TRY(ctx, hipMemsetAsync(d_out_len, 0, sizeof(uint64_t), s));
+        return SNAPMI_OK;
+    }
+    if (out_cap < snapmi_frame_max_len(in_len))
+        return fail_ctx(ctx, SNAPMI_E_ARGUMENT,
+                        "frame_compress: out_cap %llu < frame_max_len %zu",
+                        (unsigned long long)out_cap,
+                        snapmi_frame_max_len(in_len));
+    const uint64_t n64 = (in_len + kMaxBlock - 1) / kMaxBlock;
+    if (n64 > 0x7FFFFFFFu)
+        return fail_ctx(ctx, SNAPMI_E_ARGUMENT, "frame_compress: too long");
+    return frame_compress_impl(ctx, d_in, in_len, (uint32_t)n64, nullptr, true,
+                               d_out, d_out_len, d_chunk_offsets);
+}
+
+int snapmi_frame_compress_chunks(snapmi_ctx *ctx, const void *d_in,
+                                 const uint32_t *h_chunk_lens, size_t n,
+                                 uint32_t flags, void *d_out, uint64_t out_cap,
+                                 uint64_t *d_out_len,
+                                 uint64_t *d_chunk_offsets)
+{
+    if (!ctx || !d_out_len || (n && (!d_in || !d_out || !h_chunk_lens)) ||
+        n > 0x7FFFFFFFu || (flags & ~(uint32_t)SNAPMI_FRAME_NO_IDENT))
+        return SNAPMI_E_ARGUMENT;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    if (n == 0) {
+        HIP_TRY(ctx, hipMemsetAsync(d_out_len, 0, sizeof(uint64_t), s));
+        return SNAPMI_OK;
+    }
+    // input offsets of the chunks: chunk i = d_in[off[i], off[i+1])
+    std::vector<uint64_t> off(n + 1);
+    off[0] = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (h_chunk_lens[i] == 0 || h_chunk_lens[i] > kMaxBlock)
+            return fail_ctx(ctx, SNAPMI_E_ARGUMENT,
+                            "frame_compress_chunks: chunk %zu has %u bytes "
+                            "(1..65536)", i, h_chunk_lens[i]);
+        off[i + 1] = off[i] + h_chunk_lens[i];
+    }
+    const bool ident = !(flags & SNAPMI_FRAME_NO_IDENT);
+    const uint64_t need = (ident ? 10 : 0) + off[n] + 8 * (uint64_t)n;
+    if (out_cap < need)
+        return fail_ctx(ctx, SNAPMI_E_ARGUMENT,
+                        "frame_compress_chunks: out_cap %llu < %llu",
+                        (unsigned long long)out_cap, (unsigned long long)need);
+    int rc = reserve(ctx, ctx->fr_chunk_off, (n + 1) * sizeof(uint64_t));
+    if (rc)
+        return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->fr_chunk_off.p, off.data(),
+                                (n + 1) * sizeof(uint64_t),
+                                hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s)); // `off` is pageable host memory
+    return frame_compress_impl(ctx, d_in, off[n], (uint32_t)n,
+                               (const uint64_t *)ctx->fr_chunk_off.p, ident,
+                               d_out, d_out_len, d_chunk_offsets);
 }
 
 int snapmi_frame_index_host(const void *h_in, uint64_t in_len,
@@ -801,13 +976,86 @@ int snapmi_frame_index_host(const void *h_in, uint64_t in_len,
     return 0;
 }
 
-int snapmi_frame_decompress(snapmi_ctx *ctx, const void *d_in,
-                            uint64_t in_len, void *d_out, uint64_t out_cap,
-                            uint64_t *d_out_len, snapmi_error *d_err,
-                            const uint64_t *d_chunk_offsets,
-                            uint64_t n_chunks)
+// meta[] and the structural error slot before the index kernel (whose
+// threads only ever raise meta[3])
+__global__ void k_frame_meta_init(FrameDecodeArgs a)
 {
-    if (!ctx || !d_out_len || !d_err || (in_len && !d_in))
+    a.meta[0] = a.n_index;
+    a.meta[1] = 0;
+    a.meta[2] = 0xFFFFFFFFu;
+    a.meta[3] = 0;
+    a.serr[0].kind = SNAPMI_OK;
+}
+
+int snapmi_frame_scan_host(const void *h_in, uint64_t in_len, uint32_t flags,
+                           uint8_t *stale10, uint64_t *h_offsets,
+                           uint64_t cap, uint64_t *n_chunks,
+                           uint64_t *consumed)
+{
+    if (!n_chunks || !consumed || (in_len && !h_in))
+        return SNAPMI_E_ARGUMENT;
+    const uint8_t *in = (const uint8_t *)h_in;
+    uint64_t r = 0, nd = 0;
+    bool seen_ident = (flags & SNAPMI_FRAME_CONTINUATION) != 0;
+    int status = 0;
+    while (r != in_len) {
+        if (in_len - r < 4) {
+            status = 2;
+            break;
+        }
+        const uint32_t ty = in[r];
+        const uint64_t len = (uint64_t)in[r + 1] | ((uint64_t)in[r + 2] << 8) |
+                             ((uint64_t)in[r + 3] << 16);
+        if ((!seen_ident && ty != 0xFF) || len > kMaxChunk ||
+            (ty >= 0x02 && ty <= 0x7F) || (ty == 0xFF && len != 6) ||
+            (ty <= 0x01 && (len < 4 || (ty == 0x01 && len - 4 > kMaxBlock)))) {
+            status = 1;
+            break;
+        }
+        if (in_len - r - 4 < len) {
+            status = 2;
+            break;
+        }
+        if (ty == 0xFF && memcmp(in + r + 4, "sNaPpY", 6) != 0) {
+            status = 1;
+            break;
+        }
+        seen_ident = true;
+        if (ty <= 0x01) {
+            if (h_offsets) {
+                if (nd + 1 >= cap)
+                    return SNAPMI_E_ARGUMENT;
+                h_offsets[nd] = r;
+            }
+            nd++;
+        }
+        if (stale10) { // the reference reader's src[0..10), see frame_short_varint
+            memcpy(stale10, in + r, 4);
+            const uint64_t body = ty == 0x00 ? r + 8 : r + 4;
+            const uint64_t blen = ty == 0x00 ? len - 4 : (ty == 0x01 ? 0 : len);
+            memcpy(stale10, in + body, (size_t)(blen < 10 ? blen : 10));
+        }
+        r += 4 + len;
+    }
+    if (h_offsets) {
+        if (nd + 1 > cap)
+            return SNAPMI_E_ARGUMENT;
+        h_offsets[nd] = r;
+    }
+    *n_chunks = nd;
+    *consumed = r;
+    return status;
+}
+
+int snapmi_frame_decompress_ex(snapmi_ctx *ctx, const void *d_in,
+                               uint64_t in_len, void *d_out, uint64_t out_cap,
+                               uint64_t *d_out_len, snapmi_error *d_err,
+                               const uint64_t *d_chunk_offsets,
+                               uint64_t n_chunks, uint32_t flags,
+                               const uint8_t *stale10)
+{
+    if (!ctx || !d_out_len || !d_err || (in_len && !d_in) ||
+        (flags & ~(uint32_t)SNAPMI_FRAME_CONTINUATION))
         return SNAPMI_E_ARGUMENT;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
@@ -816,8 +1064,9 @@ int snapmi_frame_decompress(snapmi_ctx *ctx, const void *d_in,
         return rc;
     // capacity for the chunk table: exact with an index, else an estimate
     // that is retried once with the exact count
-    uint64_t cap = d_chunk_offsets ? n_chunks : in_len / 2048 + 64;
-    for (int attempt = 0; attempt < 2; attempt++) {
+    bool use_index = d_chunk_offsets != nullptr;
+    uint64_t cap = use_index ? n_chunks : in_len / 2048 + 64;
+    for (int attempt = 0; attempt < 3; attempt++) {
         if (cap > 0x7FFFFFFFu)
             return fail_ctx(ctx, SNAPMI_E_ARGUMENT, "frame: too many chunks");
         const size_t n = (size_t)cap;
@@ -835,9 +1084,12 @@ int snapmi_frame_decompress(snapmi_ctx *ctx, const void *d_in,
         a.out_cap = out_cap;
         a.out_len = d_out_len;
         a.err = d_err;
-        a.index = d_chunk_offsets;
-        a.n_index = d_chunk_offsets ? (uint32_t)n_chunks : 0;
+        a.index = use_index ? d_chunk_offsets : nullptr;
+        a.n_index = use_index ? (uint32_t)n_chunks : 0;
         a.cap_chunks = (uint32_t)n;
+        a.flags = flags;
+        for (int k = 0; k < 10; k++)
+            a.stale[k] = stale10 ? stale10[k] : 0;
         a.meta = carve<uint32_t>(p, 4);
         a.serr = carve<snapmi_error>(p, 1);
         a.chunks = carve<FrameChunk>(p, n);
@@ -855,16 +1107,23 @@ int snapmi_frame_decompress(snapmi_ctx *ctx, const void *d_in,
 
         const uint32_t tb = 256;
         const uint32_t gb = n ? (uint32_t)((n + tb - 1) / tb) : 1;
-        if (d_chunk_offsets)
+        if (use_index) {
+            hipLaunchKernelGGL(k_frame_meta_init, dim3(1), dim3(1), 0, s, a);
             hipLaunchKernelGGL(k_frame_index, dim3(gb), dim3(tb), 0, s, a);
-        else
+        } else {
             hipLaunchKernelGGL(k_frame_walk, dim3(1), dim3(64), 0, s, a);
+        }
         // the number of data chunks decides the launch sizes below
         uint32_t meta[4];
         HIP_TRY(ctx, hipMemcpyAsync(meta, a.meta, sizeof meta,
                                     hipMemcpyDeviceToHost, s));
         HIP_TRY(ctx, hipStreamSynchronize(s));
-        if (meta[1] && attempt == 0) { // table too small: rerun exactly
+        if (use_index && meta[3]) { // the index does not tile the stream with
+            use_index = false;      // plain data chunks: the walk decides
+            cap = n_chunks + in_len / 65536 + 64;
+            continue;
+        }
+        if (meta[1] && !use_index && cap < meta[0]) { // table too small
             cap = meta[0];
             continue;
         }
@@ -893,6 +1152,17 @@ int snapmi_frame_decompress(snapmi_ctx *ctx, const void *d_in,
         return SNAPMI_OK;
     }
     return fail_ctx(ctx, SNAPMI_E_DEVICE, "frame: chunk table retry failed");
+}
+
+int snapmi_frame_decompress(snapmi_ctx *ctx, const void *d_in,
+                            uint64_t in_len, void *d_out, uint64_t out_cap,
+                            uint64_t *d_out_len, snapmi_error *d_err,
+                            const uint64_t *d_chunk_offsets,
+                            uint64_t n_chunks)
+{
+    return snapmi_frame_decompress_ex(ctx, d_in, in_len, d_out, out_cap,
+                                      d_out_len, d_err, d_chunk_offsets,
+                                      n_chunks, 0, nullptr);
 }
 
 } // extern "C"

@@ -70,6 +70,7 @@ struct DecompressArgs {
     unsigned long long *prof;
 };
 
+__global__ void k_probe_lds_order(uint32_t *bad);
 __global__ void k_plan_compress(CompressArgs a);
 __global__ void k_compress_blocks(CompressArgs a);
 __global__ void k_match_blocks(CompressArgs a);
