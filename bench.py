@@ -12,7 +12,14 @@ directions / time, whole job, GiB/s.
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N
 
 Multi-GPU: streams are independent, so each rank compresses its own shard;
-no data-path collective (scaling = weak: G GiB per GPU).
+no data-path collective (scaling = weak: G GiB per GPU).  `--gpus N` without
+a torch.distributed environment re-executes itself under
+torch.distributed.run with N ranks (one per GPU, 127.0.0.1 rendezvous); it
+fails loudly when fewer than N devices are visible or when WORLD_SIZE
+disagrees with N.  After the timed region the line gets `extras`: BASELINE
+configs 3 and 5 at full size and the per-file rates (N = 1), and config 4 -
+the framed stream sharded by chunk range over the ranks with the RCCL gather
+of the framed parts (any N).
 """
 import argparse
 import hashlib
@@ -55,63 +62,220 @@ def build_round():
         lens, dtype=np.int64), shas
 
 
-def cpu_baseline(rnd, seconds=8.0):
-    """Oracle (the C restatement of the reference, kind 'port') timed on the
-    host cores on a bounded sample: the 12-stream round, repeated by every
-    thread (pthreads inside oracle/liboracle.so) for `seconds` per
-    direction."""
+def usable_cores():
+    """CPUs this process can actually use: the scheduler affinity mask capped
+    by the cgroup CPU quota (os.cpu_count() is the machine's, not ours)."""
+    info = {"os_cpu_count": os.cpu_count() or 1}
+    try:
+        info["affinity"] = len(os.sched_getaffinity(0))
+    except AttributeError:
+        info["affinity"] = info["os_cpu_count"]
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max",                       # cgroup v2
+                 "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):          # cgroup v1
+        try:
+            text = Path(path).read_text().split()
+        except OSError:
+            continue
+        if path.endswith("cpu.max"):
+            info["cgroup_cpu_max"] = " ".join(text)
+            if text and text[0] != "max":
+                quota = float(text[0]) / float(text[1])
+        else:
+            q = float(text[0])
+            if q > 0:
+                per = float(Path(
+                    "/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+                info["cgroup_cpu_max"] = f"{int(q)} {int(per)}"
+                quota = q / per
+        break
+    cores = info["affinity"]
+    if quota is not None:
+        cores = max(1, min(cores, int(quota + 0.999)))
+    info["usable"] = cores
+    return cores, info
+
+
+def native_oracle():
+    """oracle/snappy_oracle.c compiled -O3 -march=native for THIS host into a
+    temporary directory (the in-tree liboracle.so is built without
+    -march=native because it travels between machines).  Falls back to the
+    in-tree library if gcc is missing."""
+    import ctypes as C
+    import subprocess
+    import tempfile
+    import oracle_lib as O
+    src = O.ORACLE_DIR / "snappy_oracle.c"
+    try:
+        out = Path(tempfile.mkdtemp(prefix="snapo_native_")) / "liboracle.so"
+        subprocess.check_call(
+            ["gcc", "-O3", "-march=native", "-std=gnu11", "-fPIC", "-shared",
+             "-I", str(O.ORACLE_DIR), "-o", str(out), str(src), "-lpthread"],
+            stderr=subprocess.DEVNULL)
+        return C.CDLL(str(out)), "-O3 -march=native"
+    except (OSError, subprocess.CalledProcessError):
+        return O.lib(), "-O3 (in-tree build; gcc -march=native failed)"
+
+
+def cpu_baseline(rnd, seconds=3.0):
+    """The CPU path timed beside the GPU, on a bounded sample: the
+    12-stream round, repeated by every thread for `seconds` per leg.  Legs:
+    {restatement of the reference (oracle/snappy_oracle.c, kind 'port'),
+    Google libsnappy 1.1.8 (what the reference's own bench compares against,
+    bench/src/bench.rs:117-153)} x {all usable cores, 1 thread (README.md:
+    135-158 is a 1-thread table)} x {compress, decompress}; threads pinned,
+    buffers allocated before the clock, -O3 -march=native."""
     import ctypes as C
     import oracle_lib as O
-    L = O.lib()
-    cores = os.cpu_count() or 1
+    cores, host = usable_cores()
+    L, flags = native_oracle()
     datas = [d for _, d in rnd]
     comps = [O.compress(d) for d in datas]
     n = len(datas)
     PP = C.c_char_p * n
     SZ = C.c_size_t * n
-    L.snapo_bench.restype = C.c_double
-    L.snapo_bench.argtypes = [PP, SZ, PP, SZ, C.c_int, C.c_int, C.c_int,
-                              C.c_double, C.POINTER(C.c_uint64)]
-    res = {}
-    for direction, key in ((0, "c"), (1, "d")):
+    L.snapo_bench_ext.restype = C.c_double
+    L.snapo_bench_ext.argtypes = [PP, SZ, PP, SZ, C.c_int, C.c_int, C.c_int,
+                                  C.c_double, C.POINTER(C.c_uint64),
+                                  C.c_void_p, C.c_void_p, C.c_int]
+    ext = None
+    S = O.libsnappy()
+    if S is not None:
+        ext = (C.cast(S.snappy_compress, C.c_void_p),
+               C.cast(S.snappy_uncompress, C.c_void_p))
+
+    def leg(direction, threads, fns):
         rounds = C.c_uint64(0)
         t0 = time.perf_counter()
-        bps = L.snapo_bench(PP(*datas), SZ(*[len(d) for d in datas]),
-                            PP(*comps), SZ(*[len(c) for c in comps]), n,
-                            direction, cores, seconds, C.byref(rounds))
-        res[key] = (bps / GIB, rounds.value, time.perf_counter() - t0)
-    c, d = res["c"][0], res["d"][0]
-    combined = 2.0 / (1.0 / c + 1.0 / d)
+        bps = L.snapo_bench_ext(
+            PP(*datas), SZ(*[len(d) for d in datas]), PP(*comps),
+            SZ(*[len(c) for c in comps]), n, direction, threads, seconds,
+            C.byref(rounds), fns[0] if fns else None,
+            fns[1] if fns else None, 1)
+        return bps / GIB, rounds.value, time.perf_counter() - t0
+
+    def codec(fns):
+        ca, da = leg(0, cores, fns), leg(1, cores, fns)
+        c1, d1 = leg(0, 1, fns), leg(1, 1, fns)
+        return {"all_cores": {"threads": cores,
+                              "compress_gibs": round(ca[0], 4),
+                              "decompress_gibs": round(da[0], 4)},
+                "one_thread": {"compress_gibs": round(c1[0], 4),
+                               "decompress_gibs": round(d1[0], 4)}}, ca, da
+
+    port, ca, da = codec(None)
+    c, d = ca[0], da[0]
     out = {
-        "value": round(combined, 4), "unit": "GiB/s", "cores": cores,
-        "kind": "port",
+        "value": round(2.0 / (1.0 / c + 1.0 / d), 4), "unit": "GiB/s",
+        "cores": cores, "kind": "port",
         "compress_gibs": round(c, 4), "decompress_gibs": round(d, 4),
-        "sample": (f"12-stream zflat/uflat round (2928571 B) x "
-                   f"{res['c'][1]} (compress, {res['c'][2]:.1f}s) / x "
-                   f"{res['d'][1]} (decompress, {res['d'][2]:.1f}s) on "
-                   f"{cores} pthreads, oracle/snappy_oracle.c -O3"),
+        "sample": (f"12-stream zflat/uflat round (2928571 B) x {ca[1]} "
+                   f"(compress, {ca[2]:.1f}s) / x {da[1]} (decompress, "
+                   f"{da[2]:.1f}s) on {cores} pinned pthreads, "
+                   f"oracle/snappy_oracle.c {flags}; every leg {seconds:g} s"),
+        "host": host, "port": port,
     }
-    # one thread, for comparison with the reference README (1 core)
-    r1 = C.c_uint64(0)
-    c1 = L.snapo_bench(PP(*datas), SZ(*[len(d) for d in datas]), PP(*comps),
-                       SZ(*[len(c) for c in comps]), n, 0, 1, 2.0,
-                       C.byref(r1)) / GIB
-    d1 = L.snapo_bench(PP(*datas), SZ(*[len(d) for d in datas]), PP(*comps),
-                       SZ(*[len(c) for c in comps]), n, 1, 1, 2.0,
-                       C.byref(r1)) / GIB
-    out["one_thread"] = {"compress_gibs": round(c1, 4),
-                         "decompress_gibs": round(d1, 4)}
-    if O.libsnappy() is not None:  # informational: Google libsnappy 1.1.8
-        t0 = time.perf_counter()
-        k = 0
-        while time.perf_counter() - t0 < 2.0:
-            for dd in datas:
-                O.libsnappy_compress(dd)
-            k += 1
-        ubytes = sum(len(d) for d in datas)
-        out["libsnappy_1_1_8_compress_gibs_1thread"] = round(
-            k * ubytes / (time.perf_counter() - t0) / GIB, 4)
+    if ext is not None:
+        out["libsnappy_1_1_8"] = codec(ext)[0]
     return out
+
+
+def run_extras(args, local_rank, dev, rank, world):
+    """BASELINE configs beside the headline one, for the driver's record:
+    cfg3 (framed text, 64 GiB), cfg5 (incompressible, 32 GiB), the 12
+    per-file rates, one long raw stream and cfg4 at N = 1 - in a child
+    process (bench_configs.py --plan), so that nothing they do can take the
+    headline line down; at N > 1 cfg4 only (the framed stream sharded over
+    the ranks, gathered on rank 0), in this process group.  Each config is
+    parity-checked inside bench_configs.py; a failure is recorded."""
+    import subprocess
+    out = {}
+    if world == 1:
+        g3 = args.extras_gib or 64.0
+        g5 = args.extras_gib or 32.0
+        plan = f"cfg3:{g3:g},cfg5:{g5:g},files:2,stream:2,cfg4:8"
+        cmd = [sys.executable, str(ROOT / "bench_configs.py"), "--plan", plan]
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True,
+                               timeout=420)
+            for ln in p.stdout.splitlines():
+                if ln.startswith("{"):
+                    rec = json.loads(ln)
+                    out[rec.pop("name", f"cfg{len(out)}")] = rec
+            if p.returncode != 0:
+                out["error"] = (f"bench_configs.py exit {p.returncode}: "
+                                + p.stderr.strip()[-300:])
+        except subprocess.TimeoutExpired:
+            out["error"] = "bench_configs.py --plan timed out (420 s)"
+        return out
+    import types
+    import bench_configs as BC
+    from rust_snappy_amd import raw
+    ctx = raw.Context(local_rank)
+    a = types.SimpleNamespace(gib=8.0 * world, period_mib=256.0, steps=2)
+    t0 = time.perf_counter()
+    try:
+        res = BC.cfg4(a, ctx, dev)
+    except Exception as e:  # noqa: BLE001 - recorded, not hidden
+        res = {"error": f"{type(e).__name__}: {e}"[:300]}
+    if res is not None:
+        res["wall_s"] = round(time.perf_counter() - t0, 1)
+        out["cfg4"] = res
+    ctx.close()
+    return out if rank == 0 else None
+
+
+def maybe_spawn(args):
+    """`python bench.py --gpus N` with N > 1 and no torch.distributed
+    environment: run the N ranks ourselves (the driver's own launch line,
+    one rank per GPU, rendezvous on 127.0.0.1) and return the exit code;
+    None when this process is a rank (or N == 1) and should carry on."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return None
+    if not args.plumbing_check:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but {have} GPU(s) visible "
+                     f"(no CPU fallback, no oversubscription)")
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + \
+        sys.argv[1:]
+    log(f"[bench] --gpus {args.gpus}: spawning {args.gpus} ranks: "
+        + " ".join(cmd[1:8]) + " ...")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get(
+        "HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def plumbing_check(rank, world):
+    """The rank plumbing of the real run without a GPU: process group (gloo),
+    barrier, MAX-reduce of a per-rank time, gather of the ranks seen, one
+    JSON line from rank 0 marked invalid."""
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        dist.barrier()
+        t = torch.tensor([1.0 + rank], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        seen = [None] * world
+        dist.all_gather_object(seen, rank)
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        t, seen = torch.tensor([1.0]), [0]
+    if rank == 0:
+        print(json.dumps({"metric": "plumbing check", "n_gpus": world,
+                          "ranks_seen": sorted(seen),
+                          "max_over_ranks": float(t[0]),
+                          "INVALID": "plumbing check, no GPU work"}),
+              flush=True)
 
 
 def main():
@@ -126,12 +290,31 @@ def main():
     ap.add_argument("--no-verify", action="store_true",
                     help="experiment builds only: skip the parity gate "
                          "(the JSON line is then marked invalid)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra configs (cfg3/cfg4/cfg5/per-file)")
+    ap.add_argument("--extras-gib", type=float, default=None,
+                    help="size of the cfg3 / cfg5 extras (default: BASELINE's "
+                         "64 and 32 GiB)")
+    ap.add_argument("--plumbing-check", action="store_true",
+                    help="no GPU work: only the --gpus N launch plumbing over "
+                         "gloo (what tests/test_bench_spawn_cpu.py runs)")
     args = ap.parse_args()
 
+    spawned = maybe_spawn(args)
+    if spawned is not None:
+        sys.exit(spawned)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: "
+                 f"launch N ranks for --gpus N (or let bench.py do it)")
+    if args.plumbing_check:
+        return plumbing_check(rank, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    if torch.cuda.device_count() <= local_rank:
+        sys.exit(f"bench.py: rank {rank} wants cuda:{local_rank} but only "
+                 f"{torch.cuda.device_count()} devices are visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -252,11 +435,28 @@ def main():
         log("[bench] compress kernel ms per step: "
             + " ".join(f"{x:.1f}/{y:.1f}" for x, y in zip(k_dom_ms, k_comp_ms))
             + " | decompress: " + " ".join(f"{x:.1f}" for x in k_dec_ms))
+    per_rank = [[float(np.mean(k_dom_ms)), float(np.mean(k_comp_ms)),
+                 float(np.mean(k_dec_ms)), elapsed / args.steps * 1e3]]
     if world > 1:
         t = torch.tensor([elapsed, t_comp, t_dec], dtype=torch.float64,
                          device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed, t_comp, t_dec = t.tolist()
+        mine = torch.tensor(per_rank[0], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allr, mine)
+        per_rank = [x.tolist() for x in allr]
+
+    # ---- extra configs (never part of `value`) ---------------------------
+    extras = None
+    if not args.no_extras and not args.no_verify:
+        # the extras need the memory (cfg3: 64 GiB in, 64 GiB framed, 64 GiB
+        # decoded): drop the headline buffers and the context's scratch
+        # (87 GB of lane tables); the extras run on a context of their own
+        del src, comp, back, data, per, d_round
+        ctx.close()
+        torch.cuda.empty_cache()
+        extras = run_extras(args, local_rank, dev, rank, world)
 
     if rank == 0:
         K = args.steps
@@ -264,7 +464,7 @@ def main():
         value = 2.0 * total_u * K / elapsed / GIB
         comp_gibs = total_u * K / t_comp / GIB
         dec_gibs = total_u * K / t_dec / GIB
-        # roofline of the dominant kernel (k_compress_blocks): algorithmic
+        # roofline of the dominant kernel (k_match_blocks): algorithmic
         # bytes per launch = U read + C written ((1+rho) B per
         # uncompressed byte), over the HIP-event duration of that launch.
         kc = float(np.mean(k_comp_ms)) * 1e-3   # all compress-side kernels
@@ -279,9 +479,14 @@ def main():
         dom_name = ("k_match_blocks" if abs(kdom - kc) > 1e-9
                     else "k_compress_blocks")
         traffic = traffic_d = None
-        pmc = ROOT / "profiles" / "r1_pmc_traffic.json"
-        if pmc.exists() and abs(args.gib - 8.0) < 1e-9:
-            pj = json.loads(pmc.read_text())["kernels"]
+        pmc_name = None
+        for cand in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+            if (ROOT / "profiles" / cand).exists():
+                pmc_name = cand
+                break
+        if pmc_name and abs(args.gib - 8.0) < 1e-9:
+            pj = json.loads((ROOT / "profiles" / pmc_name).read_text())[
+                "kernels"]
             if dom_name in pj:
                 traffic = pj[dom_name]["traffic_bytes_fetch_x2"]
             if "k_decompress_streams" in pj:
@@ -294,7 +499,9 @@ def main():
             "steps": K, "warmup": args.warmup,
             "ms_per_step": round(elapsed / K * 1e3, 3),
             "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic (the reference's 12 bench inputs, committed "
+                    "under tests/golden/corpus, tiled on the device)",
             "config": {
                 "workload": (f"raw block codec, 12-stream zflat/uflat round "
                              f"tiled x{rounds} = {ubytes / GIB:.3f} GiB per "
@@ -309,7 +516,7 @@ def main():
                 "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
-                "traffic_source": "profiles/r1_pmc_traffic.json "
+                "traffic_source": f"profiles/{pmc_name} "
                                   "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                   "separate passes, FETCH_SIZE x2)",
                 "alg_bytes_per_launch": alg,
@@ -333,6 +540,11 @@ def main():
                           "compact": round(float(np.mean(compact_ms)), 3),
                           "decompress": round(kd * 1e3, 3)},
         }
+        # per rank: [dominant compress kernel, all compress kernels,
+        # decompress kernel, wall per step] in ms (HIP events / host clock)
+        line["per_rank_ms"] = [[round(v, 3) for v in r] for r in per_rank]
+        if extras is not None:
+            line["extras"] = extras
         if args.no_verify:
             line["INVALID"] = "experiment build, parity gate skipped"
         if world == 1 and not args.no_cpu:

@@ -385,8 +385,8 @@ def cfg4(args, ctx, dev):
         head = period[:1 << 20].cpu().numpy().tobytes()
         want = O.frame_compress(head)
         got = whole[:len(want)].cpu().numpy().tobytes()
-        assert got == want, "gathered framed bytes differ"
-        total = periods * period.numel()
+        parity_ok = got == want  # (raised after the last barrier: a rank
+        total = periods * period.numel()  # must not leave the others waiting)
         res = {"config": "cfg4 framed synthetic text sharded by chunk range",
                "n_gpus": world, "gib": round(total / GIB, 3),
                "framed_bytes": int(whole.numel()),
@@ -394,9 +394,17 @@ def cfg4(args, ctx, dev):
                "frame_encode_gibs_with_gather": round(
                    total / GIB / (t_enc + t_gather), 2),
                "encode_ms": round(t_enc * 1e3, 2),
-               "gather_ms": round(t_gather * 1e3, 2)}
+               "gather_ms": round(t_gather * 1e3, 2),
+               "gathered_bytes_from_peers": int(whole.numel() - part.numel()),
+               # root ingress: 7 xGMI links x 153 GB/s
+               "gather_gbs": (round((whole.numel() - part.numel()) / t_gather
+                                    / 1e9, 1) if world > 1 else None),
+               "gather_bound_gbs": 1071.0,
+               "ranks_seen": world}
     if world > 1:
         dist.barrier()
+    if rank == 0:
+        assert parity_ok, "gathered framed bytes differ from the oracle's"
     return res
 
 
@@ -406,6 +414,11 @@ def main():
     ap.add_argument("--period-mib", type=float, default=256.0)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--only", default="")
+    ap.add_argument("--plan", default="",
+                    help="name:gib,... - run these configs at these sizes, "
+                         "one JSON line each with a \"name\" key; a config "
+                         "that fails prints {\"name\", \"error\"} and the "
+                         "rest still run (bench.py's extras)")
     args = ap.parse_args()
     import __graft_entry__ as g
     g.build()
@@ -415,6 +428,23 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     ctx = raw.Context(local)
+    table = {"cfg3": cfg3, "cfg5": cfg5, "files": files, "pcie": pcie,
+             "stream": stream, "cfg4": cfg4}
+    if args.plan:
+        for item in args.plan.split(","):
+            name, gib = item.split(":")
+            args.gib = float(gib)
+            t0 = time.perf_counter()
+            try:
+                res = table[name](args, ctx, dev)
+            except Exception as e:  # noqa: BLE001 - reported, not hidden
+                res = {"error": f"{type(e).__name__}: {e}"[:300]}
+            torch.cuda.empty_cache()
+            if res is not None:
+                res["name"] = name
+                res["wall_s"] = round(time.perf_counter() - t0, 1)
+                print(json.dumps(res), flush=True)
+        return
     for name, fn in (("cfg3", cfg3), ("cfg5", cfg5), ("files", files),
                      ("pcie", pcie), ("stream", stream), ("cfg4", cfg4)):
         if args.only != name and (args.only or name == "cfg4"):

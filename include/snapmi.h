@@ -356,6 +356,39 @@ int snapmi_frame_scan_host(const void *h_in, uint64_t in_len, uint32_t flags,
                            uint64_t cap, uint64_t *n_chunks,
                            uint64_t *consumed);
 
+/*
+ * Host-buffer forms of the two calls above (blocking: H2D, kernels, D2H
+ * through the context's staging buffers) - what a host-language
+ * FrameEncoder / FrameDecoder calls once per batch of chunks (shim/src/
+ * write.rs, read.rs; rust-snappy_amd/frame.py; tools/szip.cpp).
+ *
+ * snapmi_frame_encode_host: chunks as in snapmi_frame_compress_chunks, from
+ * h_in back to back; out_cap >= snapmi_frame_encode_bound(sum, n).
+ *
+ * snapmi_frame_decode_host: decodes the complete, well-formed chunks at the
+ * start of h_in[0, in_len) - as many as out_cap / 65536 allows - and reports
+ * how far it got: *consumed input bytes, *written output bytes.  Call it again
+ * with the rest (plus more input) and SNAPMI_FRAME_CONTINUATION.
+ *   consumed == 0 and kind OK : not one whole chunk yet, supply more input
+ *   SNAPMI_FRAME_FINAL        : no more input will follow: a cut-off chunk is
+ *                               UnexpectedEof instead of "supply more"
+ *   on an error (return value = *err's kind) *written bytes in front of the
+ *   failing chunk are valid output and must be delivered first
+ *   (src/read.rs:111-118); *consumed stays 0.
+ *   stale10: 10 bytes of decoder state kept by the caller between calls
+ *   (zeros for a new stream), see snapmi_frame_decompress_ex.
+ */
+#define SNAPMI_FRAME_FINAL 2u
+size_t snapmi_frame_encode_bound(size_t total_bytes, size_t n_chunks);
+int snapmi_frame_encode_host(snapmi_ctx *ctx, const uint8_t *h_in,
+                             const uint32_t *h_chunk_lens, size_t n,
+                             uint32_t flags, uint8_t *h_out, size_t out_cap,
+                             size_t *written);
+int snapmi_frame_decode_host(snapmi_ctx *ctx, const uint8_t *h_in,
+                             size_t in_len, uint32_t flags, uint8_t *stale10,
+                             uint8_t *h_out, size_t out_cap, size_t *written,
+                             size_t *consumed, snapmi_error *err);
+
 /* Host-side chunk scan of a framed stream that is still in HOST memory: the
  * hops FrameDecoder::read makes while it reads (src/read.rs:105-172).  The
  * format is a linked list of chunk headers; on the device every hop is a

@@ -6,6 +6,9 @@
  * of the reference, not copied from it; every function cites the reference
  * lines it restates.  Paths are relative to /root/reference.
  */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE /* sched_getaffinity, pthread_setaffinity_np (bench driver) */
+#endif
 #include "snappy_oracle.h"
 
 #include <string.h>
@@ -589,13 +592,24 @@ int snapo_frame_decompress(const uint8_t *input, size_t n, uint8_t *out,
 }
 
 /* ---- multi-threaded timing driver for bench.py's cpu_baseline leg -------
- * Runs the restatement above on `threads` pthreads for about `seconds`:
- * every thread loops over the same n streams (compress, or decompress of
- * their compressed form) into private buffers.  Returns uncompressed bytes
- * per second summed over the threads.  Test/bench infrastructure only. */
+ * Runs a codec on `threads` pthreads for about `seconds`: every thread loops
+ * over the same n streams (compress, or decompress of their compressed form)
+ * into private buffers allocated before the clock starts.  Returns
+ * uncompressed bytes per second summed over the threads.  The codec is the
+ * restatement above, or - snapo_bench_ext - any pair of functions with the
+ * snappy-c.h signatures (bench.py passes libsnappy 1.1.8's, the library the
+ * reference's own bench compares against, bench/src/bench.rs:117-153).
+ * Threads are pinned to the CPUs this process may run on, one each, round
+ * robin.  Test/bench infrastructure only. */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE
+#endif
 #include <pthread.h>
+#include <sched.h>
 #include <stdlib.h>
 #include <time.h>
+
+typedef int (*snappy_c_fn)(const char *, size_t, char *, size_t *);
 
 typedef struct bench_job {
     const uint8_t *const *datas;
@@ -607,6 +621,9 @@ typedef struct bench_job {
     double seconds;
     uint64_t rounds; /* out */
     size_t maxlen;
+    snappy_c_fn ext_compress, ext_uncompress; /* NULL: the restatement */
+    int cpu; /* CPU to pin to, -1 = none */
+    pthread_barrier_t *start;
 } bench_job;
 
 static double now_s(void)
@@ -619,18 +636,35 @@ static double now_s(void)
 static void *bench_worker(void *arg)
 {
     bench_job *j = (bench_job *)arg;
+    if (j->cpu >= 0) {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        CPU_SET(j->cpu, &set);
+        pthread_setaffinity_np(pthread_self(), sizeof set, &set);
+    }
     size_t cap = snapo_max_compress_len(j->maxlen);
     uint8_t *out = (uint8_t *)malloc(cap ? cap : 64);
+    memset(out, 0, cap ? cap : 64); /* pages touched before the clock */
     snapo_error e;
     size_t w;
+    pthread_barrier_wait(j->start);
     const double t_end = now_s() + j->seconds;
     uint64_t rounds = 0;
     do {
         for (int i = 0; i < j->n; i++) {
-            if (j->direction == 0)
+            if (j->ext_compress) {
+                w = cap;
+                if (j->direction == 0)
+                    j->ext_compress((const char *)j->datas[i], j->lens[i],
+                                    (char *)out, &w);
+                else
+                    j->ext_uncompress((const char *)j->comps[i], j->clens[i],
+                                      (char *)out, &w);
+            } else if (j->direction == 0) {
                 snapo_compress(j->datas[i], j->lens[i], out, cap, &w, &e);
-            else
+            } else {
                 snapo_decompress(j->comps[i], j->clens[i], out, cap, &w, &e);
+            }
         }
         rounds++;
     } while (now_s() < t_end);
@@ -639,10 +673,11 @@ static void *bench_worker(void *arg)
     return NULL;
 }
 
-double snapo_bench(const uint8_t *const *datas, const size_t *lens,
-                   const uint8_t *const *comps, const size_t *clens, int n,
-                   int direction, int threads, double seconds,
-                   uint64_t *total_rounds)
+double snapo_bench_ext(const uint8_t *const *datas, const size_t *lens,
+                       const uint8_t *const *comps, const size_t *clens, int n,
+                       int direction, int threads, double seconds,
+                       uint64_t *total_rounds, void *ext_compress,
+                       void *ext_uncompress, int pin)
 {
     bench_job *jobs = (bench_job *)calloc((size_t)threads, sizeof *jobs);
     pthread_t *th = (pthread_t *)calloc((size_t)threads, sizeof *th);
@@ -652,21 +687,44 @@ double snapo_bench(const uint8_t *const *datas, const size_t *lens,
             maxlen = lens[i];
         ubytes += lens[i];
     }
-    const double t0 = now_s();
+    /* CPUs this process may use, in order */
+    cpu_set_t allowed;
+    int cpus[CPU_SETSIZE], ncpu = 0;
+    if (pin && sched_getaffinity(0, sizeof allowed, &allowed) == 0)
+        for (int c = 0; c < CPU_SETSIZE; c++)
+            if (CPU_ISSET(c, &allowed))
+                cpus[ncpu++] = c;
+    pthread_barrier_t start;
+    pthread_barrier_init(&start, NULL, (unsigned)threads + 1);
     for (int t = 0; t < threads; t++) {
-        jobs[t] = (bench_job){datas, lens, comps, clens, n,
-                              direction, seconds, 0, maxlen};
+        jobs[t] = (bench_job){datas, lens, comps, clens, n, direction,
+                              seconds, 0, maxlen,
+                              (snappy_c_fn)ext_compress,
+                              (snappy_c_fn)ext_uncompress,
+                              ncpu ? cpus[t % ncpu] : -1, &start};
         pthread_create(&th[t], NULL, bench_worker, &jobs[t]);
     }
+    pthread_barrier_wait(&start); /* buffers are allocated and touched */
+    const double t0 = now_s();
     uint64_t rounds = 0;
     for (int t = 0; t < threads; t++) {
         pthread_join(th[t], NULL);
         rounds += jobs[t].rounds;
     }
     const double dt = now_s() - t0;
+    pthread_barrier_destroy(&start);
     if (total_rounds)
         *total_rounds = rounds;
     free(jobs);
     free(th);
     return (double)rounds * (double)ubytes / dt;
+}
+
+double snapo_bench(const uint8_t *const *datas, const size_t *lens,
+                   const uint8_t *const *comps, const size_t *clens, int n,
+                   int direction, int threads, double seconds,
+                   uint64_t *total_rounds)
+{
+    return snapo_bench_ext(datas, lens, comps, clens, n, direction, threads,
+                           seconds, total_rounds, NULL, NULL, 1);
 }

@@ -71,6 +71,11 @@ SYMBOLS = [
     ("snapmi_frame_scan_host", C.c_int,
      [_P, C.c_uint64, C.c_uint32, _P, _P, C.c_uint64,
       C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("snapmi_frame_encode_bound", _SZ, [_SZ, _SZ]),
+    ("snapmi_frame_encode_host", C.c_int,
+     [_P, _P, _P, _SZ, C.c_uint32, _P, _SZ, _SZP]),
+    ("snapmi_frame_decode_host", C.c_int,
+     [_P, _P, _SZ, C.c_uint32, _P, _P, _SZ, _SZP, _SZP, _ERRP]),
     ("snapmi_frame_index_host", C.c_int,
      [_P, C.c_uint64, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("snapmi_crc32c_masked_batch", C.c_int, [_P, _P, _P, _P, _SZ]),

@@ -987,10 +987,12 @@ __global__ void k_frame_meta_init(FrameDecodeArgs a)
     a.serr[0].kind = SNAPMI_OK;
 }
 
-int snapmi_frame_scan_host(const void *h_in, uint64_t in_len, uint32_t flags,
-                           uint8_t *stale10, uint64_t *h_offsets,
-                           uint64_t cap, uint64_t *n_chunks,
-                           uint64_t *consumed)
+// snapmi_frame_scan_host, stopping in front of data chunk number `max_data`
+// (status 3: the caller's output buffer is full)
+static int frame_scan(const void *h_in, uint64_t in_len, uint32_t flags,
+                      uint8_t *stale10, uint64_t *h_offsets, uint64_t cap,
+                      uint64_t max_data, uint64_t *n_chunks,
+                      uint64_t *consumed)
 {
     if (!n_chunks || !consumed || (in_len && !h_in))
         return SNAPMI_E_ARGUMENT;
@@ -1022,6 +1024,10 @@ int snapmi_frame_scan_host(const void *h_in, uint64_t in_len, uint32_t flags,
         }
         seen_ident = true;
         if (ty <= 0x01) {
+            if (nd == max_data) {
+                status = 3;
+                break;
+            }
             if (h_offsets) {
                 if (nd + 1 >= cap)
                     return SNAPMI_E_ARGUMENT;
@@ -1045,6 +1051,15 @@ int snapmi_frame_scan_host(const void *h_in, uint64_t in_len, uint32_t flags,
     *n_chunks = nd;
     *consumed = r;
     return status;
+}
+
+int snapmi_frame_scan_host(const void *h_in, uint64_t in_len, uint32_t flags,
+                           uint8_t *stale10, uint64_t *h_offsets,
+                           uint64_t cap, uint64_t *n_chunks,
+                           uint64_t *consumed)
+{
+    return frame_scan(h_in, in_len, flags, stale10, h_offsets, cap,
+                      ~0ull, n_chunks, consumed);
 }
 
 int snapmi_frame_decompress_ex(snapmi_ctx *ctx, const void *d_in,
@@ -1163,6 +1178,157 @@ int snapmi_frame_decompress(snapmi_ctx *ctx, const void *d_in,
     return snapmi_frame_decompress_ex(ctx, d_in, in_len, d_out, out_cap,
                                       d_out_len, d_err, d_chunk_offsets,
                                       n_chunks, 0, nullptr);
+}
+
+// ----------------------------------------------------------------------
+// Host-buffer forms (H2D + kernels + D2H, blocking): what a host-language
+// FrameEncoder / FrameDecoder (the Rust shim, the Python mirror, tools/szip)
+// calls per batch of chunks.
+// ----------------------------------------------------------------------
+size_t snapmi_frame_encode_bound(size_t total_bytes, size_t n_chunks)
+{
+    return 10 + total_bytes + 8 * n_chunks;
+}
+
+int snapmi_frame_encode_host(snapmi_ctx *ctx, const uint8_t *h_in,
+                             const uint32_t *h_chunk_lens, size_t n,
+                             uint32_t flags, uint8_t *h_out, size_t out_cap,
+                             size_t *written)
+{
+    if (!ctx || !written || (n && (!h_in || !h_chunk_lens || !h_out)))
+        return SNAPMI_E_ARGUMENT;
+    *written = 0;
+    if (n == 0)
+        return SNAPMI_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint64_t total = 0;
+    for (size_t i = 0; i < n; i++)
+        total += h_chunk_lens[i];
+    const size_t need = snapmi_frame_encode_bound(total, n);
+    if (out_cap < need - ((flags & SNAPMI_FRAME_NO_IDENT) ? 10 : 0))
+        return fail_ctx(ctx, SNAPMI_E_ARGUMENT,
+                        "frame_encode_host: out_cap %zu < %zu", out_cap, need);
+    int rc;
+    if ((rc = reserve(ctx, ctx->st_in, total + 16)) ||
+        (rc = reserve(ctx, ctx->st_out, need + 64)) ||
+        (rc = reserve(ctx, ctx->st_desc, 64)))
+        return rc;
+    hipStream_t s = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->st_in.p, h_in, total,
+                                hipMemcpyHostToDevice, s));
+    uint64_t *d_len = (uint64_t *)ctx->st_desc.p;
+    rc = snapmi_frame_compress_chunks(ctx, ctx->st_in.p, h_chunk_lens, n,
+                                      flags, ctx->st_out.p, need, d_len,
+                                      nullptr);
+    if (rc)
+        return rc;
+    uint64_t flen = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&flen, d_len, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    if (flen > out_cap)
+        return fail_ctx(ctx, SNAPMI_E_DEVICE, "frame_encode_host: %llu > cap",
+                        (unsigned long long)flen);
+    HIP_TRY(ctx, hipMemcpy(h_out, ctx->st_out.p, flen, hipMemcpyDeviceToHost));
+    *written = (size_t)flen;
+    return SNAPMI_OK;
+}
+
+int snapmi_frame_decode_host(snapmi_ctx *ctx, const uint8_t *h_in,
+                             size_t in_len, uint32_t flags, uint8_t *stale10,
+                             uint8_t *h_out, size_t out_cap, size_t *written,
+                             size_t *consumed, snapmi_error *err)
+{
+    if (!ctx || !written || !consumed || (in_len && !h_in) ||
+        (out_cap && !h_out) ||
+        (flags & ~(uint32_t)(SNAPMI_FRAME_CONTINUATION | SNAPMI_FRAME_FINAL)))
+        return SNAPMI_E_ARGUMENT;
+    *written = 0;
+    *consumed = 0;
+    if (err)
+        memset(err, 0, sizeof *err);
+    if (in_len == 0)
+        return SNAPMI_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const bool final = (flags & SNAPMI_FRAME_FINAL) != 0;
+    const uint32_t cflag = flags & SNAPMI_FRAME_CONTINUATION;
+    // as many whole chunks as the output buffer is sure to hold (a chunk
+    // decodes to at most 65536 bytes)
+    const uint64_t max_chunks = out_cap / kMaxBlock;
+    uint8_t stale_in[10] = {0};
+    if (stale10)
+        memcpy(stale_in, stale10, 10);
+    uint8_t stale_work[10];
+    memcpy(stale_work, stale_in, 10);
+    // the scan stops at the first cut-off (2) or rejected (1) chunk, or in
+    // front of the first data chunk the output buffer has no room for (3)
+    uint64_t nd = 0, used = 0;
+    int status = frame_scan(h_in, in_len, cflag, nullptr, nullptr, 0,
+                            max_chunks, &nd, &used);
+    if (status > 3)
+        return status;
+    std::vector<uint64_t> offs(nd + 1);
+    status = frame_scan(h_in, in_len, cflag, stale_work, offs.data(), nd + 1,
+                        max_chunks, &nd, &used);
+    if (status > 3)
+        return status;
+    if (status == 3 && used == 0 && max_chunks == 0)
+        return fail_ctx(ctx, SNAPMI_E_ARGUMENT,
+                        "frame_decode_host: out_cap below 65536");
+    const bool limited = status == 3;
+    if (used == 0 && status == 2 && !final)
+        return SNAPMI_OK; // not one whole chunk yet: read more
+    const bool clean = limited || status == 0 || (status == 2 && !final);
+    const uint64_t dec_len = clean ? used : in_len;
+    int rc;
+    if ((rc = reserve(ctx, ctx->st_in, dec_len + 16)) ||
+        (rc = reserve(ctx, ctx->st_out, nd * kMaxBlock + 64)) ||
+        (rc = reserve(ctx, ctx->st_desc, 128 + (nd + 1) * 8)))
+        return rc;
+    hipStream_t s = ctx->stream;
+    uint64_t *d_len = (uint64_t *)ctx->st_desc.p;
+    snapmi_error *d_err = (snapmi_error *)((uint8_t *)ctx->st_desc.p + 64);
+    uint64_t *d_idx = (uint64_t *)((uint8_t *)ctx->st_desc.p + 128);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->st_in.p, h_in, dec_len,
+                                hipMemcpyHostToDevice, s));
+    const bool with_index = clean && nd > 0;
+    if (with_index) {
+        HIP_TRY(ctx, hipMemcpyAsync(d_idx, offs.data(), (nd + 1) * 8,
+                                    hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s)); // offs is pageable memory
+    }
+    rc = snapmi_frame_decompress_ex(ctx, ctx->st_in.p, dec_len, ctx->st_out.p,
+                                    nd * kMaxBlock, d_len, d_err,
+                                    with_index ? d_idx : nullptr, nd, cflag,
+                                    stale_in);
+    if (rc)
+        return rc;
+    struct {
+        uint64_t len;
+        snapmi_error e;
+    } h;
+    HIP_TRY(ctx, hipMemcpyAsync(&h.len, d_len, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(&h.e, d_err, sizeof h.e,
+                                hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    if (h.len > out_cap)
+        return fail_ctx(ctx, SNAPMI_E_DEVICE, "frame_decode_host: %llu > cap",
+                        (unsigned long long)h.len);
+    if (h.len)
+        HIP_TRY(ctx, hipMemcpy(h_out, ctx->st_out.p, h.len,
+                               hipMemcpyDeviceToHost));
+    *written = (size_t)h.len;
+    if (err)
+        *err = h.e;
+    if (h.e.kind != SNAPMI_OK)
+        return h.e.kind;
+    if (!clean) // the host scan saw a bad or cut-off chunk the walk did not
+        return fail_ctx(ctx, SNAPMI_E_DEVICE,
+                        "frame_decode_host: host scan and device walk "
+                        "disagree");
+    *consumed = (size_t)used;
+    if (stale10)
+        memcpy(stale10, stale_work, 10);
+    return SNAPMI_OK;
 }
 
 } // extern "C"

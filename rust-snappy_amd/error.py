@@ -30,6 +30,7 @@ class Error(Exception):
         self.kind = int(kind)
         self.variant, names = KINDS.get(self.kind, (f"Kind{kind}", ()))
         vals = (int(a), int(b), int(c))
+        self.abc = vals  # the raw (a, b, c) of snapmi_error
         self.fields = dict(zip(names, vals))
         self.message = message
         text = self.variant

@@ -5,11 +5,14 @@
     snap::read::FrameEncoder<R>    reference src/read.rs:272-363
 
 on top of the device frame layer of libsnapmi.so (CRC32C kernel, chunk
-compress / decode kernels).  The reference compresses one <=64 KiB chunk per
-call; here the writer collects everything written between flushes and hands
-the device ALL chunks at once (every chunk is an independent raw stream), so
-chunk boundaries are exactly the reference's: 65536-byte multiples of the
-bytes written since the last flush (src/write.rs:123-152).
+compress / decode kernels).  The reference handles one <=64 KiB chunk per
+call; these adapters run the reference's state machines on the host to decide
+WHERE chunks begin and end (so the bytes are the reference's), but hand the
+device a bounded batch of chunks at a time (`batch_bytes`, 64 MiB by default;
+every chunk is an independent raw stream).  Memory stays bounded by the batch,
+data flows while the stream is still being written / read, and a decoder
+returns the bytes of the chunks in front of a bad chunk before it reports the
+error, like the reference's reader does.
 """
 import ctypes as C
 import io
@@ -92,6 +95,116 @@ def decompress_device(ctx, d_in, n_in, index=None, out_cap=None):
     return out, int(out_len.item())
 
 
+def compress_chunks_device(ctx, d_in, chunk_lens, ident=True):
+    """Frame-compress the chunks d_in[0:l0], d_in[l0:l0+l1], ... (each 1..65536
+    bytes, boundaries chosen by the caller; snapmi_frame_compress_chunks).
+    Returns (framed tensor, length)."""
+    lens = np.ascontiguousarray(chunk_lens, dtype=np.uint32)
+    n = int(lens.size)
+    total = int(lens.sum(dtype=np.uint64))
+    cap = (10 if ident else 0) + total + 8 * n
+    dev = d_in.device
+    out = torch.empty(max(cap, 16), dtype=torch.uint8, device=dev)
+    out_len = torch.zeros(1, dtype=torch.int64, device=dev)
+    rc = _lib.load().snapmi_frame_compress_chunks(
+        ctx._h, C.c_void_p(d_in.data_ptr()) if n else None,
+        lens.ctypes.data_as(C.c_void_p), n, 0 if ident else 1,
+        C.c_void_p(out.data_ptr()), cap, C.c_void_p(out_len.data_ptr()), None)
+    if rc:
+        raw._raise(ctx, rc)
+    ctx.synchronize()
+    return out, int(out_len.item())
+
+
+def scan_host(data, continuation=False, stale=None):
+    """snapmi_frame_scan_host: (status, consumed, offsets) for the complete,
+    well-formed chunks at the start of `data` (host bytes).  status 0 = all of
+    it, 2 = the next chunk is cut off, 1 = the next chunk is one the decoder
+    rejects.  `stale` (bytearray(10), updated in place) is the reference
+    reader's src[0..10) - see include/snapmi.h."""
+    L = _lib.load()
+    data = bytes(data)
+    n = C.c_uint64(0)
+    used = C.c_uint64(0)
+    st = (C.c_uint8 * 10).from_buffer(stale) if stale is not None else None
+    tmp = (C.c_uint8 * 10)(*stale) if stale is not None else None
+    # first pass counts (on a copy of the stale bytes), second pass fills
+    rc = L.snapmi_frame_scan_host(data, len(data), 1 if continuation else 0,
+                                  tmp, None, 0, C.byref(n), C.byref(used))
+    if rc > 2:
+        raise Error(rc)
+    offs = np.zeros(n.value + 1, dtype=np.uint64)
+    rc = L.snapmi_frame_scan_host(data, len(data), 1 if continuation else 0,
+                                  st, offs.ctypes.data_as(C.c_void_p),
+                                  len(offs), C.byref(n), C.byref(used))
+    if rc > 2:
+        raise Error(rc)
+    return rc, int(used.value), offs.astype(np.int64)
+
+
+def decompress_batch_device(ctx, d_in, n_in, n_chunks, index=None,
+                            continuation=False, stale=None):
+    """One batch of a stream through snapmi_frame_decompress_ex.  The output
+    buffer is sized from the chunk count (a chunk yields at most 65536 bytes).
+    Returns (bytes in front of the first error - all of them without one,
+    Error or None)."""
+    dev = d_in.device
+    cap = int(n_chunks) * MAX_BLOCK_SIZE
+    out = torch.empty(max(cap, 16), dtype=torch.uint8, device=dev)
+    out_len = torch.zeros(1, dtype=torch.int64, device=dev)
+    err = torch.zeros(32, dtype=torch.uint8, device=dev)
+    st = (C.c_uint8 * 10)(*stale) if stale is not None else None
+    rc = _lib.load().snapmi_frame_decompress_ex(
+        ctx._h, C.c_void_p(d_in.data_ptr()) if n_in else None, n_in,
+        C.c_void_p(out.data_ptr()), cap, C.c_void_p(out_len.data_ptr()),
+        C.c_void_p(err.data_ptr()),
+        C.c_void_p(index.data_ptr()) if index is not None else None,
+        (index.numel() - 1) if index is not None else 0,
+        1 if continuation else 0, st)
+    if rc:
+        raw._raise(ctx, rc)
+    ctx.synchronize()
+    e = _err_tuple(err)
+    good = out[:int(out_len.item())].cpu().numpy().tobytes()
+    return good, (Error(*e) if e[0] else None)
+
+
+def encode_host(ctx, data, chunk_lens, ident=True):
+    """snapmi_frame_encode_host: host bytes -> framed bytes, chunk boundaries
+    given by the caller."""
+    L = _lib.load()
+    lens = np.ascontiguousarray(chunk_lens, dtype=np.uint32)
+    n = int(lens.size)
+    cap = L.snapmi_frame_encode_bound(len(data), n)
+    out = bytearray(max(cap, 1))
+    written = C.c_size_t(0)
+    rc = L.snapmi_frame_encode_host(
+        ctx._h, (C.c_char * len(data)).from_buffer(data) if len(data) else None,
+        lens.ctypes.data_as(C.c_void_p), n, 0 if ident else 1,
+        (C.c_char * len(out)).from_buffer(out), cap, C.byref(written))
+    if rc:
+        raw._raise(ctx, rc)
+    return bytes(out[:written.value])
+
+
+def decode_host(ctx, data, out, continuation, final, stale):
+    """snapmi_frame_decode_host: decode the whole chunks at the start of
+    `data` (bytes) into the bytearray `out`; returns (written, consumed,
+    Error or None).  `stale`: bytearray(10) of decoder state, updated."""
+    L = _lib.load()
+    written, consumed = C.c_size_t(0), C.c_size_t(0)
+    err = _lib.SnapmiError()
+    flags = (1 if continuation else 0) | (2 if final else 0)
+    rc = L.snapmi_frame_decode_host(
+        ctx._h, data, len(data), flags, (C.c_uint8 * 10).from_buffer(stale),
+        (C.c_char * len(out)).from_buffer(out), len(out), C.byref(written),
+        C.byref(consumed), C.byref(err))
+    if rc >= 100:
+        raw._raise(ctx, rc)
+    e = Error(err.kind, err.a, err.b, err.c) if rc else None
+    return written.value, consumed.value, e
+
+
 def index_host(data):
     """Chunk scan of a framed stream in host memory (the hops of
     FrameDecoder::read, src/read.rs:105-172): int64 array of the data chunk
@@ -132,43 +245,107 @@ def crc32c_masked(ctx, data):
     return int(out.item()) & 0xFFFFFFFF
 
 
-class FrameEncoder:
-    """snap::write::FrameEncoder<W>: `write`, `flush`, `into_inner`,
-    `get_ref`; flushes on close like the reference's Drop."""
+BATCH_BYTES = 64 << 20  # what the streaming adapters hand the device at once
 
-    def __init__(self, wtr, ctx=None):
+
+class IntoInnerError(Exception):
+    """std::io::IntoInnerError (re-exported by the reference, src/write.rs:17):
+    into_inner() could not flush; carries the encoder and the error."""
+
+    def __init__(self, encoder, err):
+        super().__init__(f"into_inner: flush failed: {err}")
+        self._encoder, self._err = encoder, err
+
+    def error(self):
+        return self._err
+
+    def into_inner(self):
+        return self._encoder
+
+
+class FrameEncoder:
+    """snap::write::FrameEncoder<W> (reference src/write.rs:36-192): `write`,
+    `flush`, `into_inner`, `get_ref`, `get_mut`; flushes on close / with-exit
+    like the reference's Drop.
+
+    The chunking is the reference's state machine: a 65536-byte buffer `src`;
+    a write that does not fit fills the buffer and emits it - or, when the
+    buffer is empty, goes out directly as ceil(len / 65536) chunks INCLUDING
+    its partial tail (src/write.rs:123-152,171-190).  Chunks are queued and
+    compressed `batch_bytes` at a time; flush() compresses what is queued."""
+
+    def __init__(self, wtr, ctx=None, batch_bytes=BATCH_BYTES):
         self.w = wtr
         self.ctx = ctx or raw.default_context()
-        self._src = bytearray()
+        self.batch_bytes = max(int(batch_bytes), MAX_BLOCK_SIZE)
+        self._src = bytearray()      # reference `src`, capacity MAX_BLOCK_SIZE
+        self._queue = []             # chunks cut but not yet compressed
+        self._queued = 0
         self._wrote_ident = False
 
     def get_ref(self):
         return self.w
 
-    def write(self, buf):
-        self._src += bytes(buf)
+    get_mut = get_ref
+
+    # reference Inner::write (src/write.rs:171-190): cut `buf` into chunks
+    def _inner_write(self, buf):
+        for o in range(0, len(buf), MAX_BLOCK_SIZE):
+            self._queue.append(bytes(buf[o:o + MAX_BLOCK_SIZE]))
+        self._queued += len(buf)
+        if self._queued >= self.batch_bytes:
+            self._emit()
         return len(buf)
+
+    def _emit(self):
+        if not self._queue:
+            return
+        lens = np.fromiter((len(c) for c in self._queue), dtype=np.uint32,
+                           count=len(self._queue))
+        host = bytearray().join(self._queue)
+        self._queue, self._queued = [], 0
+        framed = encode_host(self.ctx, host, lens,
+                             ident=not self._wrote_ident)
+        self._wrote_ident = True   # identifier only once (:167-170)
+        self.w.write(framed)
+
+    def write(self, buf):
+        buf = memoryview(bytes(buf))
+        total = 0
+        while True:  # src/write.rs:123-152
+            free = MAX_BLOCK_SIZE - len(self._src)
+            if len(buf) <= free:
+                break
+            if not self._src:
+                n = self._inner_write(buf)
+            else:
+                self._src += buf[:free]
+                self._flush_src()
+                n = free
+            buf = buf[n:]
+            total += n
+        self._src += buf
+        return total + len(buf)
 
     def write_all(self, buf):
         self.write(buf)
 
+    def _flush_src(self):
+        if self._src:
+            self._inner_write(self._src)
+            self._src = bytearray()
+
     def flush(self):
-        """Everything written so far becomes chunks (reference: a flush
-        emits the partial block, src/write.rs:154-161)."""
-        if not self._src:
-            return
-        dev = torch.device("cuda", self.ctx.device)
-        d_in = torch.frombuffer(self._src, dtype=torch.uint8).to(dev)
-        out, n, _ = compress_device(self.ctx, d_in)
-        framed = out[:n].cpu().numpy().tobytes()
-        if self._wrote_ident:  # identifier only once per stream (:167-170)
-            framed = framed[len(STREAM_IDENTIFIER):]
-        self._wrote_ident = True
-        self.w.write(framed)
-        self._src = bytearray()
+        """src/write.rs:154-161: the partial block becomes a chunk; everything
+        queued is compressed and written to the inner writer."""
+        self._flush_src()
+        self._emit()
 
     def into_inner(self):
-        self.flush()
+        try:
+            self.flush()
+        except Exception as e:  # src/write.rs:91-97
+            raise IntoInnerError(self, e) from e
         return self.w
 
     def close(self):
@@ -178,72 +355,167 @@ class FrameEncoder:
         return self
 
     def __exit__(self, *a):
-        self.flush()
+        try:                # Drop ignores flush errors (src/write.rs:112-120)
+            self.flush()
+        except Exception:
+            if a[0] is None:
+                raise
 
 
 class FrameDecoder:
-    """snap::read::FrameDecoder<R>: `read`, `get_ref`, `into_inner`."""
+    """snap::read::FrameDecoder<R> (reference src/read.rs:47-239): `read`,
+    `get_ref`, `get_mut`, `into_inner`.
 
-    def __init__(self, rdr, ctx=None):
+    Pulls at most `batch_bytes` from the reader at a time, cuts the batch at
+    its last complete chunk (host scan of the chunk headers, which also serves
+    as the side index) and decodes those chunks in one device call.  Bytes of
+    the chunks in front of a bad chunk are returned first; the error is raised
+    by the read that reaches it (src/read.rs:111-118)."""
+
+    def __init__(self, rdr, ctx=None, batch_bytes=BATCH_BYTES):
         self.r = rdr
         self.ctx = ctx or raw.default_context()
-        self._out = None
+        self.batch_bytes = max(int(batch_bytes), 1 << 17)
+        self._carry = b""        # bytes read but not decoded (a cut chunk)
+        self._out = b""
         self._pos = 0
+        self._err = None
+        self._eof = False
+        self._seen_ident = False
+        self._stale = bytearray(10)  # reference src[0..10): include/snapmi.h
 
     def get_ref(self):
         return self.r
+
+    get_mut = get_ref
 
     def into_inner(self):
         return self.r
 
+    def _pull(self, want):
+        parts, got = [self._carry], len(self._carry)
+        while got < want and not self._eof:
+            b = self.r.read(want - got)
+            if not b:
+                self._eof = True
+                break
+            parts.append(bytes(b))
+            got += len(b)
+        self._carry = b""
+        return b"".join(parts)
+
     def _fill(self):
-        data = self.r.read()
-        dev = torch.device("cuda", self.ctx.device)
-        if not data:
-            self._out = b""
-            return
-        d_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
-        # the reader's bytes pass through the host anyway: scan the chunk
-        # headers here and spare the device its sequential walk
-        offs = index_host(data)
-        index = torch.from_numpy(offs).to(dev) if offs is not None else None
-        out, n = decompress_device(self.ctx, d_in, len(data), index=index)
-        self._out = out[:n].cpu().numpy().tobytes()
+        want = self.batch_bytes
+        while True:
+            data = self._pull(want)
+            if not data:
+                return
+            # room for every chunk the batch can hold: a chunk is at least 8
+            # bytes of header and yields at most 65536 bytes, but a batch of
+            # 64 KiB chunks needs about its own size; decode_host consumes
+            # only as many chunks as fit and is called again for the rest
+            out = bytearray(max(2 * len(data), 1 << 20) // MAX_BLOCK_SIZE
+                            * MAX_BLOCK_SIZE)
+            n, used, err = decode_host(self.ctx, data, out, self._seen_ident,
+                                       self._eof, self._stale)
+            if err is None and used == 0:   # not one whole chunk yet
+                self._carry = data
+                want = len(data) + self.batch_bytes
+                if self._eof:
+                    raise Error(101, message="frame_decode_host made no "
+                                             "progress at end of input")
+                continue
+            break
+        self._carry = data[used:] if err is None else b""
+        self._seen_ident = self._seen_ident or used > 0
+        self._out, self._pos, self._err = bytes(out[:n]), 0, err
 
     def read(self, size=-1):
-        if self._out is None:
+        """Up to `size` bytes (all remaining for size < 0).  An error is
+        raised once the bytes in front of it have been returned."""
+        parts, need = [], (None if size is None or size < 0 else size)
+        while need is None or need > 0:
+            if self._pos < len(self._out):
+                end = len(self._out) if need is None else min(
+                    len(self._out), self._pos + need)
+                parts.append(self._out[self._pos:end])
+                if need is not None:
+                    need -= end - self._pos
+                self._pos = end
+                continue
+            if self._err is not None:
+                if parts:
+                    break          # hand out the good bytes first
+                raise self._err
+            if self._eof and not self._carry:
+                break
             self._fill()
-        if size is None or size < 0:
-            size = len(self._out) - self._pos
-        chunk = self._out[self._pos:self._pos + size]
-        self._pos += len(chunk)
-        return chunk
+            if not self._out and self._err is None and self._eof \
+                    and not self._carry:
+                break
+        return b"".join(parts)
 
     def read_to_end(self):
-        return self.read(-1)
+        """io::Read::read_to_end: all bytes, or the stream's error (with the
+        bytes decoded in front of it in `.partial`)."""
+        data = self.read(-1)
+        if self._err is not None:
+            e = self._err
+            e.partial = data
+            raise e
+        return data
 
 
 class ReadFrameEncoder:
-    """snap::read::FrameEncoder<R>: reading yields the framed stream."""
+    """snap::read::FrameEncoder<R> (reference src/read.rs:272-409): reading
+    yields the framed stream.  Like the reference, every chunk is what ONE
+    read of up to 65536 bytes from the inner reader returned (read.rs:378);
+    up to `batch_bytes` of such reads are compressed in one device call."""
 
-    def __init__(self, rdr, ctx=None):
+    def __init__(self, rdr, ctx=None, batch_bytes=BATCH_BYTES):
         self.r = rdr
         self.ctx = ctx or raw.default_context()
-        self._buf = None
+        self.batch_bytes = max(int(batch_bytes), MAX_BLOCK_SIZE)
+        self._buf = b""
         self._pos = 0
+        self._eof = False
+        self._wrote_ident = False
 
     def get_ref(self):
         return self.r
 
+    get_mut = get_ref
+
+    def _fill(self):
+        chunks, total = [], 0
+        while total < self.batch_bytes:
+            b = self.r.read(MAX_BLOCK_SIZE)
+            if not b:
+                self._eof = True
+                break
+            chunks.append(bytes(b))
+            total += len(b)
+        self._buf, self._pos = b"", 0
+        if not chunks:
+            return
+        lens = np.fromiter((len(c) for c in chunks), dtype=np.uint32,
+                           count=len(chunks))
+        self._buf = encode_host(self.ctx, bytearray().join(chunks), lens,
+                                ident=not self._wrote_ident)
+        self._wrote_ident = True
+
     def read(self, size=-1):
-        if self._buf is None:
-            sink = io.BytesIO()
-            enc = FrameEncoder(sink, self.ctx)
-            enc.write_all(self.r.read())
-            enc.flush()
-            self._buf = sink.getvalue()
-        if size is None or size < 0:
-            size = len(self._buf) - self._pos
-        chunk = self._buf[self._pos:self._pos + size]
-        self._pos += len(chunk)
-        return chunk
+        parts, need = [], (None if size is None or size < 0 else size)
+        while need is None or need > 0:
+            if self._pos < len(self._buf):
+                end = len(self._buf) if need is None else min(
+                    len(self._buf), self._pos + need)
+                parts.append(self._buf[self._pos:end])
+                if need is not None:
+                    need -= end - self._pos
+                self._pos = end
+                continue
+            if self._eof:
+                break
+            self._fill()
+        return b"".join(parts)

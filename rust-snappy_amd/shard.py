@@ -48,24 +48,28 @@ def exchange_sizes(local_bytes, device="cpu", group=None):
 def gatherv(local, dst=0, group=None):
     """Variable-length gather of 1-D uint8 tensors to rank `dst`.
 
-    RCCL has no gatherv: sizes are exchanged first, then every rank sends its
-    slab straight into the root's buffer at its prefix offset (grouped
-    point-to-point: on xGMI the root's 7 inbound links work in parallel, which
-    a ring would not).  Returns the concatenation on `dst`, None elsewhere."""
+    RCCL has no gatherv: sizes are exchanged first (one all_gather of a u64
+    per rank), then every rank's slab goes straight into the root's buffer at
+    its prefix offset as ONE group of point-to-point operations
+    (batch_isend_irecv = ncclGroupStart ... ncclSend / ncclRecv ...
+    ncclGroupEnd): on xGMI the root's 7 inbound links then receive
+    in parallel, which a ring (per-link bound) would not.  Returns the
+    concatenation on `dst`, None elsewhere."""
     rank = dist.get_rank(group)
     world = dist.get_world_size(group)
     sizes, offs = exchange_sizes(local.numel(), local.device, group)
+    ops, out = [], None
     if rank == dst:
         out = torch.empty(sum(sizes), dtype=torch.uint8, device=local.device)
         out[offs[dst]:offs[dst] + sizes[dst]] = local
-        reqs = []
         for r in range(world):
             if r != dst and sizes[r]:
-                reqs.append(dist.irecv(out[offs[r]:offs[r] + sizes[r]], src=r,
-                                       group=group))
-        for q in reqs:
+                ops.append(dist.P2POp(dist.irecv,
+                                      out[offs[r]:offs[r] + sizes[r]], r,
+                                      group))
+    elif local.numel():
+        ops.append(dist.P2POp(dist.isend, local.contiguous(), dst, group))
+    if ops:
+        for q in dist.batch_isend_irecv(ops):
             q.wait()
-        return out
-    if local.numel():
-        dist.send(local.contiguous(), dst=dst, group=group)
-    return None
+    return out

@@ -119,3 +119,42 @@ def test_frame_index_host(built):
                 f[:4] + b"sNaPpX" + f[10:],
                 f[:10] + bytes([0x01, 0x05, 0x00, 0x01]) + bytes(65541)):
         assert frame.index_host(bad) is None
+
+
+def test_frame_scan_host_batches_and_stale_bytes(built):
+    """snapmi_frame_scan_host is host code (no GPU): how far whole,
+    well-formed chunks reach, the data chunk offsets, and the 10 bytes of the
+    reference reader's scratch buffer (src/read.rs:118,151,157,168,214) that
+    the truncated-varint rule of read.rs:216 needs."""
+    import oracle_lib as O
+    from rust_snappy_amd import frame
+    data = (O.CORPUS / "alice29.txt").read_bytes()          # 3 chunks
+    f = O.frame_compress(data)
+    st, used, offs = frame.scan_host(f)
+    assert (st, used) == (0, len(f)) and len(offs) == 4 and offs[0] == 10
+    # cut inside the last chunk: status 2, consumed = end of chunk 2
+    st, used, o2 = frame.scan_host(f[:-7])
+    assert st == 2 and used == offs[2] and list(o2) == list(offs[:3])
+    # cut inside a header
+    st, used, _ = frame.scan_host(f[:int(offs[1]) + 2])
+    assert st == 2 and used == offs[1]
+    # a continuation batch does not start with the identifier
+    st, used, o3 = frame.scan_host(f[int(offs[1]):], continuation=True)
+    assert st == 0 and o3[0] == 0 and len(o3) == 3
+    st, used, _ = frame.scan_host(f[int(offs[1]):], continuation=False)
+    assert (st, used) == (1, 0)                              # StreamHeader
+    # rejected headers stop the scan where they start
+    bad = f[:int(offs[2])] + bytes([0x02, 1, 0, 0, 0])
+    st, used, _ = frame.scan_host(bad)
+    assert (st, used) == (1, int(offs[2]))
+    # the stale model: header bytes, then the body of non-stored chunks
+    stale = bytearray(10)
+    s = f[:10] + bytes([0x80, 12, 0, 0]) + bytes(range(100, 112))
+    assert frame.scan_host(s, False, stale)[0] == 0
+    assert bytes(stale) == bytes(range(100, 110))
+    stored = bytes([0x01, 9, 0, 0]) + b"CRC!" + b"hello"
+    assert frame.scan_host(stored, True, stale)[0] == 0
+    assert bytes(stale) == bytes([0x01, 9, 0, 0]) + bytes(range(104, 110))
+    comp = bytes([0x00, 7, 0, 0]) + b"CRC!" + b"\x80\x81\x82"
+    assert frame.scan_host(comp, True, stale)[0] == 0
+    assert bytes(stale) == b"\x80\x81\x82\x00" + bytes(range(104, 110))

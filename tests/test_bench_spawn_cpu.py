@@ -1,0 +1,60 @@
+"""bench.py --gpus N launch plumbing, without a GPU (gloo).  The real run needs
+N MI355X; what can be checked here is that `python bench.py --gpus N` alone
+turns into N ranks with a working process group, that rank 0 prints one JSON
+line with n_gpus = N, and that a WORLD_SIZE / --gpus mismatch is refused."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def run(args, env=None, timeout=240):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR",
+              "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, str(ROOT / "bench.py")] + args,
+                          capture_output=True, text=True, env=e,
+                          timeout=timeout)
+
+
+def json_lines(p):
+    return [json.loads(x) for x in p.stdout.splitlines() if x.startswith("{")]
+
+
+def test_gpus_n_spawns_n_ranks():
+    p = run(["--gpus", "2", "--plumbing-check"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = json_lines(p)
+    assert len(lines) == 1, p.stdout          # rank 0 only, one line
+    assert lines[0]["n_gpus"] == 2 and lines[0]["ranks_seen"] == [0, 1]
+    assert lines[0]["max_over_ranks"] == 2.0   # MAX over ranks, not rank 0's
+    assert "spawning 2 ranks" in p.stderr
+
+
+def test_single_rank_needs_no_launcher():
+    p = run(["--plumbing-check"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert json_lines(p)[0]["n_gpus"] == 1
+
+
+def test_world_size_mismatch_is_refused():
+    p = run(["--gpus", "4", "--plumbing-check"],
+            env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert p.returncode != 0
+    assert "--gpus 4 but WORLD_SIZE=2" in p.stderr
+    assert not json_lines(p)
+
+
+def test_more_gpus_than_devices_is_refused():
+    # no GPU in the CPU container: --gpus 2 without the plumbing flag must
+    # refuse before it spawns anything
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        return
+    p = run(["--gpus", "2"])
+    assert p.returncode != 0 and "GPU(s) visible" in p.stderr

@@ -108,11 +108,12 @@ def expect_error(ctx, stream, key):
         assert got.kind == want_oracle.kind
         assert got.fields["bytes"] == int.from_bytes(body, "little")
     else:
+        # every field the variant has, and the unused ones must be zero
         assert got.kind == want_oracle.kind
-        nfields = len(got.fields)
-        assert tuple(got.fields.values()) == \
-            (want_oracle.a, want_oracle.b, want_oracle.c)[:nfields]
+        assert got.abc == (want_oracle.a, want_oracle.b, want_oracle.c), \
+            (got, want_oracle)
     assert got.variant == key, (got, key)
+    return got
 
 
 def test_frame_decoder_errors(ctx):
@@ -133,13 +134,24 @@ def test_frame_decoder_errors(ctx):
     # corrupt payload -> raw decoder error surfaces
     bad = bytearray(good)
     bad[10 + 8 + 3 + 5] ^= 0xFF
-    try:
+    with pytest.raises(O.SnapError) as oe:   # the oracle rejects it ...
         O.frame_decompress(bytes(bad))
-        corrupt_ok = True
-    except O.SnapError as oe:
-        corrupt_ok = False
-        expect_error(ctx, bytes(bad), O.KIND_NAMES[oe.kind])
-    assert not corrupt_ok or True
+    assert oe.value.kind in (5, 6, 7, 8, 9, 14)  # raw decode error or CRC
+    expect_error(ctx, bytes(bad), O.KIND_NAMES[oe.value.kind])  # ... same here
+    # a sweep of single-byte corruptions of the first payload: whatever the
+    # oracle says (error variant + fields, or the decoded bytes), the GPU says
+    rng = random.Random(5)
+    from rust_snappy_amd import frame as _frame
+    for _ in range(40):
+        bad = bytearray(good)
+        bad[10 + 8 + rng.randrange(3, 2000)] ^= 1 << rng.randrange(8)
+        try:
+            want = O.frame_decompress(bytes(bad))
+        except O.SnapError as oe2:
+            expect_error(ctx, bytes(bad), O.KIND_NAMES[oe2.kind])
+        else:
+            assert _frame.FrameDecoder(io.BytesIO(bytes(bad)),
+                                       ctx).read_to_end() == want
     # truncated stream
     expect_error(ctx, good[:-5], "UnexpectedEof")
     # skippable + padding chunks are skipped (src/read.rs:143-158)
@@ -227,3 +239,376 @@ def test_read_frame_encoder_big_and_little_buffers(ctx):
     assert drain(frame.ReadFrameEncoder(io.BytesIO(data), ctx), 5) == want
     assert drain(frame.FrameDecoder(io.BytesIO(want), ctx), 5) == data
     assert drain(frame.FrameDecoder(io.BytesIO(want), ctx), 1 << 20) == data
+
+
+# ---------------------------------------------------------------------
+# streaming semantics of the adapters (reference src/write.rs:123-192,
+# src/read.rs:105-238,342-409)
+# ---------------------------------------------------------------------
+def reference_chunks(ops):
+    """Where write::FrameEncoder cuts chunks for a sequence of ("w", bytes) /
+    ("f",) operations followed by into_inner(): a literal restatement of
+    src/write.rs:123-161 (64 KiB buffer `src`; a write larger than the free
+    space goes out directly when the buffer is empty, else fills and flushes
+    the buffer)."""
+    CAP = 65536
+    src, out = bytearray(), []
+
+    def inner_write(buf):
+        for o in range(0, len(buf), CAP):
+            out.append(bytes(buf[o:o + CAP]))
+        return len(buf)
+
+    def flush():
+        if src:
+            inner_write(bytes(src))
+            del src[:]
+
+    for op in ops:
+        if op[0] == "f":
+            flush()
+            continue
+        buf = op[1]
+        while True:
+            free = CAP - len(src)
+            if len(buf) <= free:
+                break
+            if not src:
+                n = inner_write(buf)
+            else:
+                src.extend(buf[:free])
+                flush()
+                n = free
+            buf = buf[n:]
+        src.extend(buf)
+    flush()
+    return out
+
+
+def frame_of_chunks(chunks):
+    """The framed stream whose chunks are exactly `chunks`: every chunk
+    through the oracle's compress_frame (= frame_compress of <= 64 KiB)."""
+    if not chunks:
+        return b""
+    return b"\xff\x06\x00\x00sNaPpY" + b"".join(
+        O.frame_compress(c)[10:] for c in chunks)
+
+
+def test_frame_encoder_write_state_machine(ctx):
+    from rust_snappy_amd import frame
+    text = (O.CORPUS / "lcet10.txt").read_bytes()
+    jpg = (O.CORPUS / "fireworks.jpeg").read_bytes()
+    # the advisor's example: two writes of 100000 bytes, no flush between
+    ops = [("w", text[:100000]), ("w", text[100000:200000])]
+    assert [len(c) for c in reference_chunks(ops)] == [65536, 34464, 65536,
+                                                       34464]
+    rng = random.Random(21)
+    cases = [ops,
+             [("w", text[:65536]), ("w", text[65536:65537])],
+             [("w", text[:10]), ("w", text[10:200000])],
+             [("w", text[:65535]), ("w", text[65535:65537]), ("f",),
+              ("w", jpg), ("w", b"")],
+             [("w", b"")], []]
+    for _ in range(12):   # random mixes of small / large writes and flushes
+        pos, case = 0, []
+        blob = text + jpg + text
+        while pos < len(blob):
+            n = rng.choice([1, 7, 100, 4096, 65535, 65536, 65537, 100000,
+                            200000])
+            case.append(("w", blob[pos:pos + n]))
+            pos += n
+            if rng.random() < 0.2:
+                case.append(("f",))
+        cases.append(case)
+    for case in cases:
+        for batch in (frame.BATCH_BYTES, 1 << 16, 3 << 16):
+            sink = io.BytesIO()
+            enc = frame.FrameEncoder(sink, ctx, batch_bytes=batch)
+            for op in case:
+                if op[0] == "w":
+                    assert enc.write(op[1]) == len(op[1])
+                else:
+                    enc.flush()
+            got = enc.into_inner().getvalue()
+            want = frame_of_chunks(reference_chunks(case))
+            assert got == want, ([len(c) for c in reference_chunks(case)],
+                                 batch)
+            data = b"".join(op[1] for op in case if op[0] == "w")
+            assert frame.FrameDecoder(io.BytesIO(got), ctx).read_to_end() \
+                == data
+
+
+def test_frame_encoder_emits_before_flush_and_into_inner_error(ctx):
+    """With a small batch the writer sees chunks while the stream is still
+    being written (bounded memory); a failing inner writer surfaces as
+    IntoInnerError carrying the encoder (src/write.rs:91-97)."""
+    from rust_snappy_amd import frame
+    text = (O.CORPUS / "plrabn12.txt").read_bytes()
+    sink = io.BytesIO()
+    enc = frame.FrameEncoder(sink, ctx, batch_bytes=1 << 17)
+    enc.write(text[:300000])
+    assert len(sink.getvalue()) > 10     # four whole chunks are out already
+    enc.write(text[300000:])
+    assert enc.into_inner().getvalue() == frame_of_chunks(reference_chunks(
+        [("w", text[:300000]), ("w", text[300000:])]))
+
+    class Broken(io.RawIOBase):
+        def write(self, b):
+            raise OSError("disk full")
+
+    enc = frame.FrameEncoder(Broken(), ctx)
+    enc.write(b"abc")
+    with pytest.raises(frame.IntoInnerError) as ei:
+        enc.into_inner()
+    assert isinstance(ei.value.error(), OSError)
+    assert ei.value.into_inner() is enc
+
+
+class Dribble(io.RawIOBase):
+    """A reader that returns at most `step` bytes per read call."""
+
+    def __init__(self, data, step):
+        self.b, self.step = io.BytesIO(data), step
+
+    def read(self, n=-1):
+        n = self.step if n is None or n < 0 else min(n, self.step)
+        return self.b.read(n)
+
+
+def test_frame_decoder_streams_in_batches(ctx):
+    from rust_snappy_amd import frame
+    data = b"".join(d for _, d in O.corpus_round()) * 2      # ~90 chunks
+    f = O.frame_compress(data)
+    for batch, step in ((1 << 17, 1 << 20), (1 << 17, 70000), (1 << 18, 999),
+                        (frame.BATCH_BYTES, 1 << 20)):
+        dec = frame.FrameDecoder(Dribble(f, step), ctx, batch_bytes=batch)
+        out = bytearray()
+        while True:
+            b = dec.read(100000)
+            if not b:
+                break
+            out += b
+        assert bytes(out) == data, (batch, step)
+    # the reader is only asked for what a batch needs: after the first read
+    # of a small-batch decoder most of the stream is still unread
+    rd = io.BytesIO(f)
+    dec = frame.FrameDecoder(rd, ctx, batch_bytes=1 << 17)
+    assert dec.read(10) == data[:10]
+    assert rd.tell() <= (1 << 17) + 10
+    # concatenated streams / other chunk types across batch boundaries
+    g = f + f[:10] + bytes([0x80, 3, 0, 0, 1, 2, 3]) + f[10:] + \
+        bytes([0xFE, 2, 0, 0, 9, 9])
+    dec = frame.FrameDecoder(io.BytesIO(g), ctx, batch_bytes=1 << 17)
+    assert dec.read_to_end() == data + data == O.frame_decompress(g)
+
+
+def test_frame_decoder_returns_good_chunks_before_the_error(ctx):
+    """src/read.rs:111-118: bytes of earlier chunks are handed out before the
+    read that reaches a bad chunk fails."""
+    import rust_snappy_amd as R
+    from rust_snappy_amd import frame
+    data = (O.CORPUS / "alice29.txt").read_bytes()           # 3 chunks
+    f = bytearray(O.frame_compress(data))
+    offs = frame.index_host(bytes(f))
+    f[int(offs[1]) + 8 + 20] ^= 0xFF                          # 2nd chunk body
+    with pytest.raises(O.SnapError) as oe:
+        O.frame_decompress(bytes(f))
+    for batch in (1 << 17, frame.BATCH_BYTES):
+        dec = frame.FrameDecoder(io.BytesIO(bytes(f)), ctx, batch_bytes=batch)
+        assert dec.read(65536) == data[:65536]   # the good chunk is readable
+        with pytest.raises(R.Error) as ei:
+            dec.read(1)
+        assert ei.value.kind == oe.value.kind
+        assert ei.value.abc == (oe.value.a, oe.value.b, oe.value.c)
+        dec = frame.FrameDecoder(io.BytesIO(bytes(f)), ctx, batch_bytes=batch)
+        with pytest.raises(R.Error) as ei:
+            dec.read_to_end()
+        assert ei.value.partial == data[:65536]
+    # truncated in the third chunk: two chunks readable, then UnexpectedEof
+    g = O.frame_compress(data)[:-7]
+    dec = frame.FrameDecoder(io.BytesIO(g), ctx, batch_bytes=1 << 17)
+    assert dec.read(1 << 20) == data[:131072]
+    with pytest.raises(R.Error) as ei:
+        dec.read(1)
+    assert ei.value.variant == "UnexpectedEof"
+    # device entry point: valid prefix length next to the error
+    d_in = torch.frombuffer(bytearray(f), dtype=torch.uint8).cuda()
+    for index in (None, torch.from_numpy(offs).cuda()):
+        good, err = frame.decompress_batch_device(ctx, d_in, len(f), 3, index)
+        assert good == data[:65536] and err.kind == oe.value.kind
+
+
+def test_read_frame_encoder_chunks_follow_the_reads(ctx):
+    """read::FrameEncoder makes ONE read of up to 65536 bytes per chunk
+    (src/read.rs:378): a reader that returns short reads gets short chunks."""
+    from rust_snappy_amd import frame
+    data = (O.CORPUS / "asyoulik.txt").read_bytes()
+    for step in (65536, 50000, 1000):
+        want = frame_of_chunks([data[o:o + step]
+                                for o in range(0, len(data), step)])
+        for batch in (1 << 16, frame.BATCH_BYTES):
+            enc = frame.ReadFrameEncoder(Dribble(data, step), ctx,
+                                         batch_bytes=batch)
+            out = bytearray()
+            while True:
+                b = enc.read(4097)
+                if not b:
+                    break
+                out += b
+            assert bytes(out) == want, (step, batch)
+
+
+# ---------------------------------------------------------------------
+# src/read.rs:216: decompress_len over the reader's whole scratch buffer
+# ---------------------------------------------------------------------
+def chunk(ty, body, crc=b""):
+    n = len(crc) + len(body)
+    return bytes([ty, n & 255, (n >> 8) & 255, n >> 16]) + crc + body
+
+
+def test_frame_short_varint_reads_the_stale_scratch_buffer(ctx):
+    """A compressed chunk whose payload has no varint terminator (fewer than
+    10 bytes, all >= 0x80, or empty): the reference parses the length from its
+    76 490-byte scratch buffer, i.e. continues into this chunk's own header
+    bytes and the bodies of earlier chunks.  The oracle models that buffer;
+    the device reproduces it (frame_short_varint).  Every outcome: Header,
+    Empty, TooBig, UnsupportedChunkLength."""
+    import rust_snappy_amd as R
+    from rust_snappy_amd import frame
+    ident = b"\xff\x06\x00\x00sNaPpY"
+    good = O.frame_compress((O.CORPUS / "html").read_bytes())[10:]
+    crc = b"\x11\x22\x33\x44"
+    skip = lambda body: chunk(0x80, body)
+    streams = {
+        # payload ff ff, then header bytes 2..3 (00 00): varint ends -> 16383,
+        # acceptable -> Decoder::decompress(2 bytes) -> Header
+        "hdr": ident + chunk(0, b"\xff\xff", crc),
+        # empty payload: phantom length from the header bytes -> Empty
+        "empty": ident + chunk(0, b"", crc),
+        # 5 continuation bytes, stale[5] = 0x7f from a skippable chunk -> TooBig
+        "toobig": ident + skip(b"\xaa" * 5 + b"\x7f" + b"\xaa" * 4)
+                  + chunk(0, b"\xff" * 5, crc),
+        # 80 80 80 80 then stale[4] = 01 -> 1 << 28 -> UnsupportedChunkLength
+        "len": ident + skip(b"\xbb" * 4 + b"\x01" + b"\xbb" * 5)
+               + chunk(0, b"\x80" * 4, crc),
+        # stale bytes from an earlier COMPRESSED chunk's payload (good data)
+        "after_data": ident + good + chunk(0, b"\x80" * 6, crc),
+        # stale continuation never ends -> Header
+        "never": ident + skip(b"\xcc" * 10) + chunk(0, b"\x80" * 4, crc),
+        # a stored chunk in between does not touch the scratch buffer
+        "stored_between": ident + skip(b"\xdd" * 5 + b"\x03" + b"\xdd" * 4)
+                          + chunk(1, b"x" * 20, struct.pack(
+                              "<I", O.crc32c_masked(b"x" * 20)))
+                          + chunk(0, b"\x80" * 5, crc),
+    }
+    seen = set()
+    for name, s in streams.items():
+        with pytest.raises(O.SnapError) as oe:
+            O.frame_decompress(s)
+        seen.add(oe.value.name)
+        got = expect_error(ctx, s, oe.value.name)
+        assert got.abc == (oe.value.a, oe.value.b, oe.value.c), name
+        # small batches: the stale bytes travel from batch to batch
+        dec = frame.FrameDecoder(Dribble(s, 7), ctx, batch_bytes=1 << 17)
+        with pytest.raises(R.Error) as ei:
+            dec.read_to_end()
+        assert ei.value == got, name
+        # a side index does not change the verdict (the walk takes over)
+        st, used, offs = frame.scan_host(s)
+        d_in = torch.frombuffer(bytearray(s), dtype=torch.uint8).cuda()
+        _, err = frame.decompress_batch_device(
+            ctx, d_in, len(s), len(offs) - 1, torch.from_numpy(offs).cuda())
+        assert err == got, name
+    assert seen == {"Header", "Empty", "TooBig", "UnsupportedChunkLength"}
+    # the good chunks in front of such a chunk are still delivered
+    dec = frame.FrameDecoder(io.BytesIO(streams["after_data"]), ctx)
+    html = (O.CORPUS / "html").read_bytes()
+    assert dec.read(1 << 20) == html
+
+
+def test_frame_side_index_is_only_a_hint(ctx):
+    """A wrong side index (out of range, not increasing, skipping chunks,
+    pointing into a payload) must give the result of decoding without one."""
+    from rust_snappy_amd import frame
+    data = b"".join(d for _, d in O.corpus_round()[:3])
+    f = O.frame_compress(data)
+    offs = frame.index_host(f)
+    d_in = torch.frombuffer(bytearray(f), dtype=torch.uint8).cuda()
+    n = len(offs) - 1
+    bad = []
+    for mut in range(6):
+        o = offs.copy()
+        if mut == 0:
+            o[1] = np.int64(-8)                 # 2^64 - 8: r + 8 wraps
+        elif mut == 1:
+            o[2], o[3] = o[3], o[2]
+        elif mut == 2:
+            o = np.delete(o, 1)                 # skips a chunk
+        elif mut == 3:
+            o[1] += 3                           # into a payload
+        elif mut == 4:
+            o[-1] -= 1
+        else:
+            o[0] = 0
+        bad.append(o)
+    for o in bad:
+        good, err = frame.decompress_batch_device(
+            ctx, d_in, len(f), n, torch.from_numpy(o.astype(np.int64)).cuda())
+        assert err is None and good == data
+
+
+# ---------------------------------------------------------------------
+# BASELINE configs 3 and 5 at reduced size, whole output against the oracle
+# ---------------------------------------------------------------------
+def test_cfg3_shape_framed_text_1024_chunks(ctx):
+    """64 MiB of the cfg3 synthetic text (bench_configs.synth_text, seeded) =
+    1024 chunks through snapmi_frame_compress: the WHOLE framed stream
+    against the oracle's restatement of write::FrameEncoder, then decoded with
+    the side index, without it, and through the streaming FrameDecoder."""
+    import bench_configs as BC
+    from rust_snappy_amd import frame
+    dev = torch.device("cuda", 0)
+    text = BC.synth_text(dev, 64 << 20)
+    out, flen, index = frame.compress_device(ctx, text, want_index=True)
+    got = out[:flen].cpu().numpy().tobytes()
+    host = text.cpu().numpy().tobytes()
+    want = O.frame_compress(host)
+    assert got == want
+    assert index.numel() - 1 == 1024
+    for idx in (index, None):
+        back, m = frame.decompress_device(ctx, out, flen, index=idx)
+        assert m == len(host) and torch.equal(back[:m], text)
+    dec = frame.FrameDecoder(io.BytesIO(got), ctx, batch_bytes=8 << 20)
+    assert dec.read_to_end() == host
+
+
+def test_cfg5_shape_jpeg_through_the_frame_layer(ctx):
+    """fireworks.jpeg tiled to ~31 MiB through the frame layer: every chunk
+    takes the Uncompressed branch of compress_frame (src/frame.rs:85) at
+    scale - 472 stored chunks, byte-identical to the oracle - plus a stream
+    that alternates stored and compressed chunks."""
+    from rust_snappy_amd import frame
+    jpg = (O.CORPUS / "fireworks.jpeg").read_bytes()
+    txt = (O.CORPUS / "alice29.txt").read_bytes()
+    data = jpg * 256
+    d = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    out, flen, index = frame.compress_device(ctx, d, want_index=True)
+    got = out[:flen].cpu().numpy().tobytes()
+    assert got == O.frame_compress(data)
+    idx = index.cpu().numpy()
+    types = [got[int(o)] for o in idx[:-1]]
+    assert len(types) == (len(data) + 65535) // 65536 and set(types) == {1}
+    back, m = frame.decompress_device(ctx, out, flen, index=index)
+    assert m == len(data) and torch.equal(back[:m], d)
+    mixed = (jpg[:65536] + txt[:65536]) * 40 + jpg[:1000]
+    f = framed(ctx, mixed)
+    assert f == O.frame_compress(mixed)
+    offs = frame.index_host(f)
+    assert {f[int(o)] for o in offs[:-1]} == {0, 1}
+    assert frame.FrameDecoder(io.BytesIO(f), ctx).read_to_end() == mixed
+    # the raw path of cfg5: the jpeg as independent raw streams
+    from test_gpu_parity import gpu_compress, gpu_decompress
+    comp = gpu_compress(ctx, [jpg] * 64)
+    assert all(c == O.compress(jpg) for c in comp)
+    outs, errs = gpu_decompress(ctx, comp)
+    assert all(o == jpg for o in outs) and all(e[0] == 0 for e in errs)

@@ -414,3 +414,55 @@ def test_scalar_decompress_uses_long_stream_path(ctx):
     data = b"".join(d for _, d in O.corpus_round()) * 2
     dec = R.raw.Decoder(ctx=ctx)
     assert dec.decompress_vec(O.compress(data)) == data
+
+
+def _lane_ctx(**opts):
+    import rust_snappy_amd as R
+    c = R.raw.Context(0)
+    c.set_option("compress_mode", 1)
+    c.set_option("lane_min_blocks", 1)
+    for k, v in opts.items():
+        c.set_option(k, v)
+    return c
+
+
+def test_lane_table_epoch_wrap(built):
+    """The lane kernel never zeroes its HBM hash tables: entries carry a
+    16-bit epoch and a lane bumps its epoch per block.  After 65 535 blocks on
+    one lane the epoch wraps: the table is really cleared and the epoch
+    restarts at 1 (snapmi_compress.hip, `if (epoch == 0)`).  Epochs persist in
+    the context, so a long-lived context gets there.  The option
+    lane_epoch_preset starts every lane shortly before the wrap; stale entries
+    of epochs 1, 2, ... left by the earlier batch must not come back to life
+    after it.  One wavefront (64 lanes) for ~300 blocks: about five blocks per
+    lane in one launch, across the wrap."""
+    rnd = O.corpus_round()
+    streams = [d for _, d in rnd] * 6                    # 300 blocks
+    want = [O.compress(d) for _, d in rnd] * 6
+    for preset in (0xFFFD, 0xFFFE, 0xFFFF):
+        c = _lane_ctx(lane_max_waves=1)
+        assert gpu_compress(c, streams) == want          # epochs 1..5 in use
+        c.set_option("lane_epoch_preset", preset)
+        assert gpu_compress(c, streams) == want, hex(preset)
+        assert gpu_compress(c, streams[::-1]) == want[::-1], hex(preset)
+        c.close()
+    # the same across launches (one block per lane and launch, segments of 64)
+    c = _lane_ctx(lane_segment_blocks=64)
+    assert gpu_compress(c, streams) == want
+    c.set_option("lane_epoch_preset", 0xFFFE)
+    assert gpu_compress(c, streams) == want
+    c.close()
+
+
+def test_compress_without_lds_atomic_order(built):
+    """A context whose LDS-atomic-order self-check failed (forced here) must
+    not launch the wavefront-per-block kernel: small batches then go to the
+    lane kernel and still give the reference's bytes."""
+    import rust_snappy_amd as R
+    c = R.raw.Context(0)
+    c.set_option("lds_order_ok", 0)
+    ins = [d for _, d in O.corpus_round()] + random_inputs(11, 60)
+    got = gpu_compress(c, ins)
+    for d, g in zip(ins, got):
+        assert g == O.compress(d), len(d)
+    c.close()
