@@ -104,6 +104,9 @@ int snapmi_ctx_create(int device, void *hip_stream, snapmi_ctx **out);
 void snapmi_ctx_destroy(snapmi_ctx *ctx);
 /* Message for the last SNAPMI_E_DEVICE / SNAPMI_E_ARGUMENT on this ctx. */
 const char *snapmi_last_error(const snapmi_ctx *ctx);
+/* "ms ms ..." of the placement probe for every candidate region of the last
+ * lane-table allocation ("" when lane_table_tries is 1). */
+const char *snapmi_table_probe_log(const snapmi_ctx *ctx);
 /* hipStream_t the context launches on (for event timing by the caller). */
 void *snapmi_ctx_stream(const snapmi_ctx *ctx);
 /* "snapmi <version> gfx950" */
@@ -121,7 +124,12 @@ const char *snapmi_version(void);
  *                          spread over up to 4x their size, within a third of
  *                          the free device memory (HBM sustains more random
  *                          accesses that way); 0: packed (25 GB at most)
+ *   "lane_table_tries"     placements of the lane tables that are timed
+ *                          (k_probe_tables) before the fastest is kept, when
+ *                          a context first allocates them
  * Test knobs (results still never depend on them):
+ *   "lane_tables_renew"    1: free the lane tables now; the next large batch
+ *                          allocates (and places) new ones
  *   "lane_max_waves"       cap on the lane kernel's wavefronts (0 = none), so
  *                          a small batch puts several blocks on one lane
  *   "lane_epoch_preset"    0..65535: every lane's hash-table epoch is set to

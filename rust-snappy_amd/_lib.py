@@ -41,6 +41,7 @@ SYMBOLS = [
     ("snapmi_ctx_create", C.c_int, [C.c_int, _P, C.POINTER(_P)]),
     ("snapmi_ctx_destroy", None, [_P]),
     ("snapmi_last_error", C.c_char_p, [_P]),
+    ("snapmi_table_probe_log", C.c_char_p, [_P]),
     ("snapmi_ctx_stream", _P, [_P]),
     ("snapmi_version", C.c_char_p, []),
     ("snapmi_ctx_set_option", C.c_int, [_P, C.c_char_p, C.c_int64]),

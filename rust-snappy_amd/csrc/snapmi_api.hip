@@ -219,7 +219,22 @@ int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value)
     else if (strcmp(name, "lane_max_waves") == 0 && value >= 0 &&
              value <= 0x7FFFFFFF)
         ctx->lane_max_waves = (uint32_t)value;
-    else if (strcmp(name, "lane_epoch_preset") == 0 && value >= -1 &&
+    else if (strcmp(name, "lane_table_tries") == 0 && value >= 1 &&
+             value <= 16)
+        ctx->lane_table_tries = (uint32_t)value;
+    else if (strcmp(name, "lane_table_probe") == 0 && value >= 0 &&
+             value <= 1)
+        ctx->lane_table_probe = value != 0; // time the placement even if 1 try
+    else if (strcmp(name, "lane_tables_renew") == 0 && value == 1) {
+        // experiment knob: drop the tables so the next launch places new ones
+        if (ctx->lane_tables.p) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            HIP_TRY(ctx, hipFree(ctx->lane_tables.p));
+            ctx->lane_tables.p = nullptr;
+            ctx->lane_tables.cap = 0;
+            ctx->n_lanes = 0;
+        }
+    } else if (strcmp(name, "lane_epoch_preset") == 0 && value >= -1 &&
              value <= 0xFFFF)
         ctx->lane_epoch_preset = value;
     else if (strcmp(name, "lds_order_ok") == 0 && value >= 0 && value <= 1)
@@ -227,6 +242,11 @@ int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value)
     else
         return fail_ctx(ctx, SNAPMI_E_ARGUMENT, "unknown option %s", name);
     return SNAPMI_OK;
+}
+
+const char *snapmi_table_probe_log(const snapmi_ctx *ctx)
+{
+    return ctx ? ctx->probe_log.c_str() : "";
 }
 
 const char *snapmi_last_error(const snapmi_ctx *ctx)
@@ -405,7 +425,11 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                 size_t free_b = 0, total_b = 0;
                 HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
                 free_b += ctx->lane_tables.cap; // about to be released
-                stride = free_b / 3 / lanes / 4096 * 4096;
+                // (a third; a quarter when several placements are tried,
+                // so that three regions fit while one is being chosen)
+                stride = free_b /
+                         (ctx->lane_table_tries > 1 && lanes >= 16384 ? 4 : 3) /
+                         lanes / 4096 * 4096;
                 if (stride > 4 * tbytes)
                     stride = 4 * tbytes;
                 if (stride < tbytes)
@@ -418,14 +442,80 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                 ctx->lane_tables.cap = 0;
                 ctx->n_lanes = 0;
             }
-            HIP_TRY(ctx, hipMalloc(&ctx->lane_tables.p, (size_t)lanes * stride));
-            ctx->lane_tables.cap = (size_t)lanes * stride;
-            ctx->lane_stride = stride / 16;
             if ((rc = reserve(ctx, ctx->lane_epochs,
                               (size_t)lanes * sizeof(uint32_t))))
                 return rc;
-            HIP_TRY(ctx, hipMemset2DAsync(ctx->lane_tables.p, stride, 0,
-                                          tbytes, lanes, ctx->stream));
+            // WHERE in HBM the tables land decides 10-25 % of the kernel's
+            // duration (profiles/r2_placement_probe.txt: 112-144 ms for the
+            // same launch on contexts created one after the other in one
+            // process).  The placement cannot be requested, but it can be
+            // measured: up to lane_table_tries regions are allocated - the
+            // best one so far and the last loser stay allocated meanwhile, so
+            // every new region is a different piece of memory - each is timed
+            // with k_probe_tables (the kernel's own access pattern: dependent
+            // random 16-byte read + write per lane), and the fastest is kept.
+            const size_t bytes = (size_t)lanes * stride;
+            void *best = nullptr, *loser = nullptr;
+            float best_ms = 0;
+            ctx->probe_log.clear();
+            // (only worth it for a launch that fills the chip: a small
+            // batch gets a handful of tables and no measurable placement)
+            const uint32_t tries =
+                lanes >= 16384 && ctx->lane_table_tries
+                    ? ctx->lane_table_tries : 1;
+            for (uint32_t t = 0; t < tries; t++) {
+                void *cand = nullptr;
+                if (hipMalloc(&cand, bytes) != hipSuccess) {
+                    (void)hipGetLastError();
+                    break; // no room for another candidate: keep the best
+                }
+                if (loser) {
+                    HIP_TRY(ctx, hipFree(loser));
+                    loser = nullptr;
+                }
+                HIP_TRY(ctx, hipMemset2DAsync(cand, stride, 0, tbytes, lanes,
+                                              ctx->stream));
+                float ms = 0;
+                if (tries > 1 || ctx->lane_table_probe) {
+                    hipLaunchKernelGGL(k_probe_tables, dim3(lanes / 64),
+                                       dim3(64), 0, ctx->stream,
+                                       (unsigned long long *)cand,
+                                       (unsigned long long)(stride / 16), 64u);
+                    HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+                    hipLaunchKernelGGL(k_probe_tables, dim3(lanes / 64),
+                                       dim3(64), 0, ctx->stream,
+                                       (unsigned long long *)cand,
+                                       (unsigned long long)(stride / 16),
+                                       768u);
+                    HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+                    HIP_TRY(ctx, hipEventSynchronize(ctx->ev[5]));
+                    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[4],
+                                                     ctx->ev[5]));
+                    HIP_TRY(ctx, hipMemset2DAsync(cand, stride, 0, tbytes,
+                                                  lanes, ctx->stream));
+                    char buf[32];
+                    snprintf(buf, sizeof buf, "%s%.2f", t ? " " : "", ms);
+                    ctx->probe_log += buf;
+                }
+                if (!best || ms < best_ms) {
+                    loser = best;
+                    best = cand;
+                    best_ms = ms;
+                } else {
+                    loser = cand;
+                }
+            }
+            if (loser) {
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                HIP_TRY(ctx, hipFree(loser));
+            }
+            if (!best)
+                return fail_ctx(ctx, SNAPMI_E_DEVICE,
+                                "hipMalloc of %zu bytes of lane tables failed",
+                                bytes);
+            ctx->lane_tables.p = best;
+            ctx->lane_tables.cap = bytes;
+            ctx->lane_stride = stride / 16;
             HIP_TRY(ctx, hipMemsetAsync(ctx->lane_epochs.p, 0,
                                         (size_t)lanes * 4, ctx->stream));
             ctx->n_lanes = lanes;

@@ -641,6 +641,32 @@ __global__ __launch_bounds__(64) void k_probe_lds_order(uint32_t *bad)
 }
 
 // ---------------------------------------------------------------------
+// Placement probe for the lane tables (snapmi_api.hip, lane_table_tries):
+// the access pattern of k_match_blocks' probe rounds - every lane a chain of
+// dependent random 16-byte reads, each followed by a write to the same
+// entry, in its own 256 KiB table - without any of the parse.  Its duration
+// on a candidate region ranks that region for the real kernel.  The caller
+// zeroes the tables afterwards.
+// ---------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_probe_tables(unsigned long long *tables,
+                                                     unsigned long long stride,
+                                                     uint32_t steps)
+{
+    typedef __attribute__((address_space(1))) u32x4 g_u32x4;
+    const uint32_t gid = blockIdx.x * 64 + threadIdx.x;
+    g_u32x4 *t = (g_u32x4 *)tables + (uint64_t)gid * stride;
+    uint32_t state = gid * 2654435761u + 12345u;
+    for (uint32_t i = 0; i < steps; i++) {
+        const uint32_t h = (state * 0x1E35A7BDu) >> 18;
+        const u32x4 e = t[h];
+        t[h] = (u32x4){state, i, h, gid};
+        state = state * 1664525u + (e.x ^ e.y ^ e.z ^ e.w) + 1013904223u;
+    }
+    if (state == 0x12345678u) // keep the chain alive
+        t[0] = (u32x4){state, 0, 0, 0};
+}
+
+// ---------------------------------------------------------------------
 // K1: persistent workgroups of five wavefronts, one 32 KiB table each.
 // ---------------------------------------------------------------------
 __global__ __launch_bounds__(kCompressWaves * 64) void k_compress_blocks(

@@ -53,6 +53,11 @@ struct snapmi_ctx {
     uint32_t lane_segment_blocks = 262144;
     uint32_t lane_waves_per_cu = 6; // 24 KiB of LDS per wave
     uint32_t lane_max_waves = 0;    // test knob: cap on lane-kernel waves (0 = none)
+    // placements of the lane tables that are timed before one is kept
+    // (default 6 for a full-size launch: profiles/r2_placement_probe2.txt)
+    uint32_t lane_table_tries = 6;
+    bool lane_table_probe = false; // experiment knob: probe even with 1 try
+    std::string probe_log;          // k_probe_tables ms of every candidate
     // test knob: every lane's table epoch is set to this value before the
     // next lane-kernel launch (-1 = leave the epochs alone); lets a test
     // reach the 16-bit epoch wrap without 65 535 blocks per lane

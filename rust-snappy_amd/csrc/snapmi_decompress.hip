@@ -679,10 +679,16 @@ __global__ __launch_bounds__(64) void k_decompress_streams(DecompressArgs a)
 // ---------------------------------------------------------------------
 namespace {
 constexpr unsigned long long kNone = ~0ull;
-// k_stream_scan follows a chain at most this far behind its segment's end;
-// streams of the usual encoders land on a tabulated offset within a few
-// elements (a literal is at most 65536 bytes in their output)
-constexpr uint64_t kScanOverrun = 4 * 65536 + 2 * kSeg;
+// k_stream_scan follows a chain at most this many elements behind its
+// segment's end.  Compressible data lands on a tabulated offset (within 64
+// bytes of a 4 KiB boundary) at the next boundary unless an element of 64+
+// encoded bytes jumps over it, which costs a segment of small elements
+// (~1 300 hops of 3 bytes) until the next chance; incompressible data
+// (64 KiB literals) lands with probability 1/64 per element.  8 192 hops
+// cover several misses in a row and all but (63/64)^8192 of the literal
+// walks, and bound what a crafted stream can cost to 128 hops per input
+// byte (it was quadratic in the input length without a bound).
+constexpr uint32_t kScanOverrun = 8192;
 
 typedef unsigned long long su64x2 __attribute__((ext_vector_type(2)));
 
@@ -897,12 +903,12 @@ __global__ __launch_bounds__(64) void k_stream_scan(StreamArgs a)
     // through elements itself.
     // The walk past the segment's end is bounded (a crafted stream whose
     // elements all end 64+ bytes off a segment boundary would otherwise make
-    // every thread walk to the end of the input): past kScanOverrun bytes the
-    // entry is left as "cannot follow", and whoever needs it sets meta[2] -
-    // the sequential decoder then owns the stream.
-    const uint64_t giveup = end + kScanOverrun;
+    // every thread walk to the end of the input): after kScanOverrun
+    // elements the entry is left as "cannot follow", and whoever needs it
+    // sets meta[2] - the sequential decoder then owns the stream.
+    uint32_t over = 0; // elements hopped behind the segment's end
     while (ok && p < a.in_len && (p < end || (p & (kSeg - 1)) >= kWave)) {
-        if (p >= giveup) {
+        if (p >= end && ++over > kScanOverrun) {
             ok = false;
             break;
         }

@@ -71,6 +71,8 @@ struct DecompressArgs {
 };
 
 __global__ void k_probe_lds_order(uint32_t *bad);
+__global__ void k_probe_tables(unsigned long long *tables,
+                               unsigned long long stride, uint32_t steps);
 __global__ void k_plan_compress(CompressArgs a);
 __global__ void k_compress_blocks(CompressArgs a);
 __global__ void k_match_blocks(CompressArgs a);

@@ -5,6 +5,7 @@ import io
 import random
 import struct
 
+import numpy as np
 import pytest
 import torch
 
