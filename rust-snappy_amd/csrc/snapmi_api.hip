@@ -104,6 +104,8 @@ int snapmi_ctx_create(int device, void *hip_stream, snapmi_ctx **out)
             const long v = atol(e);
             ctx->lane_min_blocks = (uint32_t)(v < 1 ? 1 : v);
         }
+        if (const char *e = getenv("SNAPMI_DECODE_KERNEL"))
+            ctx->decode_kernel = atoi(e) == 1 ? 1 : 2;
         if (const char *m = getenv("SNAPMI_COMPRESS"))
             ctx->compress_mode = strcmp(m, "waves") == 0
                                      ? 0
@@ -219,6 +221,8 @@ int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value)
     else if (strcmp(name, "lane_max_waves") == 0 && value >= 0 &&
              value <= 0x7FFFFFFF)
         ctx->lane_max_waves = (uint32_t)value;
+    else if (strcmp(name, "decode_kernel") == 0 && value >= 1 && value <= 2)
+        ctx->decode_kernel = (int)value;
     else if (strcmp(name, "lane_table_tries") == 0 && value >= 1 &&
              value <= 16)
         ctx->lane_table_tries = (uint32_t)value;
@@ -651,8 +655,12 @@ int launch_decompress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], s));
     hipLaunchKernelGGL(k_plan_decompress, dim3(1), dim3(1024), 0, s, a);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], s));
-    hipLaunchKernelGGL(k_decompress_streams, dim3((uint32_t)n), dim3(64), 0,
-                       s, a);
+    if (ctx->decode_kernel == 1)
+        hipLaunchKernelGGL(k_decompress_streams, dim3((uint32_t)n), dim3(64),
+                           0, s, a);
+    else
+        hipLaunchKernelGGL(k_decompress_streams2, dim3((uint32_t)n), dim3(64),
+                           0, s, a);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], s));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[3], s));
     HIP_TRY(ctx, hipGetLastError());

@@ -37,6 +37,9 @@ struct snapmi_ctx {
     // two-ended ticket (no faster: the wavefront kernel takes whole CUs' LDS
     // away from the lanes' input windows; kept as a cross-check)
     int compress_mode = 1;
+    // 2: element-major decoder k_decompress_streams2 (default); 1: the
+    // first-generation byte-per-lane kernel, kept as a cross-check
+    int decode_kernel = 2;
     hipStream_t stream2 = nullptr; // the wavefront kernel's side stream
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // staging for the host-pointer (scalar) entry points

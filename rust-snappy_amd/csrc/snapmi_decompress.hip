@@ -252,6 +252,11 @@ __device__ __forceinline__ uint64_t ld64g(gcptr src, uint64_t pos,
     return v;
 }
 
+// 16 bytes as two qwords
+struct B16x {
+    uint64_t lo, hi;
+};
+
 #ifdef SNAPMI_PROFILE
 #define TICK(i)                                                               \
     do {                                                                      \
@@ -649,6 +654,485 @@ __global__ __launch_bounds__(64) void k_decompress_streams(DecompressArgs a)
         atomicAdd(&a.prof[12], (unsigned long long)n_elem);
         atomicAdd(&a.prof[13], (unsigned long long)n_fence);
         atomicAdd(&a.prof[14], (unsigned long long)n_res);
+        atomicAdd(&a.prof[15], 1ull);
+    }
+#endif
+    if (d != dst_len)
+        SNAPMI_FAIL(SNAPMI_HEADER_MISMATCH, dst_len, d, 0);
+    if (lane == 0) {
+        set_error(a.errs, st, SNAPMI_OK, 0, 0, 0);
+        a.out_lens[st] = dst_len;
+    }
+}
+
+// ---------------------------------------------------------------------
+// K2 (second generation): one wavefront per raw stream, element-major.
+//
+// The first-generation kernel above produces output one BYTE per lane and
+// pass; two thirds of its instructions find, for every output byte, the
+// element it belongs to.  Here a lane that sits on an element's first
+// compressed byte copies that whole element itself:
+//
+//   1. every lane decodes the element that would start at its byte of the
+//      64-byte window (as before), and loads 16 literal bytes speculatively;
+//   2. the real element starts are the orbit of lane 0 under "next element":
+//      five rounds of mask doubling (reach |= reach[next]; next = next[next]),
+//      three ds_bpermute each, leave the 64-bit set in lane 0 - no compaction,
+//      no per-element gather, the records stay where they were decoded;
+//   3. a DPP scan of the output lengths over the start lanes places every
+//      element; the window is cut after 2048 output bytes (kWinMax), so a
+//      4 KiB ring of recent output in LDS always keeps 2 KiB of history that
+//      the window's own writes cannot touch;
+//   4. ONE lane-parallel copy step: every element whose source is complete
+//      before the window (literals; copies from in front of it) is copied by
+//      its lane, 16 bytes per trip - source: the speculative literal bytes,
+//      the ring (two unaligned ds_read_b64), or HBM for what the ring no
+//      longer holds - and written to the ring with exactly its length
+//      (8 + 4 + 2 + 1 decomposition, unaligned DS stores);
+//   5. the few elements that read the window's own output (1.3 per window on
+//      the corpus) or repeat a short period are swept in stream order, each
+//      by the whole wave (lane k = byte k, k mod offset for overlaps);
+//   6. the ring goes to HBM 256 bytes at a time (one dword per lane), so
+//      global stores are whole aligned lines instead of 64 byte stores.
+//
+// Everything irregular - a failed check, an element cut off by the end of
+// the input - stops the wide path at a window boundary: the ring is stored
+// and the sequential decoder above finishes the stream from (s, d) with the
+// reference's exact error.  tests/model_decoder.py restates this algorithm
+// lane by lane on the CPU (test infrastructure, not used here).
+// ---------------------------------------------------------------------
+namespace {
+constexpr uint32_t kRing2 = 4096;
+constexpr uint32_t kWinMax = 2048;
+typedef __attribute__((address_space(3))) uint8_t l_u8;
+typedef __attribute__((address_space(3))) uint16_t l_u16x;
+typedef __attribute__((address_space(3))) uint32_t l_u32;
+typedef __attribute__((address_space(3))) uint64_t l_u64;
+
+__device__ __forceinline__ uint32_t lds_ld32(const l_u8 *p)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+__device__ __forceinline__ uint64_t lds_ld64(const l_u8 *p)
+{
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+__device__ __forceinline__ void lds_st64(l_u8 *p, uint64_t v)
+{
+    __builtin_memcpy(p, &v, 8);
+}
+__device__ __forceinline__ void lds_st32(l_u8 *p, uint32_t v)
+{
+    __builtin_memcpy(p, &v, 4);
+}
+__device__ __forceinline__ void lds_st16(l_u8 *p, uint16_t v)
+{
+    __builtin_memcpy(p, &v, 2);
+}
+
+struct Ring2 {
+    l_u8 *rg;       // kRing2 bytes + a 16-byte mirror of its first 16
+    gptr dst;
+    uint32_t lane;
+    uint32_t gflush; // dst[0, gflush) has been stored
+    uint32_t fenced; // ... and those stores are known to be complete
+
+    // ring[0,16) again behind the end: unaligned reads may run past it
+    __device__ __forceinline__ void mirror() const
+    {
+        if (lane < 4)
+            lds_st32(rg + kRing2 + 4 * lane, lds_ld32(rg + 4 * lane));
+    }
+    // whole 256-byte pieces of dst[gflush, d), one dword per lane
+    __device__ __forceinline__ void flush_chunks(uint32_t d)
+    {
+        while (gflush + 256 <= d) {
+            const uint32_t p = gflush + 4 * lane;
+            st32u(dst + p, lds_ld32(rg + (p & (kRing2 - 1))));
+            gflush += 256;
+        }
+    }
+    // everything up to `upto`, bytewise (before a long literal, at the end,
+    // when the sequential decoder takes over)
+    __device__ __forceinline__ void flush_partial(uint32_t upto)
+    {
+        for (uint32_t p = gflush + lane; p < upto; p += kWave)
+            dst[p] = rg[p & (kRing2 - 1)];
+        gflush = upto;
+    }
+    // a far source must be a completed store
+    __device__ __forceinline__ void fence_for(uint32_t limit)
+    {
+        if (limit > fenced) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            fenced = gflush;
+        }
+    }
+};
+} // namespace
+
+// 8 waves per SIMD (64 VGPRs, 5 KiB of LDS each): the kernel waits on a chain
+// of LDS / HBM round trips per window, and two more waves to switch to are
+// worth more than the 9 spilled dwords (36.0 -> 32.2 ms at cfg2).
+__attribute__((amdgpu_waves_per_eu(8, 8)))
+__global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t ring_mem[kRing2 + 16];
+    const uint32_t lane = threadIdx.x;
+    if (a.gate && uni64(*a.gate) != a.gate_value)
+        return;
+    const uint64_t st = a.order[blockIdx.x];
+    gcptr in = (gcptr)a.in_ptrs[st];
+    const uint64_t in_len = a.in_lens[st];
+    const bool piece = a.modes && a.modes[st] == 2;
+
+    if (a.modes && a.modes[st] == 1) {
+        // stored frame chunk (reference src/read.rs:173-199): the payload is
+        // the data; 256 bytes per instruction
+        const uint64_t cap0 = a.out_caps[st];
+        if (in_len > cap0)
+            SNAPMI_FAIL(SNAPMI_BUFFER_TOO_SMALL, cap0, in_len, 0);
+        gptr to = (gptr)a.out_ptrs[st];
+        for (uint64_t i = 4 * lane; i + 4 <= in_len; i += 4 * kWave)
+            st32u(to + i, ld32u(in + i));
+        const uint64_t t = in_len & ~3ull;
+        if (lane < (in_len & 3))
+            to[t + lane] = in[t + lane];
+        if (lane == 0) {
+            set_error(a.errs, st, SNAPMI_OK, 0, 0, 0);
+            a.out_lens[st] = in_len;
+        }
+        return;
+    }
+    // reference Decoder::decompress, src/decompress.rs:75-95
+    uint32_t hdr = 0;
+    uint64_t dst_len = 0;
+    if (piece) { // elements [in, in + in_len) produce exactly out_caps bytes
+        dst_len = a.out_caps[st];
+    } else {
+        if (in_len == 0)
+            SNAPMI_FAIL(SNAPMI_EMPTY, 0, 0, 0);
+        snapmi_error *e = lane == 0 ? a.errs : nullptr;
+        if (read_header(in, in_len, &hdr, &dst_len, e, st) != SNAPMI_OK) {
+            if (lane == 0)
+                a.out_lens[st] = 0;
+            return;
+        }
+    }
+    hdr = uni(hdr);
+    dst_len = uni64(dst_len);
+    const uint64_t cap = a.out_caps[st];
+    if (dst_len > cap)
+        SNAPMI_FAIL(SNAPMI_BUFFER_TOO_SMALL, cap, dst_len, 0);
+
+    gcptr src = in + hdr;
+    const uint64_t src_len = in_len - hdr;
+    gptr dst = (gptr)a.out_ptrs[st];
+
+    uint64_t s = 0;       // position in src (uniform)
+    uint32_t d = 0;       // position in dst (uniform; dst_len < 2^32)
+    uint32_t ring_lo = 0; // the ring holds dst[max(ring_lo, d - 4096), d)
+    Ring2 R;
+    R.rg = (l_u8 *)ring_mem;
+    R.dst = dst;
+    R.lane = lane;
+    R.gflush = 0;
+    R.fenced = 0;
+    l_u8 *const rg = R.rg;
+
+    // streams too short for the 8-byte window loads go to the sequential
+    // decoder at once; so does the first failed check
+    bool irregular = src_len < 8;
+    uint64_t w = irregular ? 0 : ld64c(src, lane, src_len); // src[s+lane..]
+#ifdef SNAPMI_PROFILE
+    uint64_t n_win = 0, n_elem = 0, n_dep = 0, n_fence = 0, n_far = 0,
+             n_trip = 0;
+#endif
+    while (!irregular && s < src_len) {
+        COUNT(n_win);
+        // bytes of input left, as far as this window can see (<= 2^20)
+        const uint32_t rem =
+            src_len - s < (1u << 20) ? (uint32_t)(src_len - s) : 1u << 20;
+        // ---- 1. the element that would start at src[s + lane] ------------
+        const uint32_t tag = (uint32_t)w & 0xFF;
+        const uint32_t b14 = (uint32_t)(w >> 8); // the 4 bytes after the tag
+        const uint32_t type = tag & 3, n6 = tag >> 2;
+        const bool is_lit = type == 0;
+        // literal (reference read_literal, src/decompress.rs:161-228)
+        const uint32_t lnb = n6 >= 60 ? n6 - 59 : 0; // extra length bytes
+        const uint32_t lmask = lnb == 4 ? 0xFFFFFFFFu : ((1u << (8 * lnb)) - 1);
+        const uint32_t lraw = lnb ? (b14 & lmask) : n6; // length - 1
+        const uint32_t hd = 1 + lnb;
+        const bool lng = is_lit && lraw >= 64; // > 64 bytes: not in a window
+        // copy (reference TagEntry::offset / read_copy, :233-250,433-474)
+        const uint32_t cnb = type == 1 ? 1 : (type == 2 ? 2 : 4);
+        const uint32_t clen = type == 1 ? 4 + (n6 & 7) : 1 + n6;
+        const uint32_t off = type == 1 ? (((tag >> 5) << 8) | (b14 & 0xFF))
+                                       : (type == 2 ? (b14 & 0xFFFF) : b14);
+        const uint32_t olen = is_lit ? lraw + 1 : clen;      // if !lng
+        const uint32_t enc = is_lit ? hd + lraw + 1 : 1 + cnb; // if !lng
+        // the whole element lies inside the input (:189-217 src side, CopyRead)
+        // (an extended literal length is read as 4 bytes: :189-198)
+        const bool fits = lane < rem && !lng && enc <= rem - lane &&
+                          !(is_lit && lnb && lane + 5 > rem);
+        // 16 literal bytes, speculatively (only windows well inside the input)
+        const bool inner = rem >= 64 + 5 + 16;
+        B16x lit16;
+        lit16.lo = lit16.hi = 0;
+        if (inner) {
+            __builtin_memcpy(&lit16, src + s + lane + hd, 16);
+        }
+        // ---- 2. element starts: the orbit of lane 0 under "next" ----------
+        uint32_t nk = (lng || lane >= rem) ? kWave
+                                           : (lane + enc < kWave ? lane + enc
+                                                                 : kWave);
+        uint32_t rlo = lane < 32 ? 1u << lane : 0;
+        uint32_t rhi = lane >= 32 ? 1u << (lane - 32) : 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 5; k++) {
+            const int sel = (int)((nk & 63) << 2);
+            const uint32_t glo =
+                (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)rlo);
+            const uint32_t ghi =
+                (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)rhi);
+            const uint32_t gnk =
+                (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)nk);
+            const bool ok = nk < kWave;
+            rlo |= ok ? glo : 0;
+            rhi |= ok ? ghi : 0;
+            nk = ok ? gnk : kWave;
+            if (k >= 2 && rdlane(nk, 0) >= kWave)
+                break; // lane 0's chain has left the window
+        }
+        const uint64_t S = ((uint64_t)rdlane(rhi, 0) << 32) | rdlane(rlo, 0);
+        const bool is_start = (S >> lane) & 1;
+        // ---- 3. placement, window cut, checks ------------------------------
+        const bool elem = is_start && fits;
+        const uint32_t o = elem ? olen : 0;
+        const uint32_t incl = wave_inclusive_add(o);
+        // the window ends in front of the first start that is a long literal
+        // or does not fit, and after kWinMax output bytes
+        const uint64_t stop = __ballot(is_start && !fits);
+        const uint64_t below =
+            stop ? ((1ull << __builtin_ctzll(stop)) - 1) : ~0ull;
+        const uint64_t K = __ballot(elem && incl <= kWinMax) & below;
+        if (K == 0) {
+            // lane 0 is a literal of more than 64 bytes: 256 B per instruction
+            const uint32_t lng0 = rdlane(lng ? 1u : 0u, 0);
+            const uint64_t Lq = (uint64_t)rdlane(lraw, 0) + 1;
+            const uint32_t h0 = rdlane(hd, 0);
+            if (!lng0 || rem < h0 || src_len - (s + h0) < Lq ||
+                dst_len - d < Lq) {
+                irregular = true; // the sequential decoder names the error
+                break;
+            }
+            R.flush_partial(d);
+            gcptr from = src + s + h0;
+            gptr to = dst + d;
+            for (uint64_t i = 4 * lane; i + 4 <= Lq; i += 4 * kWave)
+                st32u(to + i, ld32u(from + i));
+            const uint64_t t = Lq & ~3ull;
+            if (lane < (Lq & 3))
+                to[t + lane] = from[t + lane];
+            s += h0 + Lq;
+            d += (uint32_t)Lq;
+            R.gflush = d;
+            ring_lo = d; // these bytes are not in the ring
+            if (s < src_len)
+                w = ld64c(src, s + lane, src_len);
+            continue;
+        }
+        const bool keep = (K >> lane) & 1;
+        const uint32_t last = 63 - (uint32_t)__builtin_clzll(K);
+        const uint32_t W = rdlane(incl, last);         // output of the window
+        const uint32_t cur = last + rdlane(enc, last); // input consumed
+        const uint32_t dstp = d + (incl - o);          // element's position
+        // reference checks :209-217 (dst side), :245-250, :327-332
+        const bool cpy = keep && !is_lit;
+        if ((uint64_t)d + W > dst_len ||
+            __ballot(cpy && (off == 0 || off > dstp)) != 0) {
+            irregular = true;
+            break;
+        }
+#ifdef SNAPMI_PROFILE
+        n_elem += __builtin_popcountll(K);
+#endif
+        // next window's bytes: issued now, consumed after the expand
+        const uint64_t w_next = ld64c(src, s + cur + lane, src_len);
+
+        // ---- 4. the lane-parallel copy step --------------------------------
+        const uint32_t q = dstp - off;               // copy source (if cpy)
+        const uint32_t n = olen < off ? olen : off;  // bytes a copy reads
+        const uint32_t dW = d + W;
+        uint32_t safe_lo = dW > kRing2 ? dW - kRing2 : 0;
+        safe_lo = safe_lo > ring_lo ? safe_lo : ring_lo;
+        const bool ring_ok = q >= safe_lo;
+        const bool far_ok = q + n <= R.gflush;
+        // 16-byte loads from HBM must stay inside the buffers: an element
+        // that ends within 15 bytes of the input's / the output's end is
+        // left to the sweep, which moves exactly its bytes
+        const uint32_t pad = (olen + 15) & ~15u;
+        const uint32_t dst_lim =
+            dst_len < 0xFFFFFFFFull ? (uint32_t)dst_len : 0xFFFFFFFFu;
+        const bool lw =
+            keep &&
+#ifdef SNAPMI_DEC2_ONETRIP
+            olen <= 16 &&
+#endif
+            ((is_lit && inner && lane + hd + pad <= rem) ||
+             (cpy && q + n <= d &&
+              (ring_ok ? (olen <= off || off >= 16)
+                       : (far_ok && olen <= off && pad <= dst_lim - q))));
+        const bool far = lw && cpy && !ring_ok;
+        {
+            const uint64_t farm = __ballot(far);
+            if (farm) {
+#ifdef SNAPMI_PROFILE
+                n_far += __builtin_popcountll(farm);
+#endif
+                if (__ballot(far && q + n > R.fenced) != 0) {
+                    R.fence_for(0xFFFFFFFFu);
+                    COUNT(n_fence);
+                }
+            }
+#ifdef SNAPMI_DEC2_NOTRIP
+            if (0)
+#endif
+            for (uint32_t c = 0;; c += 16) {
+                const bool act = lw && c < olen;
+                if (__ballot(act) == 0)
+                    break;
+                COUNT(n_trip);
+                const uint32_t m = olen - c < 16 ? olen - c : 16;
+                // source: 16 bytes from the literal, the ring, or HBM
+                B16x v;
+                v.lo = v.hi = 0;
+                if (c == 0) {
+                    v = lit16;
+                } else if (act && is_lit) {
+                    __builtin_memcpy(&v, src + s + lane + hd + c, 16);
+                }
+                if (farm && act && far)
+                    __builtin_memcpy(&v, dst + q + c, 16);
+                if (act && cpy && ring_ok) {
+                    // (only the lanes that need it: the LDS serves a wave's
+                    // scattered unaligned reads a few lanes per cycle)
+                    v.lo = lds_ld64(rg + ((q + c) & (kRing2 - 1)));
+                    v.hi = lds_ld64(rg + ((q + c + 8) & (kRing2 - 1)));
+                }
+                // destination: exactly m bytes at the element's position
+                const uint32_t wa = (dstp + c) & (kRing2 - 1);
+                const bool strad = act && wa + m > kRing2;
+                if (act && !strad) {
+                    l_u8 *p = rg + wa;
+                    uint64_t lo = v.lo, hi = v.hi;
+                    if (m & 16) {
+                        lds_st64(p, lo);
+                        lds_st64(p + 8, hi);
+                    }
+                    if (m & 8) {
+                        lds_st64(p, lo);
+                        p += 8;
+                        lo = hi;
+                    }
+                    if (m & 4) {
+                        lds_st32(p, (uint32_t)lo);
+                        p += 4;
+                        lo >>= 32;
+                    }
+                    if (m & 2) {
+                        lds_st16(p, (uint16_t)lo);
+                        p += 2;
+                        lo >>= 16;
+                    }
+                    if (m & 1)
+                        *p = (uint8_t)lo;
+                }
+                if (__ballot(strad) != 0 && strad) {
+                    // (rare) the write wraps around the ring's end: bytewise
+                    for (uint32_t j = 0; j < m; j++) {
+                        const uint64_t part = j < 8 ? v.lo : v.hi;
+                        rg[(wa + j) & (kRing2 - 1)] =
+                            (uint8_t)(part >> (8 * (j & 7)));
+                    }
+                }
+                // a write reached ring[0,16): mirror it behind the end
+                if (__ballot(act && (wa < 16 || strad)) != 0)
+                    R.mirror();
+            }
+        }
+        // ---- 5. the sweep: elements that depend on this window -------------
+        uint64_t dep = K & ~__ballot(lw);
+#ifdef SNAPMI_DEC2_NOSWEEP
+        dep = 0;
+#endif
+        while (dep) {
+            COUNT(n_dep);
+            const uint32_t i = (uint32_t)__builtin_ctzll(dep);
+            dep &= dep - 1;
+            const uint32_t ni = rdlane(olen, i), di = rdlane(dstp, i);
+            uint32_t val = 0;
+            if (rdlane(is_lit ? 1u : 0u, i)) {
+                // (only windows at the very end of the input, `inner` false)
+                if (lane < ni)
+                    val = src[s + i + rdlane(hd, i) + lane];
+            } else {
+                const uint32_t qi = rdlane(q, i), oi = rdlane(off, i);
+                const uint32_t nsrc = ni < oi ? ni : oi;
+                uint32_t kk = lane;
+                if (oi < ni) { // overlapping: byte k repeats byte k mod oi
+                    const uint32_t quo = (uint32_t)(
+                        ((float)lane + 0.5f) *
+                        __builtin_amdgcn_rcpf((float)oi));
+                    kk = lane - quo * oi;
+                }
+                const bool in_ring = qi >= safe_lo;
+                if (!in_ring) {
+                    // bytes the ring has lost that are not stored yet (only
+                    // right after a long literal): store them first
+                    if (qi + nsrc > R.gflush)
+                        R.flush_partial(di);
+                    if (qi + nsrc > R.fenced) {
+                        R.fence_for(0xFFFFFFFFu);
+                        COUNT(n_fence);
+                    }
+                }
+                if (lane < ni)
+                    val = in_ring ? (uint32_t)rg[(qi + kk) & (kRing2 - 1)]
+                                  : (uint32_t)dst[qi + kk];
+            }
+            if (lane < ni)
+                rg[(di + lane) & (kRing2 - 1)] = (uint8_t)val;
+            const uint32_t wa = di & (kRing2 - 1);
+            if (wa < 16 || wa + ni > kRing2)
+                R.mirror();
+        }
+        // ---- 6. advance; whole 256-byte pieces go to HBM -------------------
+        d += W;
+        s += cur;
+        w = w_next;
+#ifndef SNAPMI_DEC2_NOFLUSH
+        R.flush_chunks(d);
+#endif
+    }
+    if (irregular) {
+        R.flush_partial(d);
+        decode_sequential(a, st, lane, src, src_len, dst, dst_len, s, d);
+        return;
+    }
+    R.flush_partial(d);
+#ifdef SNAPMI_PROFILE
+    if (lane == 0 && a.prof) {
+        atomicAdd(&a.prof[10], (unsigned long long)n_win);
+        atomicAdd(&a.prof[11], (unsigned long long)n_trip);
+        atomicAdd(&a.prof[12], (unsigned long long)n_elem);
+        atomicAdd(&a.prof[13], (unsigned long long)n_fence);
+        atomicAdd(&a.prof[14], (unsigned long long)n_dep);
+        atomicAdd(&a.prof[9], (unsigned long long)n_far);
         atomicAdd(&a.prof[15], 1ull);
     }
 #endif

@@ -131,6 +131,7 @@ __global__ void k_stream_finish(StreamArgs a);
 
 __global__ void k_plan_decompress(DecompressArgs a);
 __global__ void k_decompress_streams(DecompressArgs a);
+__global__ void k_decompress_streams2(DecompressArgs a);
 __global__ void k_decompress_len(DecompressArgs a);
 
 } // namespace snapmi

@@ -19,13 +19,17 @@ def built():
     return True
 
 
-@pytest.fixture(scope="session")
-def ctx(built):
+@pytest.fixture(scope="session", params=["dec2", "dec1"])
+def ctx(request, built):
+    """A context per decoder kernel: the element-major k_decompress_streams2
+    (default) and the first-generation byte-per-lane kernel kept as a
+    cross-check, so every decoder parity test runs through both."""
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import rust_snappy_amd as R
     c = R.raw.Context(0)
+    c.set_option("decode_kernel", {"dec2": 2, "dec1": 1}[request.param])
     yield c
     c.close()
 

@@ -284,6 +284,52 @@ def test_hw_lds_atomic_lane_order(ctx):
     assert "PASS ascending-lane order" in out, out
 
 
+def test_hw_lds_unaligned_access(built):
+    """The element-major decoder reads 8 bytes and writes 8 / 4 / 2 / 1 bytes
+    at arbitrary byte addresses of its LDS ring with single DS instructions;
+    checked bytewise on the hardware (tests/hw/lds_unaligned.hip)."""
+    import subprocess
+    from conftest import ROOT
+    exe = ROOT / "tests" / "hw" / "lds_unaligned"
+    assert exe.exists(), "run __graft_entry__.build() first"
+    out = subprocess.run([str(exe)], capture_output=True, text=True,
+                         timeout=60).stdout
+    assert "PASS unaligned DS access is bytewise" in out, out
+
+
+def test_decode_streams_that_end_at_the_allocation_end(ctx):
+    """Compressed input and decoded output both end exactly where their
+    device allocations end: the decoder's 16-byte loads (speculative literal
+    bytes, far back-references) must never touch a byte behind them."""
+    import torch
+    from rust_snappy_amd import batch, raw
+    rnd = O.corpus_round()
+    jpg, txt = rnd[2][1], rnd[6][1]
+    for data in (txt, jpg[:70000] + txt[:3000], txt[:70] + jpg[:66000],
+                 b"x" * 100 + jpg[:100], txt[:131072]):
+        comp = O.compress(data)
+        n, m = len(comp), len(data)
+        # allocations of exactly n and m bytes (torch rounds up internally;
+        # the tensors are carved from the END of bigger ones, whose last byte
+        # is the allocation's last byte for a 2 MiB multiple)
+        big_in = torch.empty(2 << 20, dtype=torch.uint8, device="cuda")
+        big_out = torch.empty(4 << 20, dtype=torch.uint8, device="cuda")
+        d_in = big_in[(2 << 20) - n:]
+        d_in.copy_(torch.frombuffer(bytearray(comp), dtype=torch.uint8))
+        d_out = big_out[(4 << 20) - m:]
+        ptr = lambda t: torch.tensor([t.data_ptr()], dtype=torch.int64,
+                                     device="cuda")
+        lens = lambda v: torch.tensor([v], dtype=torch.int64, device="cuda")
+        out_len = torch.zeros(1, dtype=torch.int64, device="cuda")
+        errs = torch.zeros(32, dtype=torch.uint8, device="cuda")
+        raw.decompress_batch(ctx, ptr(d_in), lens(n), ptr(d_out), lens(m),
+                             out_len, errs)
+        ctx.synchronize()
+        assert batch.read_errors(errs)[0][0] == 0
+        assert int(out_len.item()) == m
+        assert d_out.cpu().numpy().tobytes() == data
+
+
 def test_compress_stream_at_end_of_allocation(cctx):
     """The input ends exactly where its device allocation ends: the kernels
     may read whole cache lines, but never a line that starts behind the
