@@ -1,0 +1,147 @@
+//! `snap::Error`, `snap::Result`, `IntoInnerError`: the reference's types
+//! (src/error.rs), field for field, so that callers matching on variants keep
+//! working.  `PartialEq`/`Eq`/`Clone`/`Debug` as in the reference (:70).
+use std::fmt;
+use std::io;
+use std::result;
+
+/// `Result<T, snap::Error>`.
+pub type Result<T> = result::Result<T, Error>;
+
+/// Consuming an encoder failed to flush: the encoder and the error
+/// (reference src/error.rs:8-58).
+pub struct IntoInnerError<W> {
+    wtr: W,
+    err: io::Error,
+}
+
+impl<W> IntoInnerError<W> {
+    pub(crate) fn new(wtr: W, err: io::Error) -> IntoInnerError<W> {
+        IntoInnerError { wtr, err }
+    }
+    /// The error that made `into_inner` fail.
+    pub fn error(&self) -> &io::Error {
+        &self.err
+    }
+    /// The error, consuming `self`.
+    pub fn into_error(self) -> io::Error {
+        self.err
+    }
+    /// The writer that could not be flushed.
+    pub fn into_inner(self) -> W {
+        self.wtr
+    }
+}
+
+impl<W: std::any::Any> std::error::Error for IntoInnerError<W> {}
+
+impl<W> fmt::Display for IntoInnerError<W> {
+    fn fmt(&self, f: &mut fmt::Formatter<'_>) -> fmt::Result {
+        self.err.fmt(f)
+    }
+}
+
+impl<W> fmt::Debug for IntoInnerError<W> {
+    fn fmt(&self, f: &mut fmt::Formatter<'_>) -> fmt::Result {
+        self.err.fmt(f)
+    }
+}
+
+/// Everything that can go wrong with Snappy data (reference
+/// src/error.rs:72-180; same variants, same field names and types).
+#[derive(Clone, Debug, Eq, PartialEq)]
+#[allow(missing_docs)]
+pub enum Error {
+    TooBig { given: u64, max: u64 },
+    BufferTooSmall { given: u64, min: u64 },
+    Empty,
+    Header,
+    HeaderMismatch { expected_len: u64, got_len: u64 },
+    Literal { len: u64, src_len: u64, dst_len: u64 },
+    CopyRead { len: u64, src_len: u64 },
+    CopyWrite { len: u64, dst_len: u64 },
+    Offset { offset: u64, dst_pos: u64 },
+    StreamHeader { byte: u8 },
+    StreamHeaderMismatch { bytes: Vec<u8> },
+    UnsupportedChunkType { byte: u8 },
+    UnsupportedChunkLength { len: u64, header: bool },
+    Checksum { expected: u32, got: u32 },
+}
+
+impl From<Error> for io::Error {
+    fn from(err: Error) -> io::Error {
+        io::Error::new(io::ErrorKind::Other, err) // reference :182-186
+    }
+}
+
+impl std::error::Error for Error {}
+
+impl fmt::Display for Error {
+    fn fmt(&self, f: &mut fmt::Formatter<'_>) -> fmt::Result {
+        match *self {
+            Error::TooBig { given, max } => {
+                write!(f, "snappy: input buffer (size = {}) is larger than allowed (size = {})", given, max)
+            }
+            Error::BufferTooSmall { given, min } => {
+                write!(f, "snappy: output buffer (size = {}) is smaller than required (size = {})", given, min)
+            }
+            Error::Empty => write!(f, "snappy: corrupt input (empty)"),
+            Error::Header => write!(f, "snappy: corrupt input (invalid header)"),
+            Error::HeaderMismatch { expected_len, got_len } => write!(
+                f,
+                "snappy: corrupt input (header mismatch; expected {} decompressed bytes but got {})",
+                expected_len, got_len
+            ),
+            Error::Literal { len, src_len, dst_len } => write!(
+                f,
+                "snappy: corrupt input (expected literal read of length {}; remaining src: {}; remaining dst: {})",
+                len, src_len, dst_len
+            ),
+            Error::CopyRead { len, src_len } => write!(
+                f,
+                "snappy: corrupt input (expected copy read of length {}; remaining src: {})",
+                len, src_len
+            ),
+            Error::CopyWrite { len, dst_len } => write!(
+                f,
+                "snappy: corrupt input (expected copy write of length {}; remaining dst: {})",
+                len, dst_len
+            ),
+            Error::Offset { offset, dst_pos } => write!(
+                f,
+                "snappy: corrupt input (expected valid offset but got offset {}; dst position: {})",
+                offset, dst_pos
+            ),
+            Error::StreamHeader { byte } => write!(
+                f,
+                "snappy: corrupt input (expected stream header but got unexpected chunk type byte {})",
+                byte
+            ),
+            Error::StreamHeaderMismatch { ref bytes } => write!(
+                f,
+                "snappy: corrupt input (expected sNaPpY stream header but got {:?})",
+                bytes
+            ),
+            Error::UnsupportedChunkType { byte } => write!(
+                f,
+                "snappy: corrupt input (unsupported chunk type: {})",
+                byte
+            ),
+            Error::UnsupportedChunkLength { len, header: false } => write!(
+                f,
+                "snappy: corrupt input (unsupported chunk length: {})",
+                len
+            ),
+            Error::UnsupportedChunkLength { len, header: true } => write!(
+                f,
+                "snappy: corrupt input (invalid stream header length: {})",
+                len
+            ),
+            Error::Checksum { expected, got } => write!(
+                f,
+                "snappy: corrupt input (bad checksum; expected: {}, got: {})",
+                expected, got
+            ),
+        }
+    }
+}

@@ -1,0 +1,278 @@
+//! `snap::read::FrameDecoder` and `snap::read::FrameEncoder` (reference
+//! src/read.rs).
+//!
+//! `FrameDecoder` pulls up to `BATCH` bytes from the reader, lets
+//! `snapmi_frame_decode_host` decode every complete chunk in them in one
+//! device call (header checks, raw decode, CRC, all in the reference's order)
+//! and keeps the cut-off tail for the next round.  Bytes of the chunks in
+//! front of a bad chunk are returned before the error (reference :111-118).
+use std::cmp;
+use std::fmt;
+use std::io::{self, Read};
+
+use crate::gpu::{self, Context, Failure, SnapmiError};
+use crate::MAX_BLOCK_SIZE;
+
+const BATCH: usize = 64 << 20;
+
+/// Decompresses a Snappy frame stream while it is read (reference :37-101).
+pub struct FrameDecoder<R: io::Read> {
+    r: R,
+    ctx: Context,
+    /// Compressed bytes read but not decoded yet (src[..srce]).
+    src: Vec<u8>,
+    srce: usize,
+    /// Decoded bytes not yet handed out: dst[dsts..dste].
+    dst: Vec<u8>,
+    dsts: usize,
+    dste: usize,
+    /// An error that follows the bytes in `dst`.
+    pending: Option<io::Error>,
+    eof: bool,
+    read_stream_ident: bool,
+    /// First 10 bytes of the reference reader's scratch buffer (the
+    /// truncated-varint rule of reference :216; see include/snapmi.h).
+    stale: [u8; 10],
+}
+
+impl<R: io::Read> FrameDecoder<R> {
+    /// A new streaming decompressor reading from `rdr`.
+    pub fn new(rdr: R) -> FrameDecoder<R> {
+        FrameDecoder {
+            r: rdr,
+            ctx: Context::new(),
+            src: vec![0; BATCH],
+            srce: 0,
+            dst: vec![0; 2 * BATCH],
+            dsts: 0,
+            dste: 0,
+            pending: None,
+            eof: false,
+            read_stream_ident: false,
+            stale: [0; 10],
+        }
+    }
+
+    /// The underlying reader.
+    pub fn get_ref(&self) -> &R {
+        &self.r
+    }
+
+    /// The underlying reader, mutably.
+    pub fn get_mut(&mut self) -> &mut R {
+        &mut self.r
+    }
+
+    /// The underlying reader; undecoded input is dropped.
+    pub fn into_inner(self) -> R {
+        self.r
+    }
+
+    /// One batch: read, decode the whole chunks, keep the tail.
+    fn fill(&mut self) -> io::Result<()> {
+        loop {
+            while self.srce < self.src.len() && !self.eof {
+                let n = self.r.read(&mut self.src[self.srce..])?;
+                if n == 0 {
+                    self.eof = true;
+                }
+                self.srce += n;
+            }
+            if self.srce == 0 {
+                return Ok(()); // clean end of the stream
+            }
+            let mut flags = 0;
+            if self.read_stream_ident {
+                flags |= gpu::SNAPMI_FRAME_CONTINUATION;
+            }
+            if self.eof {
+                flags |= gpu::SNAPMI_FRAME_FINAL;
+            }
+            let (mut written, mut consumed) = (0usize, 0usize);
+            let mut e = SnapmiError::default();
+            let rc = unsafe {
+                gpu::snapmi_frame_decode_host(
+                    self.ctx.as_ptr(), self.src.as_ptr(), self.srce, flags,
+                    self.stale.as_mut_ptr(), self.dst.as_mut_ptr(), self.dst.len(),
+                    &mut written, &mut consumed, &mut e,
+                )
+            };
+            self.dsts = 0;
+            self.dste = written;
+            if rc != 0 {
+                // the good bytes first, the error by the read that reaches it
+                self.pending = Some(match gpu::to_failure(rc, &e, Some(&self.ctx)) {
+                    Failure::Snap(e) => io::Error::from(e),
+                    Failure::UnexpectedEof => io::ErrorKind::UnexpectedEof.into(),
+                    Failure::Device(msg) => io::Error::new(io::ErrorKind::Other, msg),
+                });
+                self.srce = 0;
+                return Ok(());
+            }
+            if consumed == 0 {
+                // not one whole chunk in the buffer (a chunk is < 76 KiB, so
+                // only at the very start): read more
+                if self.eof {
+                    return Err(io::Error::new(io::ErrorKind::Other, "snapmi: no progress"));
+                }
+                if self.srce == self.src.len() {
+                    self.src.resize(2 * self.src.len(), 0);
+                }
+                continue;
+            }
+            self.read_stream_ident = true;
+            self.src.copy_within(consumed..self.srce, 0);
+            self.srce -= consumed;
+            return Ok(());
+        }
+    }
+}
+
+impl<R: io::Read> io::Read for FrameDecoder<R> {
+    fn read(&mut self, buf: &mut [u8]) -> io::Result<usize> {
+        loop {
+            if self.dsts < self.dste {
+                let len = cmp::min(self.dste - self.dsts, buf.len());
+                buf[..len].copy_from_slice(&self.dst[self.dsts..self.dsts + len]);
+                self.dsts += len;
+                return Ok(len);
+            }
+            if let Some(err) = self.pending.take() {
+                return Err(err);
+            }
+            if self.eof && self.srce == 0 {
+                return Ok(0);
+            }
+            self.fill()?;
+            if self.dsts == self.dste && self.pending.is_none() && self.eof && self.srce == 0 {
+                return Ok(0);
+            }
+        }
+    }
+}
+
+impl<R: fmt::Debug + io::Read> fmt::Debug for FrameDecoder<R> {
+    fn fmt(&self, f: &mut fmt::Formatter<'_>) -> fmt::Result {
+        f.debug_struct("FrameDecoder")
+            .field("r", &self.r)
+            .field("src", &"[...]")
+            .field("dst", &"[...]")
+            .field("dsts", &self.dsts)
+            .field("dste", &self.dste)
+            .field("read_stream_ident", &self.read_stream_ident)
+            .finish()
+    }
+}
+
+/// Compresses what is read from `R` into the Snappy frame format (reference
+/// :254-409).  As in the reference every chunk is what ONE read of up to
+/// 65536 bytes from `R` returned (:378); up to `BATCH` bytes of such reads
+/// are compressed by one device call.
+pub struct FrameEncoder<R: io::Read> {
+    r: R,
+    ctx: Context,
+    src: Vec<u8>,
+    lens: Vec<u32>,
+    dst: Vec<u8>,
+    dsts: usize,
+    dste: usize,
+    eof: bool,
+    wrote_stream_ident: bool,
+}
+
+impl<R: io::Read> FrameEncoder<R> {
+    /// A new streaming compressor reading from `rdr`.
+    pub fn new(rdr: R) -> FrameEncoder<R> {
+        FrameEncoder {
+            r: rdr,
+            ctx: Context::new(),
+            src: Vec::new(),
+            lens: Vec::new(),
+            dst: Vec::new(),
+            dsts: 0,
+            dste: 0,
+            eof: false,
+            wrote_stream_ident: false,
+        }
+    }
+
+    /// The underlying reader.
+    pub fn get_ref(&self) -> &R {
+        &self.r
+    }
+
+    /// The underlying reader, mutably.
+    pub fn get_mut(&mut self) -> &mut R {
+        &mut self.r
+    }
+
+    fn fill(&mut self) -> io::Result<()> {
+        self.src.clear();
+        self.lens.clear();
+        while self.src.len() < BATCH {
+            let at = self.src.len();
+            self.src.resize(at + MAX_BLOCK_SIZE, 0);
+            let n = self.r.read(&mut self.src[at..])?;
+            self.src.truncate(at + n);
+            if n == 0 {
+                self.eof = true;
+                break;
+            }
+            self.lens.push(n as u32);
+        }
+        self.dsts = 0;
+        self.dste = 0;
+        if self.lens.is_empty() {
+            return Ok(());
+        }
+        let cap = unsafe { gpu::snapmi_frame_encode_bound(self.src.len(), self.lens.len()) };
+        self.dst.resize(cap, 0);
+        let flags = if self.wrote_stream_ident { gpu::SNAPMI_FRAME_NO_IDENT } else { 0 };
+        let mut written = 0usize;
+        let rc = unsafe {
+            gpu::snapmi_frame_encode_host(
+                self.ctx.as_ptr(), self.src.as_ptr(), self.lens.as_ptr(), self.lens.len(), flags,
+                self.dst.as_mut_ptr(), cap, &mut written,
+            )
+        };
+        if rc != 0 {
+            let e = SnapmiError::default();
+            return Err(match gpu::to_failure(rc, &e, Some(&self.ctx)) {
+                Failure::Snap(e) => io::Error::from(e),
+                Failure::UnexpectedEof => io::ErrorKind::UnexpectedEof.into(),
+                Failure::Device(msg) => io::Error::new(io::ErrorKind::Other, msg),
+            });
+        }
+        self.wrote_stream_ident = true;
+        self.dste = written;
+        Ok(())
+    }
+}
+
+impl<R: io::Read> io::Read for FrameEncoder<R> {
+    fn read(&mut self, buf: &mut [u8]) -> io::Result<usize> {
+        loop {
+            if self.dsts < self.dste {
+                let len = cmp::min(self.dste - self.dsts, buf.len());
+                buf[..len].copy_from_slice(&self.dst[self.dsts..self.dsts + len]);
+                self.dsts += len;
+                return Ok(len);
+            }
+            if self.eof {
+                return Ok(0);
+            }
+            self.fill()?;
+        }
+    }
+}
+
+impl<R: fmt::Debug + io::Read> fmt::Debug for FrameEncoder<R> {
+    fn fmt(&self, f: &mut fmt::Formatter<'_>) -> fmt::Result {
+        f.debug_struct("FrameEncoder")
+            .field("r", &self.r)
+            .field("dst", &"[...]")
+            .field("dsts", &self.dsts)
+            .field("dste", &self.dste)
+            .finish()
+    }
+}
