@@ -104,6 +104,11 @@ int snapmi_ctx_create(int device, void *hip_stream, snapmi_ctx **out);
 void snapmi_ctx_destroy(snapmi_ctx *ctx);
 /* Message for the last SNAPMI_E_DEVICE / SNAPMI_E_ARGUMENT on this ctx. */
 const char *snapmi_last_error(const snapmi_ctx *ctx);
+/* Page-locked host memory for the host-buffer entry points (their H2D / D2H
+ * copies run at PCIe speed from such buffers, at about a third of it from
+ * pageable memory).  NULL when it cannot be had. */
+void *snapmi_host_alloc(size_t bytes);
+void snapmi_host_free(void *p);
 /* "ms ms ..." of the placement probe for every candidate region of the last
  * lane-table allocation ("" when lane_table_tries is 1). */
 const char *snapmi_table_probe_log(const snapmi_ctx *ctx);

@@ -248,6 +248,22 @@ int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value)
     return SNAPMI_OK;
 }
 
+void *snapmi_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+
+void snapmi_host_free(void *p)
+{
+    if (p)
+        (void)hipHostFree(p);
+}
+
 const char *snapmi_table_probe_log(const snapmi_ctx *ctx)
 {
     return ctx ? ctx->probe_log.c_str() : "";
