@@ -74,6 +74,10 @@ struct Job {
     Buf in, out;
     size_t in_len = 0, out_len = 0;
     uint32_t flags = 0;       // decode: CONTINUATION / FINAL
+    // compress from a regular file: the worker reads [file_off, +in_len)
+    // itself (page cache -> pinned buffer is a memcpy; N workers, N copies)
+    int fd = -1;
+    uint64_t file_off = 0;
     uint8_t stale[10] = {0};  // decode: reader state in front of this slab
     size_t n_chunks = 0;      // decode: data chunks in the slab
     int rc = 0;               // result
@@ -204,6 +208,24 @@ int run_stream(const Options &opt, FILE *src, FILE *dst, const char *name)
                     j->rc = SNAPMI_E_DEVICE;
                     j->msg = "no usable GPU";
                 } else if (!opt.decompress) {
+                    if (j->fd >= 0) {
+                        j->in.reserve(kSlab);
+                        size_t got = 0;
+                        while (got < j->in_len) {
+                            const ssize_t k = pread(j->fd, j->in.p + got,
+                                                    j->in_len - got,
+                                                    (off_t)(j->file_off + got));
+                            if (k <= 0)
+                                break;
+                            got += (size_t)k;
+                        }
+                        if (got != j->in_len) {
+                            j->rc = SNAPMI_E_ARGUMENT;
+                            j->msg = "short read";
+                            done.push(j);
+                            continue;
+                        }
+                    }
                     std::vector<uint32_t> lens((j->in_len + kChunk - 1) /
                                                kChunk, (uint32_t)kChunk);
                     if (j->in_len % kChunk)
@@ -273,11 +295,32 @@ int run_stream(const Options &opt, FILE *src, FILE *dst, const char *name)
     // the reader (this thread): slabs of whole chunks
     uint64_t seq = 0;
     bool first = true;
-    if (!opt.decompress) {
+    struct stat sst;
+    const int sfd = fileno(src);
+    if (!opt.decompress && fstat(sfd, &sst) == 0 && S_ISREG(sst.st_mode) &&
+        ftell(src) == 0) {
+        for (uint64_t off = 0; off < (uint64_t)sst.st_size && !failed;
+             off += kSlab) {
+            Job *j = nullptr;
+            if (!pool.pop(j))
+                break;
+            j->fd = sfd;
+            j->file_off = off;
+            j->in_len = (size_t)((uint64_t)sst.st_size - off < kSlab
+                                     ? (uint64_t)sst.st_size - off
+                                     : kSlab);
+            j->seq = seq++;
+            j->rc = 0;
+            j->out_len = 0;
+            j->flags = off == 0 ? 0 : SNAPMI_FRAME_NO_IDENT;
+            todo.push(j);
+        }
+    } else if (!opt.decompress) {
         for (;;) {
             Job *j = nullptr;
             if (!pool.pop(j))
                 break;
+            j->fd = -1;
             j->in.reserve(kSlab);
             j->in_len = read_full(src, j->in.p, kSlab);
             if (j->in_len == 0) {
@@ -405,6 +448,7 @@ int do_file(const Options &opt, const std::string &path)
     setvbuf(dst, nullptr, _IOFBF, 1 << 20);
     const auto t0 = std::chrono::steady_clock::now();
     int rc = run_stream(opt, src, dst, path.c_str());
+    fflush(dst);
     fclose(src);
     if (fclose(dst) != 0)
         rc = 1;
