@@ -432,6 +432,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if rank == 0:
+        probe = R._lib.load().snapmi_table_probe_log(ctx._h).decode()
+        log(f"[bench] lane-table placement probe ms per candidate: {probe}")
         log("[bench] compress kernel ms per step: "
             + " ".join(f"{x:.1f}/{y:.1f}" for x, y in zip(k_dom_ms, k_comp_ms))
             + " | decompress: " + " ".join(f"{x:.1f}" for x in k_dec_ms))
@@ -478,6 +480,8 @@ def main():
         ach_d = alg / kd / 1e9
         dom_name = ("k_match_blocks" if abs(kdom - kc) > 1e-9
                     else "k_compress_blocks")
+        dec_name = ("k_decompress_streams" if os.environ.get(
+            "SNAPMI_DECODE_KERNEL") == "1" else "k_decompress_streams2")
         traffic = traffic_d = None
         pmc_name = None
         for cand in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
@@ -489,9 +493,8 @@ def main():
                 "kernels"]
             if dom_name in pj:
                 traffic = pj[dom_name]["traffic_bytes_fetch_x2"]
-            if "k_decompress_streams" in pj:
-                traffic_d = pj["k_decompress_streams"][
-                    "traffic_bytes_fetch_x2"]
+            if dec_name in pj:
+                traffic_d = pj[dec_name]["traffic_bytes_fetch_x2"]
         line = {
             "metric": "GiB/s uncompressed (compress + decompress) on "
                       "zflat/uflat corpus",
@@ -522,7 +525,7 @@ def main():
                 "alg_bytes_per_launch": alg,
                 "avg_launch_ms": round(kdom * 1e3, 3)},
             "roofline_decompress": {
-                "kernel": "k_decompress_streams", "bound": "hbm",
+                "kernel": dec_name, "bound": "hbm",
                 "achieved": round(ach_d, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(ach_d / HBM_PEAK_GBS, 5),
                 "traffic": traffic_d, "alg_bytes_per_launch": alg,

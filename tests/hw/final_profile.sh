@@ -12,7 +12,7 @@ rm -rf $R/gpurun_out/prof_$tag
 timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$tag -o $tag -- python $R/bench.py --steps 5 --warmup 1 --no-cpu --no-extras > $R/gpurun_out/prof_$tag.log 2>&1
 db=$(find $R/gpurun_out/prof_$tag -name "*.db" | head -1)
 python $R/profiles/db_stats.py $db > $R/gpurun_out/kernel_stats_$tag.md; head -8 $R/gpurun_out/kernel_stats_$tag.md
-tail -1 $R/gpurun_out/prof_$tag.log > $R/gpurun_out/prof_${tag}_bench.json
+grep "^{\"metric" $R/gpurun_out/prof_$tag.log > $R/gpurun_out/prof_${tag}_bench.json
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $R/gpurun_out/pmc_${tag}_$c
   timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmc_${tag}_$c -o p -- python $R/bench.py --steps 1 --warmup 0 --no-cpu --no-extras > $R/gpurun_out/pmc_${tag}_$c.log 2>&1
