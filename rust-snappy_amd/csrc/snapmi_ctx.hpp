@@ -57,8 +57,9 @@ struct snapmi_ctx {
     uint32_t lane_waves_per_cu = 6; // 24 KiB of LDS per wave
     uint32_t lane_max_waves = 0;    // test knob: cap on lane-kernel waves (0 = none)
     // placements of the lane tables that are timed before one is kept
-    // (default 6 for a full-size launch: profiles/r2_placement_probe2.txt)
-    uint32_t lane_table_tries = 6;
+    // (default 10 for a full-size launch: profiles/r2_placement_probe2.txt;
+    // a candidate costs one hipMalloc and a 3 ms probe)
+    uint32_t lane_table_tries = 10;
     bool lane_table_probe = false; // experiment knob: probe even with 1 try
     std::string probe_log;          // k_probe_tables ms of every candidate
     // test knob: every lane's table epoch is set to this value before the
