@@ -132,6 +132,9 @@ const char *snapmi_version(void);
  *   "lane_table_tries"     placements of the lane tables that are timed
  *                          (k_probe_tables) before the fastest is kept, when
  *                          a context first allocates them
+ *   "frame_parallel_walk_min"  framed streams of at least this many bytes
+ *                          decoded without a side index get their chunk
+ *                          headers found in parallel (default 4 MiB)
  * Test knobs (results still never depend on them):
  *   "lane_tables_renew"    1: free the lane tables now; the next large batch
  *                          allocates (and places) new ones

@@ -221,6 +221,10 @@ int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value)
     else if (strcmp(name, "lane_max_waves") == 0 && value >= 0 &&
              value <= 0x7FFFFFFF)
         ctx->lane_max_waves = (uint32_t)value;
+    else if (strcmp(name, "frame_walk_segment") == 0 && value >= (128 << 10))
+        ctx->frame_walk_segment = (uint64_t)value;
+    else if (strcmp(name, "frame_parallel_walk_min") == 0 && value >= 0)
+        ctx->frame_parallel_walk_min = (uint64_t)value;
     else if (strcmp(name, "decode_kernel") == 0 && value >= 1 && value <= 2)
         ctx->decode_kernel = (int)value;
     else if (strcmp(name, "lane_table_tries") == 0 && value >= 1 &&

@@ -49,6 +49,10 @@ struct snapmi_ctx {
     // frame layer scratch (snapmi_frame.hip)
     snapmi::DevBuf fr_tables, fr_desc, fr_meta, fr_scan, fr_slots, fr_chunk_off;
     bool fr_tables_ready = false;
+    // framed streams of at least this many bytes without a side index get
+    // their chunk headers found in parallel (k_fw_*); shorter ones are walked
+    uint64_t frame_parallel_walk_min = 4ull << 20;
+    uint64_t frame_walk_segment = 32ull << 20; // >= 128 KiB (test knob)
     int num_cus = 0;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t lane_min_blocks = 8192; // measured crossover ~0.5 GiB

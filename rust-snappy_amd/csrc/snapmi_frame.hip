@@ -307,6 +307,15 @@ struct FrameDecodeArgs {
     uint64_t *out_lens;
     uint8_t *modes;
     uint32_t *crcs; // computed
+    // parallel header walk (k_fw_*): per 32 MiB segment of the stream, the
+    // chains that start at a plausible header inside its first 76 494 bytes
+    // and reach the segment's end: {entry, exit, data chunks on the way}
+    unsigned long long *fw_cand; // [nseg * kFwCands * 3]
+    uint32_t *fw_ncand;          // [nseg]
+    unsigned long long *fw_entry; // [nseg + 1] the real chain's entry per segment
+    uint32_t *fw_base;           // [nseg + 1] data chunks in front of the segment
+    uint32_t nseg;
+    unsigned long long fw_seg; // segment bytes (32 MiB; smaller in tests)
 };
 
 __device__ inline void walk_fail(const FrameDecodeArgs &a, uint32_t n_data,
@@ -394,6 +403,164 @@ __device__ inline bool short_varint(gcptr p, uint64_t pl)
         if (p[k] < 0x80)
             return false;
     return true;
+}
+
+// ---------------------------------------------------------------------
+// Parallel header walk.  The frame format is a linked list without an index:
+// k_frame_walk below hops from header to header, 0.7 us per hop (1.1 s for the
+// 1 048 576 chunks of a 64 GiB stream).  But a header is easy to recognise
+// (type byte, 24-bit length within the format's limits, chunk inside the
+// stream: 0.2 % of random positions pass) and a chain that starts at a wrong
+// position dies within a hop or two.  So, per 32 MiB segment of the stream:
+//   k_fw_candidates  every position of the segment's first 76 494 bytes (the
+//                    real chain must touch down there) that looks like a
+//                    header is followed to the segment's end; the survivors
+//                    are recorded as {entry, exit, data chunks};
+//   k_fw_resolve     one thread strings the segments together: the real
+//                    chain enters segment k where it left segment k-1;
+//   k_fw_emit        one thread per segment walks its real chain again and
+//                    writes the chunk records at their final index.
+// Only well-formed stretches are decided here: the first header that the
+// reference's reader would reject (or a chunk the stale-buffer rule applies
+// to) makes the chain "die", the resolve step then finds no continuation and
+// sets meta[3] = 2, and the sequential walk runs and reports the error.
+// ---------------------------------------------------------------------
+constexpr uint32_t kFwCands = 32;
+constexpr uint32_t kFwScan = 4 + kMaxChunk; // longest chunk, header included
+
+// One hop of a well-formed chain: the chunk at r (header checks of
+// src/read.rs:119-187 that need no history).  Returns false if the reader
+// would stop here; *data = 1 for a compressed / stored chunk.
+__device__ inline bool fw_hop(const FrameDecodeArgs &a, uint64_t &r,
+                              uint32_t &data)
+{
+    gcptr in = (gcptr)a.in;
+    if (a.in_len - r < 4)
+        return false;
+    const uint32_t hd = ld32u(in + r);
+    const uint32_t ty = hd & 0xFF;
+    const uint64_t len = hd >> 8;
+    data = 0;
+    if (len > kMaxChunk || (ty >= 0x02 && ty <= 0x7F) ||
+        a.in_len - r - 4 < len)
+        return false;
+    if (ty == 0xFF) {
+        if (len != 6)
+            return false;
+        const uint8_t body[6] = {'s', 'N', 'a', 'P', 'p', 'Y'};
+        for (int k = 0; k < 6; k++)
+            if (in[r + 4 + k] != body[k])
+                return false;
+    } else if (ty <= 0x01) {
+        if (len < 4 || (ty == 0x01 && len - 4 > kMaxBlock))
+            return false;
+        if (ty == 0x00 && short_varint(in + r + 8, len - 4))
+            return false; // read.rs:216: the sequential walk's business
+        data = 1;
+    }
+    r += 4 + len;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_fw_candidates(FrameDecodeArgs a)
+{
+    const uint64_t seg = blockIdx.y;
+    const uint64_t lo = seg * a.fw_seg;
+    uint64_t end = lo + a.fw_seg; // the chain leaves the segment at or past it
+    if (end > a.in_len)
+        end = a.in_len;
+    const uint64_t off = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (off >= kFwScan || lo + off >= a.in_len)
+        return;
+    if (seg == 0 && off != 0)
+        return; // the stream starts at its first byte
+    uint64_t r = lo + off;
+    uint32_t n = 0, data = 0;
+    while (r < end) {
+        if (!fw_hop(a, r, data))
+            return; // not a chain (or the real one's first bad chunk)
+        n += data;
+    }
+    const uint32_t k = atomicAdd(&a.fw_ncand[seg], 1u);
+    if (k < kFwCands) {
+        unsigned long long *c = a.fw_cand + (seg * kFwCands + k) * 3;
+        c[0] = lo + off;
+        c[1] = r;
+        c[2] = n;
+    }
+}
+
+__global__ void k_fw_resolve(FrameDecodeArgs a)
+{
+    gcptr in = (gcptr)a.in;
+    a.meta[0] = 0;
+    a.meta[1] = 0;
+    a.meta[2] = 0xFFFFFFFFu;
+    a.meta[3] = 2; // until proven well-formed: the sequential walk decides
+    a.serr[0].kind = SNAPMI_OK;
+    // the first chunk must be the stream identifier (src/read.rs:123-128)
+    if (!(a.flags & SNAPMI_FRAME_CONTINUATION) &&
+        (a.in_len < 4 || in[0] != 0xFF))
+        return;
+    uint64_t cur = 0;
+    uint32_t total = 0;
+    for (uint32_t seg = 0; seg < a.nseg; seg++) {
+        a.fw_entry[seg] = ~0ull;
+        a.fw_base[seg] = total;
+        if (cur >= ((uint64_t)seg + 1) * a.fw_seg)
+            continue; // (a chunk of <= 76 KiB spans a whole small test segment)
+        const uint32_t nc =
+            a.fw_ncand[seg] < kFwCands ? a.fw_ncand[seg] : kFwCands;
+        bool found = false;
+        for (uint32_t k = 0; k < nc && !found; k++) {
+            const unsigned long long *c =
+                a.fw_cand + ((uint64_t)seg * kFwCands + k) * 3;
+            if (c[0] == cur) {
+                a.fw_entry[seg] = cur;
+                cur = c[1];
+                total += (uint32_t)c[2];
+                found = true;
+            }
+        }
+        if (!found)
+            return; // the real chain does not survive this segment
+    }
+    if (cur != a.in_len)
+        return;
+    a.fw_base[a.nseg] = total;
+    a.meta[0] = total;
+    a.meta[1] = total > a.cap_chunks ? 1 : 0;
+    a.meta[3] = 0;
+}
+
+__global__ void k_fw_emit(FrameDecodeArgs a)
+{
+    const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
+    if (seg >= a.nseg || a.meta[3] != 0 || a.meta[1] != 0)
+        return;
+    uint64_t r = a.fw_entry[seg];
+    if (r == ~0ull)
+        return;
+    gcptr in = (gcptr)a.in;
+    uint64_t end = ((uint64_t)seg + 1) * a.fw_seg;
+    if (end > a.in_len)
+        end = a.in_len;
+    uint32_t idx = a.fw_base[seg];
+    while (r < end) {
+        const uint32_t hd = ld32u(in + r);
+        const uint32_t ty = hd & 0xFF;
+        const uint32_t len = hd >> 8;
+        if (ty <= 0x01) {
+            FrameChunk c;
+            c.payload_off = r + 8;
+            c.payload_len = len - 4;
+            c.crc = ld32u(in + r + 4);
+            c.type = ty;
+            c.pad = 0;
+            a.chunks[idx++] = c;
+        }
+        r += 4 + (uint64_t)len;
+    }
 }
 
 // Sequential walk over the chunk headers: reference FrameDecoder::read,
@@ -1080,15 +1247,24 @@ int snapmi_frame_decompress_ex(snapmi_ctx *ctx, const void *d_in,
     // capacity for the chunk table: exact with an index, else an estimate
     // that is retried once with the exact count
     bool use_index = d_chunk_offsets != nullptr;
+    // long streams without an index: find the headers in parallel (k_fw_*)
+    bool parallel_walk = in_len >= ctx->frame_parallel_walk_min;
     uint64_t cap = use_index ? n_chunks : in_len / 2048 + 64;
-    for (int attempt = 0; attempt < 3; attempt++) {
+    const uint64_t fw_seg = ctx->frame_walk_segment;
+    const uint64_t nseg64 = (in_len + fw_seg - 1) / fw_seg;
+    if (nseg64 == 0 || nseg64 > 65535)
+        parallel_walk = false; // (empty; grid limit: 2 TiB at the default)
+    const uint32_t nseg = parallel_walk ? (uint32_t)nseg64 : 0;
+    for (int attempt = 0; attempt < 4; attempt++) {
         if (cap > 0x7FFFFFFFu)
             return fail_ctx(ctx, SNAPMI_E_ARGUMENT, "frame: too many chunks");
         const size_t n = (size_t)cap;
         const size_t meta_bytes = 64 + sizeof(snapmi_error) +
                                   n * (sizeof(FrameChunk) + 8 + 8 +
                                        sizeof(snapmi_error) * 2 + 8 * 5 + 1 +
-                                       4) + 32 * 16;
+                                       4) + 32 * 16 +
+                                  (size_t)(nseg + 2) *
+                                      (kFwCands * 24 + 4 + 8 + 4);
         if ((rc = reserve(ctx, ctx->fr_meta, meta_bytes)))
             return rc;
         FrameDecodeArgs a;
@@ -1119,12 +1295,26 @@ int snapmi_frame_decompress_ex(snapmi_ctx *ctx, const void *d_in,
         a.out_lens = carve<uint64_t>(p, n);
         a.crcs = carve<uint32_t>(p, n);
         a.modes = carve<uint8_t>(p, n);
+        a.nseg = nseg;
+        a.fw_seg = fw_seg;
+        a.fw_cand = carve<unsigned long long>(p, (size_t)nseg * kFwCands * 3);
+        a.fw_entry = carve<unsigned long long>(p, (size_t)nseg + 1);
+        a.fw_ncand = carve<uint32_t>(p, nseg);
+        a.fw_base = carve<uint32_t>(p, (size_t)nseg + 1);
 
         const uint32_t tb = 256;
         const uint32_t gb = n ? (uint32_t)((n + tb - 1) / tb) : 1;
         if (use_index) {
             hipLaunchKernelGGL(k_frame_meta_init, dim3(1), dim3(1), 0, s, a);
             hipLaunchKernelGGL(k_frame_index, dim3(gb), dim3(tb), 0, s, a);
+        } else if (parallel_walk) {
+            HIP_TRY(ctx, hipMemsetAsync(a.fw_ncand, 0, a.nseg * 4, s));
+            hipLaunchKernelGGL(k_fw_candidates,
+                               dim3((kFwScan + 255) / 256, a.nseg), dim3(256),
+                               0, s, a);
+            hipLaunchKernelGGL(k_fw_resolve, dim3(1), dim3(1), 0, s, a);
+            hipLaunchKernelGGL(k_fw_emit, dim3((a.nseg + 63) / 64), dim3(64),
+                               0, s, a);
         } else {
             hipLaunchKernelGGL(k_frame_walk, dim3(1), dim3(64), 0, s, a);
         }
@@ -1136,6 +1326,10 @@ int snapmi_frame_decompress_ex(snapmi_ctx *ctx, const void *d_in,
         if (use_index && meta[3]) { // the index does not tile the stream with
             use_index = false;      // plain data chunks: the walk decides
             cap = n_chunks + in_len / 65536 + 64;
+            continue;
+        }
+        if (parallel_walk && meta[3] == 2) { // something in the stream that
+            parallel_walk = false;           // only the sequential walk judges
             continue;
         }
         if (meta[1] && !use_index && cap < meta[0]) { // table too small

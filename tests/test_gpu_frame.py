@@ -613,3 +613,70 @@ def test_cfg5_shape_jpeg_through_the_frame_layer(ctx):
     assert all(c == O.compress(jpg) for c in comp)
     outs, errs = gpu_decompress(ctx, comp)
     assert all(o == jpg for o in outs) and all(e[0] == 0 for e in errs)
+
+
+def test_frame_parallel_header_walk(built):
+    """Without a side index the chunk headers are found in parallel (k_fw_*:
+    plausible headers per segment, chains followed to the segment's end, the
+    segments strung together); anything the reference's reader would reject
+    sends the stream to the sequential walk.  Forced here for small streams
+    with 128 KiB segments, against the sequential walk and the oracle."""
+    import rust_snappy_amd as R
+    from rust_snappy_amd import frame
+    par = R.raw.Context(0)
+    par.set_option("frame_parallel_walk_min", 0)
+    par.set_option("frame_walk_segment", 128 << 10)
+    seq = R.raw.Context(0)
+    seq.set_option("frame_parallel_walk_min", 1 << 60)
+    rnd = O.corpus_round()
+    data = b"".join(d for _, d in rnd)                    # 45 chunks
+    f = O.frame_compress(data)
+    ident = f[:10]
+    offs = frame.index_host(f)
+    # other chunk types between data chunks, at several places
+    g = bytearray(ident)
+    for i in range(len(offs) - 1):
+        g += f[int(offs[i]):int(offs[i + 1])]
+        if i % 7 == 3:
+            g += bytes([0x80, 5, 0, 0]) + b"skip!"
+        if i % 11 == 5:
+            g += bytes([0xFE, 3, 0, 0]) + b"pad" + ident
+    jpg = rnd[2][1]
+    streams = [f, bytes(g), O.frame_compress(jpg * 3),
+               O.frame_compress(b"x" * 70000), ident, b"",
+               O.frame_compress(data[:65536])]
+    bad = []
+    for cut in (1, 5, 9, 300, 70000):
+        bad.append(f[:-cut])                               # UnexpectedEof
+    b2 = bytearray(f); b2[int(offs[20])] = 0x05; bad.append(bytes(b2))
+    b3 = bytearray(f); b3[int(offs[30]) + 3] = 0xFF; bad.append(bytes(b3))
+    b4 = bytearray(f); b4[int(offs[12]) + 4] ^= 1; bad.append(bytes(b4))   # crc
+    b5 = bytearray(f); b5[int(offs[40]) + 100] ^= 0x40; bad.append(bytes(b5))
+    bad.append(b"\x00" + f[1:])                            # StreamHeader
+    bad.append(f[:int(offs[9])] + chunk(0, b"\x80" * 5, b"\x01\x02\x03\x04")
+               + f[int(offs[9]):])                         # stale-buffer rule
+    for s in streams + bad:
+        n_chunks = len(s) // 8 + 1
+        d_in = torch.frombuffer(bytearray(s or b"\0"),
+                                dtype=torch.uint8).cuda()
+        got = frame.decompress_batch_device(par, d_in, len(s), n_chunks)
+        want = frame.decompress_batch_device(seq, d_in, len(s), n_chunks)
+        assert got[0] == want[0] and got[1] == want[1], len(s)
+        try:
+            truth = O.frame_decompress(s)
+            assert got == (truth, None)
+        except O.SnapError as oe:
+            assert got[1] is not None
+            if oe.kind >= 0 and got[1].variant != "StreamHeaderMismatch":
+                assert (got[1].kind,) + got[1].abc == \
+                    (oe.kind, oe.a, oe.b, oe.c), (got[1], oe)
+    # default segment size, a stream of several segments (cfg3 shape)
+    import bench_configs as BC
+    dev = torch.device("cuda", 0)
+    text = BC.synth_text(dev, 96 << 20)
+    c = R.raw.Context(0)
+    out, flen, index = frame.compress_device(c, text, want_index=True)
+    back, m = frame.decompress_device(c, out, flen)        # no index
+    assert m == text.numel() and torch.equal(back[:m], text)
+    for x in (par, seq, c):
+        x.close()
