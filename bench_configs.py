@@ -81,11 +81,13 @@ def cfg3(args, ctx, dev):
     data = period.repeat(reps)
     n = data.numel()
     out, flen, index = frame.compress_device(ctx, data, want_index=True)
-    # parity: the first 4 MiB against the oracle's restatement of
-    # write::FrameEncoder, chunk for chunk; every period equal to period 0
-    head = data[:4 << 20].cpu().numpy().tobytes()
+    # parity: the first 64 MiB (1024 chunks) against the oracle's restatement
+    # of write::FrameEncoder, chunk for chunk; the timed decode below checks
+    # every period of the round trip against the generator's period
+    hn = min(64 << 20, n // 65536 * 65536)
+    head = data[:hn].cpu().numpy().tobytes()
     want = O.frame_compress(head)
-    k = (4 << 20) // 65536
+    k = hn // 65536
     cut = int(index[k].item())
     assert out[:cut].cpu().numpy().tobytes() == want[:cut], "framed bytes differ"
     import ctypes as C

@@ -132,6 +132,10 @@ int snapmi_ctx_create(int device, void *hip_stream, snapmi_ctx **out)
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) !=
             hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) !=
+            hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_crc[0], hipEventDisableTiming) !=
+            hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_crc[1], hipEventDisableTiming) !=
             hipSuccess) {
         snapmi_ctx_destroy(ctx);
         return SNAPMI_E_DEVICE;
@@ -196,6 +200,9 @@ void snapmi_ctx_destroy(snapmi_ctx *ctx)
         (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join)
         (void)hipEventDestroy(ctx->ev_join);
+    for (auto &ev : ctx->ev_crc)
+        if (ev)
+            (void)hipEventDestroy(ev);
     if (ctx->owns_stream && ctx->stream)
         (void)hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -1006,14 +1006,24 @@ static int frame_compress_impl(snapmi_ctx *ctx, const void *d_in,
         a.cnt = cnt;
         const uint32_t tb = 256, gb = (cnt + tb - 1) / tb;
         hipLaunchKernelGGL(k_frame_chunks, dim3(gb), dim3(tb), 0, s, a);
+        // The checksums only need the input: they run on the side stream,
+        // under the match finder (which waits on HBM round trips and leaves
+        // 16 KiB of LDS per CU free - room for three CRC workgroups).  Fusing
+        // the CRC into the match finder's own block loads would add ~380
+        // vector instructions per 128-byte line to a loop of ~150 per round
+        // to save a kernel of 1 % of the pass: not done.
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_crc[0], s));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_crc[0], 0));
+        hipLaunchKernelGGL(k_crc32c, dim3(cnt), dim3(64), 0, ctx->stream2,
+                           a.in_ptrs, a.in_lens, a.crcs, cnt,
+                           (const CrcTables *)ctx->fr_tables.p);
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_crc[1], ctx->stream2));
         // every chunk is a one-block raw stream: cnt blocks, no scratch slots
         rc = launch_compress(ctx, a.in_ptrs, a.in_lens, a.slot_ptrs, nullptr,
                              a.clens, nullptr, cnt, cnt, 0);
         if (rc)
             return rc;
-        hipLaunchKernelGGL(k_crc32c, dim3(cnt), dim3(64), 0, s, a.in_ptrs,
-                           a.in_lens, a.crcs, cnt,
-                           (const CrcTables *)ctx->fr_tables.p);
+        HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_crc[1], 0));
         hipLaunchKernelGGL(k_frame_sizes, dim3(gb), dim3(tb), 0, s, a);
         hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, s, a.sizes,
                            a.offs, cnt);
