@@ -760,7 +760,7 @@ int snapmi_decompress_stream(snapmi_ctx *ctx, const void *d_in,
     const size_t blocks = (size_t)a.nseg + a.nsuper + a.nsuper3;
     const size_t rows = (size_t)a.nseg +
                         ((size_t)a.nsuper + a.nsuper3) * kSegPerSuper;
-    const size_t t_bytes = 64 + rows * kWave * 16 + blocks * 16 +
+    const size_t t_bytes = 64 + rows * kEntry * 16 + blocks * 16 +
                            ((size_t)a.kmax + 1) * 16;
     // descriptors: the pieces, then the whole stream as batch entry [kmax]
     const size_t d_stride = 8 + 8 + 8 + 8 + 8 + sizeof(snapmi_error);
@@ -773,11 +773,11 @@ int snapmi_decompress_stream(snapmi_ctx *ctx, const void *d_in,
     a.meta = t;
     t += 8;
     a.s1 = t;
-    t += (size_t)a.nseg * kWave * 2;
+    t += (size_t)a.nseg * kEntry * 2;
     a.s2 = t;
-    t += (size_t)a.nsuper * kSegPerSuper * kWave * 2;
+    t += (size_t)a.nsuper * kSegPerSuper * kEntry * 2;
     a.s3 = t;
-    t += (size_t)a.nsuper3 * kSegPerSuper * kWave * 2;
+    t += (size_t)a.nsuper3 * kSegPerSuper * kEntry * 2;
     a.e1 = t; // e1, e2, e3 contiguous: one memset
     t += (size_t)a.nseg * 2;
     a.e2 = t;
@@ -821,11 +821,14 @@ int snapmi_decompress_stream(snapmi_ctx *ctx, const void *d_in,
 
     hipLaunchKernelGGL(k_stream_head, dim3(1), dim3(1), 0, s, a);
     STREAM_CHECK(k_stream_head);
-    hipLaunchKernelGGL(k_stream_scan, dim3(a.nseg), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_stream_scan,
+                       dim3((a.nseg + kWave / kEntry - 1) / (kWave / kEntry)),
+                       dim3(64), 0, s, a);
     STREAM_CHECK(k_stream_scan);
-    hipLaunchKernelGGL(k_stream_super, dim3(a.nsuper), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_stream_super, dim3(a.nsuper), dim3(kEntry), 0, s, a);
     STREAM_CHECK(k_stream_super);
-    hipLaunchKernelGGL(k_stream_super3, dim3(a.nsuper3), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_stream_super3, dim3(a.nsuper3), dim3(kEntry), 0, s,
+                       a);
     STREAM_CHECK(k_stream_super3);
     hipLaunchKernelGGL(k_stream_chain, dim3(1), dim3(1), 0, s, a);
     STREAM_CHECK(k_stream_chain);

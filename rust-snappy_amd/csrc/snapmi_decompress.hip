@@ -1164,14 +1164,14 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
 namespace {
 constexpr unsigned long long kNone = ~0ull;
 // k_stream_scan follows a chain at most this many elements behind its
-// segment's end.  Compressible data lands on a tabulated offset (within 64
-// bytes of a 4 KiB boundary) at the next boundary unless an element of 64+
-// encoded bytes jumps over it, which costs a segment of small elements
-// (~1 300 hops of 3 bytes) until the next chance; incompressible data
-// (64 KiB literals) lands with probability 1/64 per element.  8 192 hops
-// cover several misses in a row and all but (63/64)^8192 of the literal
-// walks, and bound what a crafted stream can cost to 128 hops per input
-// byte (it was quadratic in the input length without a bound).
+// segment's end.  Compressible data lands on a tabulated offset (within
+// kEntry = 8 bytes of a 4 KiB boundary) at the next boundary unless an
+// element of 9+ encoded bytes jumps over it, which costs a segment of small
+// elements (~1 300 hops of 3 bytes) until the next chance; incompressible
+// data (64 KiB literals) lands with probability 1/512 per element.  8 192
+// hops cover several misses in a row and all but (511/512)^8192 = 1e-7 of
+// the literal walks, and bound what a crafted stream can cost to 16 hops
+// per input byte (it was quadratic in the input length without a bound).
 constexpr uint32_t kScanOverrun = 8192;
 
 typedef unsigned long long su64x2 __attribute__((ext_vector_type(2)));
@@ -1229,9 +1229,9 @@ __device__ __forceinline__ su64x2 *level_entry(const StreamArgs &a)
 
 // Follow the chain from p to the end of the level-L block that contains p
 // (or of the stream).  Tables: level 1 [segment][o]: enter the segment at
-// offset o < 64; levels 2, 3 [block][child][o]: enter the block at offset
-// o < 64 of its child (a block of the level below).  A position deeper than
-// 64 bytes inside a child - the chain landed there after a long element - is
+// offset o < kEntry; levels 2, 3 [block][child][o]: enter the block at offset
+// o < kEntry of its child (a block of the level below).  A position deeper than
+// kEntry bytes inside a child - the chain landed there after a long element - is
 // first taken to that child's end one level down.
 template <int L>
 __device__ __forceinline__ bool reach_end(const StreamArgs &a, uint64_t &p,
@@ -1242,8 +1242,8 @@ __device__ __forceinline__ bool reach_end<1>(const StreamArgs &a, uint64_t &p,
 {
     const uint64_t seg = p / kSeg;
     const uint64_t o = p - seg * kSeg;
-    if (o < kWave) {
-        const su64x2 e = level_table<1>(a)[seg * kWave + o];
+    if (o < kEntry) {
+        const su64x2 e = level_table<1>(a)[seg * kEntry + o];
         if (e.x == kNone)
             return false;
         p = e.x;
@@ -1270,9 +1270,9 @@ __device__ __forceinline__ bool reach_end(const StreamArgs &a, uint64_t &p,
     while (p < end) {
         const uint64_t rel = p - blk * B;
         const uint64_t c = rel / Bc, o = rel - c * Bc;
-        if (o < kWave) {
+        if (o < kEntry) {
             const su64x2 e =
-                level_table<L>(a)[(blk * kSegPerSuper + c) * kWave + o];
+                level_table<L>(a)[(blk * kSegPerSuper + c) * kEntry + o];
             if (e.x == kNone)
                 return false;
             p = e.x;
@@ -1289,7 +1289,7 @@ __device__ __forceinline__ bool reach_end(const StreamArgs &a, uint64_t &p,
 // child c continues, after that child, with an entry already tabulated
 template <int L> __device__ __forceinline__ void build_level(const StreamArgs &a)
 {
-    __shared__ su64x2 tab[kSegPerSuper * kWave]; // 64 KiB
+    __shared__ su64x2 tab[kSegPerSuper * kEntry]; // 16 KiB
     if (a.meta[2])
         return;
     const uint64_t B = level_bytes<L>(), Bc = level_bytes<L - 1>();
@@ -1303,8 +1303,8 @@ template <int L> __device__ __forceinline__ void build_level(const StreamArgs &a
         while (ok && p < end) {
             const uint64_t rel = p - blk * B;
             const uint64_t c2 = rel / Bc, o2 = rel - c2 * Bc;
-            if (o2 < kWave) {
-                const su64x2 e = tab[c2 * kWave + o2]; // c2 > c: done before
+            if (o2 < kEntry) {
+                const su64x2 e = tab[c2 * kEntry + o2]; // c2 > c: done before
                 ok = e.x != kNone;
                 p = e.x;
                 out += e.y;
@@ -1312,11 +1312,11 @@ template <int L> __device__ __forceinline__ void build_level(const StreamArgs &a
             }
             ok = reach_end<L - 1>(a, p, out);
         }
-        tab[c * kWave + threadIdx.x] = (su64x2){ok ? p : kNone, out};
+        tab[c * kEntry + threadIdx.x] = (su64x2){ok ? p : kNone, out};
         __syncthreads();
     }
-    su64x2 *dst = level_table<L>(a) + blk * kSegPerSuper * kWave;
-    for (uint32_t i = threadIdx.x; i < kSegPerSuper * kWave; i += kWave)
+    su64x2 *dst = level_table<L>(a) + blk * kSegPerSuper * kEntry;
+    for (uint32_t i = threadIdx.x; i < kSegPerSuper * kEntry; i += kEntry)
         dst[i] = tab[i];
 }
 
@@ -1374,37 +1374,42 @@ __global__ __launch_bounds__(64) void k_stream_scan(StreamArgs a)
 {
     if (a.meta[2])
         return;
-    const uint64_t seg = blockIdx.x;
-    uint64_t p = seg * kSeg + threadIdx.x, out = 0;
+    // kWave / kEntry segments per wavefront, kEntry entry offsets each
+    const uint64_t seg = (uint64_t)blockIdx.x * (kWave / kEntry) +
+                         threadIdx.x / kEntry;
+    const uint32_t o = threadIdx.x % kEntry;
+    if (seg >= a.nseg)
+        return;
+    uint64_t p = seg * kSeg + o, out = 0;
     uint64_t end = (seg + 1) * kSeg;
     if (end > a.in_len)
         end = a.in_len;
     bool ok = p < a.in_len;
     // The exit is the first element start at or behind the segment's end
-    // that lies within 64 bytes of a segment boundary (or the end of the
+    // that lies within kEntry bytes of a segment boundary (or the end of the
     // stream): whoever follows the tables therefore always lands on a
     // tabulated offset, also behind a long element, and never has to hop
     // through elements itself.
     // The walk past the segment's end is bounded (a crafted stream whose
-    // elements all end 64+ bytes off a segment boundary would otherwise make
-    // every thread walk to the end of the input): after kScanOverrun
-    // elements the entry is left as "cannot follow", and whoever needs it
-    // sets meta[2] - the sequential decoder then owns the stream.
+    // elements all end off the landing zone would otherwise make every
+    // thread walk to the end of the input): after kScanOverrun elements the
+    // entry is left as "cannot follow", and whoever needs it sets meta[2] -
+    // the sequential decoder then owns the stream.
     uint32_t over = 0; // elements hopped behind the segment's end
-    while (ok && p < a.in_len && (p < end || (p & (kSeg - 1)) >= kWave)) {
+    while (ok && p < a.in_len && (p < end || (p & (kSeg - 1)) >= kEntry)) {
         if (p >= end && ++over > kScanOverrun) {
             ok = false;
             break;
         }
         ok = elem_step((gcptr)a.in, a.in_len, p, out);
     }
-    level_table<1>(a)[seg * kWave + threadIdx.x] = (su64x2){ok ? p : kNone, out};
+    level_table<1>(a)[seg * kEntry + o] = (su64x2){ok ? p : kNone, out};
 }
-__global__ __launch_bounds__(64) void k_stream_super(StreamArgs a)
+__global__ __launch_bounds__(kEntry) void k_stream_super(StreamArgs a)
 {
     build_level<2>(a);
 }
-__global__ __launch_bounds__(64) void k_stream_super3(StreamArgs a)
+__global__ __launch_bounds__(kEntry) void k_stream_super3(StreamArgs a)
 {
     build_level<3>(a);
 }

@@ -83,9 +83,17 @@ __global__ void k_compact(CompressArgs a);
 // One long raw stream decoded by many wavefronts (snapmi_decompress_stream).
 // The element chain is sequential, so it is resolved hierarchically first:
 // per 4 KiB segment and per 256 KiB super-segment, "if an element starts at
-// offset o (< 64) of this piece, where does the chain leave it and how many
+// offset o (< kEntry) of this piece, where does the chain leave it and how many
 // bytes has it produced".
 constexpr uint32_t kSeg = 4096;           // bytes of compressed input
+// Entry offsets tabulated per segment / child: a chain is followed from the
+// first kEntry bytes behind a boundary.  8 instead of a full wavefront of 64:
+// the 64 chains of a segment merge within a few elements, so most of the
+// scan's hops were duplicates; a wavefront now scans eight segments (one raw
+// stream of 3 GiB: 52 -> 119 GiB/s; 16 entries gave 103, 4 gave 123 within
+// noise of 8).  A literal of 9-60 bytes that straddles a boundary jumps over
+// the landing zone and costs one more segment of hops: rare next to the 8x.
+constexpr uint32_t kEntry = 8;
 constexpr uint32_t kSegPerSuper = 64;
 constexpr uint32_t kStreamChunk = 65536;  // output bytes per piece: the
                                           // encoders' block size, so pieces
@@ -102,7 +110,7 @@ struct StreamArgs {
     // not independent), [3] pieces
     unsigned long long *meta;
     // per level (4 KiB, 256 KiB, 16 MiB blocks): tables of (exit, produced)
-    // per entry offset < 64 - level 1 [segments * 64], levels 2 and 3
+    // per entry offset < kEntry - level 1 [segments * kEntry], levels 2 and 3
     // [blocks * 64 children * 64] - and entries [blocks] of (position,
     // produced) where the chain enters each block (~0 = it does not)
     unsigned long long *s1, *s2, *s3;
