@@ -1,5 +1,5 @@
-// Hardware probe: do unaligned LDS accesses (ds_read_b64 / b32 / u16 and
-// ds_write_b64 / b32 / b16 at arbitrary byte addresses) behave bytewise?  The
+// Hardware probe: do unaligned LDS accesses (ds_read_b128 / b64 / b32 / u16 and
+// ds_write_b128 / b64 / b32 / b16 at arbitrary byte addresses) behave bytewise?  The
 // element-major decoder (k_decompress_streams2) reads 8 bytes and writes
 // 8 / 4 / 2 / 1 bytes at unaligned ring positions.  hipcc emits single DS
 // instructions for align-1 accesses on gfx950 (unaligned access mode); this
@@ -33,6 +33,29 @@ __global__ void probe(uint32_t *bad)
         fails += v8 != w8;
         fails += v4 != w4;
         fails += v2 != w2;
+        // 16 bytes at once (hipcc merges two 8-byte copies into ds_read_b128 /
+        // ds_write_b128 whatever the alignment)
+        struct { uint64_t lo, hi; } v16;
+        __builtin_memcpy(&v16, m + a + 5, 16);
+        uint64_t e0 = 0, e1 = 0;
+        for (int k = 7; k >= 0; k--) e0 = (e0 << 8) | (uint8_t)((a + 5 + k) * 7 + rep);
+        for (int k = 7; k >= 0; k--) e1 = (e1 << 8) | (uint8_t)((a + 13 + k) * 7 + rep);
+        fails += v16.lo != e0;
+        fails += v16.hi != e1;
+        __syncthreads();
+        {   // 16-byte write at 61 * lane + rep + 20 (inside the lane's 61)
+            const uint32_t b16 = 61 * lane + rep + 20;
+            struct { uint64_t lo, hi; } x16 = {0x1122334455667788ull ^ lane,
+                                               0x99AABBCCDDEEFF00ull + lane};
+            __builtin_memcpy(m + b16, &x16, 16);
+            __syncthreads();
+            for (int k = 0; k < 8; k++) fails += m[b16 + k] != (uint8_t)(x16.lo >> (8 * k));
+            for (int k = 0; k < 8; k++) fails += m[b16 + 8 + k] != (uint8_t)(x16.hi >> (8 * k));
+            fails += m[b16 + 16] != (uint8_t)((b16 + 16) * 7 + rep);
+            fails += m[b16 - 1] != (uint8_t)((b16 - 1) * 7 + rep);
+            __syncthreads();
+            for (int k = 0; k < 16; k++) m[b16 + k] = (uint8_t)((b16 + k) * 7 + rep);
+        }
         __syncthreads();
         // writes: lane owns 16 bytes at 61 * lane + rep; writes 8 + 4 + 2 + 1
         const uint32_t b = 61 * lane + rep;
