@@ -680,3 +680,49 @@ def test_frame_parallel_header_walk(built):
     assert m == text.numel() and torch.equal(back[:m], text)
     for x in (par, seq, c):
         x.close()
+
+
+def test_frame_decoder_output_larger_than_its_buffer(ctx):
+    """Highly compressible data: a batch of compressed chunks decodes to far
+    more than the decoder's output buffer (snapmi_frame_decode_host then
+    takes only as many chunks as fit and reports how far it got); also the
+    C call directly with a buffer of one and two chunks."""
+    import ctypes as C
+    from rust_snappy_amd import _lib, frame
+    data = bytes(40 << 20) + b"".join(d for _, d in O.corpus_round()) + \
+        b"ab" * (3 << 20)
+    f = O.frame_compress(data)
+    assert len(f) < len(data) // 8
+    for batch in (1 << 17, 1 << 20, frame.BATCH_BYTES):
+        dec = frame.FrameDecoder(io.BytesIO(f), ctx, batch_bytes=batch)
+        out = bytearray()
+        while True:
+            b = dec.read(1 << 20)
+            if not b:
+                break
+            out += b
+        assert bytes(out) == data, batch
+    # the C call with room for exactly one / two chunks at a time
+    for room in (65536, 131072 + 5):
+        pos, out, stale, cont = 0, bytearray(), bytearray(10), False
+        buf = bytearray(room)
+        while pos < len(f):
+            piece = f[pos:pos + (1 << 20)]
+            n, used, err = frame.decode_host(ctx, piece, buf, cont,
+                                             pos + len(piece) >= len(f), stale)
+            assert err is None and used > 0
+            assert n <= room // 65536 * 65536
+            out += buf[:n]
+            pos += used
+            cont = True
+        assert bytes(out) == data
+    # a buffer below one chunk: the identifier is consumed, then the call is
+    # refused (never an overrun)
+    import rust_snappy_amd as R
+    small = bytearray(1000)
+    n, used, err = frame.decode_host(ctx, f[:1 << 20], small, False, False,
+                                     bytearray(10))
+    assert (n, used, err) == (0, 10, None)
+    with pytest.raises(R.Error):
+        frame.decode_host(ctx, f[10:1 << 20], small, True, False,
+                          bytearray(10))
