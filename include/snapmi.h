@@ -120,6 +120,10 @@ const char *snapmi_version(void);
  * Tuning knobs (results never depend on them, only speed):
  *   "compress_mode"        0 wavefront-per-block kernel only, 1 lane-per-block
  *                          kernel on large batches (default), 2 both at once
+ *   "small_batch_kernel"   1 (default): batches of at most two blocks per
+ *                          CU run one block per CU with table AND input block
+ *                          in LDS; 0 never; 2 whenever the wavefront kernel
+ *                          would run
  *   "lane_min_blocks"      batches with at least this many 64 KiB blocks use
  *                          the lane-per-block kernel (default 8192)
  *   "lane_waves_per_cu"    lanes in flight = 64 x this x CUs (default 6)

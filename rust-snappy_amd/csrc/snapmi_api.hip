@@ -228,6 +228,9 @@ int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value)
     else if (strcmp(name, "lane_max_waves") == 0 && value >= 0 &&
              value <= 0x7FFFFFFF)
         ctx->lane_max_waves = (uint32_t)value;
+    else if (strcmp(name, "small_batch_kernel") == 0 && value >= 0 &&
+             value <= 2)
+        ctx->small_batch_kernel = (int)value;
     else if (strcmp(name, "frame_walk_segment") == 0 && value >= (128 << 10))
         ctx->frame_walk_segment = (uint64_t)value;
     else if (strcmp(name, "frame_parallel_walk_min") == 0 && value >= 0)
@@ -595,12 +598,27 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
             }
             // persistent: one 5-wave workgroup per CU (all of its LDS), each
             // wavefront pulls blocks from the back of the ticket
-            const uint64_t want =
-                (blocks + kCompressWaves - 1) / kCompressWaves;
-            const uint32_t wgs = (uint32_t)(
-                want < (uint64_t)ctx->num_cus ? want : ctx->num_cus);
-            hipLaunchKernelGGL(k_compress_blocks, dim3(wgs),
-                               dim3(kCompressWaves * 64), 0, ws, a);
+            // the smallest batches (no more than two blocks per CU: scalar
+            // calls, short frames) run one block per CU with the input block
+            // in LDS too - half the time per block, a fifth of the blocks in
+            // flight; five tables per CU from there
+            const bool lds_input =
+                ctx->small_batch_kernel == 2 ||
+                (ctx->small_batch_kernel == 1 &&
+                 blocks <= 2 * (uint64_t)ctx->num_cus);
+            if (lds_input) {
+                const uint32_t wgs = (uint32_t)(
+                    blocks < (uint64_t)ctx->num_cus ? blocks : ctx->num_cus);
+                hipLaunchKernelGGL(k_compress_block_lds, dim3(wgs), dim3(64),
+                                   0, ws, a);
+            } else {
+                const uint64_t want =
+                    (blocks + kCompressWaves - 1) / kCompressWaves;
+                const uint32_t wgs = (uint32_t)(
+                    want < (uint64_t)ctx->num_cus ? want : ctx->num_cus);
+                hipLaunchKernelGGL(k_compress_blocks, dim3(wgs),
+                                   dim3(kCompressWaves * 64), 0, ws, a);
+            }
         }
         if (lanes_mode) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev[4], s));

@@ -48,6 +48,8 @@
 // (after the varint); later blocks go to scratch slots and are moved into
 // place by k_compact once the sizes are known (reference Encoder::compress
 // concatenates them serially, src/compress.rs:128-153).
+#include <type_traits>
+
 #include "snapmi_device.hpp"
 #include "snapmi_kernels.hpp"
 
@@ -88,6 +90,23 @@ __device__ __forceinline__ B16 ld128u(gcptr p)
 {
     B16 v;
     __builtin_memcpy(&v, p, 16);
+    return v;
+}
+
+// the same loads from a copy of the block in LDS (k_compress_block_lds)
+typedef __attribute__((address_space(3))) uint8_t l_u8c;
+typedef const l_u8c *lcptr;
+__device__ __forceinline__ B16 ld128u(lcptr p)
+{
+    B16 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+using snapmi::ld32u; // (the global-memory overload of snapmi_device.hpp)
+__device__ __forceinline__ uint32_t ld32u(lcptr p)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
     return v;
 }
 
@@ -294,7 +313,8 @@ struct TokenSink {
 // Continue a match past its first 16 bytes: common prefix of src[c..] and
 // src[p..] bounded by the block end n, 256 bytes per wave instruction
 // (reference extend_match, src/compress.rs:378-412).
-__device__ __forceinline__ uint32_t extend_match(gcptr src, uint32_t n,
+template <class P>
+__device__ __forceinline__ uint32_t extend_match(P src, uint32_t n,
                                                  uint32_t c, uint32_t p,
                                                  uint32_t lane)
 {
@@ -342,11 +362,15 @@ __device__ __forceinline__ uint32_t extend_match(gcptr src, uint32_t n,
 
 } // namespace
 
-// One 64 KiB block, by one wavefront.
+// One 64 KiB block, by one wavefront.  kLds: the match finder reads the block
+// from a copy in LDS at `lblock` (filled here) instead of HBM / L2 - every
+// load on the per-copy dependency chain is then an LDS access.
+template <bool kLds>
 __device__ __forceinline__ void compress_one_block(
     const CompressArgs &a, const uint32_t b, const uint32_t lane,
     const lptr16 table, const uint32_t tbase, const uint32_t c2,
-    const uint32_t c3, const uint32_t cB, const uint32_t cBn)
+    const uint32_t c3, const uint32_t cB, const uint32_t cBn,
+    __attribute__((address_space(3))) uint8_t *lblock = nullptr)
 {
 
     // stream lookup: blk_first[st] <= b < blk_first[st + 1]
@@ -396,6 +420,24 @@ __device__ __forceinline__ void compress_one_block(
         if (lane == 0)
             a.blk_size[b] = out.d;
         return;
+    }
+    // what the match finder reads: the block itself, or its copy in LDS
+    typename std::conditional<kLds, lcptr, gcptr>::type msrc;
+    if constexpr (kLds) {
+        // 1 KiB per wave instruction, coalesced; the tail bytewise
+        typedef __attribute__((address_space(3))) u32x4 l_u32x4;
+        typedef __attribute__((address_space(1))) u32x4 g_u32x4c;
+        const uint32_t mis = (uint32_t)(uintptr_t)src & 15u; // 16-byte lines
+        l_u32x4 *to = (l_u32x4 *)lblock;
+        // LDS copy starts at the 16-byte line that holds src[0]
+        const g_u32x4c *from = (const g_u32x4c *)(src - mis);
+        const uint32_t lines = (n + mis + 15) / 16;
+        for (uint32_t i = lane; i < lines; i += kWave)
+            to[i] = from[i]; // (never past the line that holds the last byte)
+        __builtin_amdgcn_wave_barrier();
+        msrc = (lcptr)lblock + mis;
+    } else {
+        msrc = src;
     }
 
     // table sizing + zero fill: reference src/compress.rs:491-518
@@ -472,7 +514,7 @@ __device__ __forceinline__ void compress_one_block(
         }
         // issued after the window reads so that its latency overlaps the
         // hash, the LDS atomic and the candidate gather
-        const B16 x = ld128u(src + pc);
+        const B16 x = ld128u(msrc + pc);
         if (!(chain && q == 0)) {
             hx = x.w[0];
             // keep this a real (uniform) branch: as a select it would make
@@ -489,7 +531,7 @@ __device__ __forceinline__ void compress_one_block(
             cand = (old >> sh) & 0xFFFFu;
         }
         TICK(2);
-        const B16 y = ld128u(src + cand);
+        const B16 y = ld128u(msrc + cand);
         TICK(3);
         const uint32_t m = common16(x, y);
         // (cand < p always holds when the DS atomic applies lanes in ascending
@@ -514,7 +556,7 @@ __device__ __forceinline__ void compress_one_block(
         TICK(4);
         TICK(5);
         if (len == 16)
-            len += extend_match(src, n, ck + 16, pk + 16, lane);
+            len += extend_match(msrc, n, ck + 16, pk + 16, lane);
         TICK(6);
         // literal next_emit..pk (reference :250-257) + copy (:272-273)
         out.record(next_emit, pk - next_emit, pk - ck, len);
@@ -537,15 +579,15 @@ __device__ __forceinline__ void compress_one_block(
                     wv2 = wv3;
                     wbase += 64;
                     const uint32_t wp = wbase + 192 + lane;
-                    wv3 = ld32u(src + (wp < n - 4 ? wp : n - 4));
+                    wv3 = ld32u(msrc + (wp < n - 4 ? wp : n - 4));
                 } else {
                     wbase = s - 1;
                     const uint32_t w0 = wbase + lane;
                     const uint32_t n4 = n - 4;
-                    wv0 = ld32u(src + (w0 < n4 ? w0 : n4));
-                    wv1 = ld32u(src + (w0 + 64 < n4 ? w0 + 64 : n4));
-                    wv2 = ld32u(src + (w0 + 128 < n4 ? w0 + 128 : n4));
-                    wv3 = ld32u(src + (w0 + 192 < n4 ? w0 + 192 : n4));
+                    wv0 = ld32u(msrc + (w0 < n4 ? w0 : n4));
+                    wv1 = ld32u(msrc + (w0 + 64 < n4 ? w0 + 64 : n4));
+                    wv2 = ld32u(msrc + (w0 + 128 < n4 ? w0 + 128 : n4));
+                    wv3 = ld32u(msrc + (w0 + 192 < n4 ? w0 + 192 : n4));
                 }
             }
         }
@@ -694,12 +736,13 @@ __global__ __launch_bounds__(kCompressWaves * 64) void k_compress_blocks(
     {
         const uint32_t b = blockIdx.x * kCompressWaves + wave;
         if (b < nblocks)
-            compress_one_block(a, b, lane, table, tbase, c2, c3, cB, cBn);
+            compress_one_block<false>(a, b, lane, table, tbase, c2, c3, cB,
+                                      cBn);
     }
 #elif defined(SNAPMI_STRIDE)
     for (uint32_t b = blockIdx.x * kCompressWaves + wave; b < nblocks;
          b += gridDim.x * kCompressWaves)
-        compress_one_block(a, b, lane, table, tbase, c2, c3, cB, cBn);
+        compress_one_block<false>(a, b, lane, table, tbase, c2, c3, cB, cBn);
 #else
     // one ticket per wavefront per block
     // (the helper's result comes back in a VGPR: re-pin it to an SGPR so the
@@ -708,10 +751,48 @@ __global__ __launch_bounds__(kCompressWaves * 64) void k_compress_blocks(
     while (b != 0xFFFFFFFFu) {
         if (lane == 0 && a.ntok)
             a.ntok[b] = 0xFFFFFFFFu; // encoded here, not by k_encode_tokens
-        compress_one_block(a, b, lane, table, tbase, c2, c3, cB, cBn);
+        compress_one_block<false>(a, b, lane, table, tbase, c2, c3, cB, cBn);
         b = uni(next_ticket(a.ticket, lane, nblocks));
     }
 #endif
+}
+
+// ---------------------------------------------------------------------
+// K1 for the smallest batches: ONE wavefront per CU with the hash table AND
+// the 64 KiB input block in LDS (32 KiB + 64 KiB + a line of slack: one such
+// workgroup per CU).  Every load on the per-copy dependency chain - the hash
+// inputs, the candidate gather, the match extension - is an LDS access, so a
+// block finishes about twice as fast as in k_compress_blocks, where the
+// gather goes to L2 / HBM.  It is what BASELINE.json's north_star describes
+// ("one 64 KiB block per workgroup with the hash table and the input block
+// staged in LDS"); with one block per CU in flight it is the right kernel
+// only while the batch has no more blocks than a couple per CU (scalar calls,
+// small frames): five tables per CU win from there, a lane per block beyond.
+// ---------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_compress_block_lds(CompressArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t table_mem[kMaxTable];
+    __shared__ __attribute__((aligned(16))) uint8_t block_mem[kMaxBlock + 32];
+
+    const uint32_t lane = threadIdx.x;
+    const lptr16 table = (lptr16)&table_mem[0];
+    const uint32_t tbase = (uint32_t)(uintptr_t)table;
+    uint32_t nblocks = a.blk_first[a.n_streams];
+    if (nblocks > a.host_blocks)
+        nblocks = a.host_blocks;
+    const uint32_t c2 = lane >= 1 ? kDelta.d[lane - 1] : 0;
+    const uint32_t c3 = kDelta.d[lane];
+    const uint32_t cB = lane >= 2 ? 1 + kDelta.d[lane - 2] : lane - 1;
+    const uint32_t cBn = lane >= 2 ? 1 + c2 : 0;
+    uint32_t b = uni(next_ticket(a.ticket, lane, nblocks));
+    while (b != 0xFFFFFFFFu) {
+        if (lane == 0 && a.ntok)
+            a.ntok[b] = 0xFFFFFFFFu;
+        compress_one_block<true>(
+            a, b, lane, table, tbase, c2, c3, cB, cBn,
+            (__attribute__((address_space(3))) uint8_t *)block_mem);
+        b = uni(next_ticket(a.ticket, lane, nblocks));
+    }
 }
 
 // ---------------------------------------------------------------------

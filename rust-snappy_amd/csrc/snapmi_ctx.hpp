@@ -37,6 +37,10 @@ struct snapmi_ctx {
     // two-ended ticket (no faster: the wavefront kernel takes whole CUs' LDS
     // away from the lanes' input windows; kept as a cross-check)
     int compress_mode = 1;
+    // k_compress_block_lds (one block per CU, input block in LDS as well):
+    // 1 = for batches of at most two blocks per CU (default), 0 = never,
+    // 2 = whenever the wavefront kernel would run (tests)
+    int small_batch_kernel = 1;
     // 2: element-major decoder k_decompress_streams2 (default); 1: the
     // first-generation byte-per-lane kernel, kept as a cross-check
     int decode_kernel = 2;

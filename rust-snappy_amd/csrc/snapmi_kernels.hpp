@@ -75,6 +75,7 @@ __global__ void k_probe_tables(unsigned long long *tables,
                                unsigned long long stride, uint32_t steps);
 __global__ void k_plan_compress(CompressArgs a);
 __global__ void k_compress_blocks(CompressArgs a);
+__global__ void k_compress_block_lds(CompressArgs a);
 __global__ void k_match_blocks(CompressArgs a);
 __global__ void k_encode_tokens(CompressArgs a);
 __global__ void k_scan_sizes(CompressArgs a);

@@ -35,20 +35,25 @@ def ctx(request, built):
 
 
 @pytest.fixture(scope="session",
-                params=["waves", "lanes", "lanes_segmented", "both"])
+                params=["waves", "waves_lds", "lanes", "lanes_segmented",
+                        "both"])
 def cctx(request, built):
-    """A context per compressor kernel: the wavefront-per-block kernel, the
-    lane-per-block kernel (one launch, and split into segments of 64 blocks)
-    and both at once, each forced for every batch size, so every parity test
-    of the encoder runs through all of them."""
+    """A context per compressor kernel: the two wavefront-per-block kernels,
+    the lane-per-block kernel (one launch, and split into segments of 64
+    blocks) and both at once, each forced for every batch size, so every
+    parity test of the encoder runs through all of them."""
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import rust_snappy_amd as R
     c = R.raw.Context(0)
-    c.set_option("compress_mode", {"waves": 0, "lanes": 1,
+    c.set_option("compress_mode", {"waves": 0, "waves_lds": 0, "lanes": 1,
                                    "lanes_segmented": 1, "both": 2}[
         request.param])
+    # waves: five tables per CU, input from L2; waves_lds: one block per CU,
+    # table and input block in LDS (the kernel of the smallest batches)
+    c.set_option("small_batch_kernel", 2 if request.param == "waves_lds"
+                 else 0)
     c.set_option("lane_min_blocks", 1)
     if request.param == "lanes_segmented":
         c.set_option("lane_segment_blocks", 64)
