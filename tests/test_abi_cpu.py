@@ -158,3 +158,52 @@ def test_frame_scan_host_batches_and_stale_bytes(built):
     comp = bytes([0x00, 7, 0, 0]) + b"CRC!" + b"\x80\x81\x82"
     assert frame.scan_host(comp, True, stale)[0] == 0
     assert bytes(stale) == b"\x80\x81\x82\x00" + bytes(range(104, 110))
+
+
+def test_rust_shim_binds_only_exported_symbols(built):
+    """shim/ cannot be compiled here (no rustc); what can be checked is that
+    every `extern "C"` function it declares is exported by libsnapmi.so with
+    the same number of parameters as include/snapmi.h declares, and that its
+    error mapping names every snap::Error variant of the reference."""
+    import re
+    from rust_snappy_amd import _lib
+    L = _lib.load()
+    gpu = (ROOT / "shim" / "src" / "gpu.rs").read_text()
+    block = gpu[gpu.index('extern "C" {'):]
+    block = block[:block.index("\n}\n")]
+    decls = re.findall(r"pub fn (\w+)\s*\(([^;]*?)\)\s*(?:->\s*[\w:*<> ]+)?;",
+                       block, re.S)
+    assert len(decls) >= 10
+    header = (ROOT / "include" / "snapmi.h").read_text()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    for name, params in decls:
+        assert hasattr(L, name), f"shim binds {name}, not exported"
+        m = re.search(r"\b%s\s*\(([^;]*?)\)\s*;" % name, header, re.S)
+        assert m, f"{name} is not declared in include/snapmi.h"
+        n_rust = len([p for p in params.split(",") if p.strip()])
+        c_params = m.group(1).strip()
+        n_c = 0 if c_params in ("", "void") else len(c_params.split(","))
+        assert n_rust == n_c, (name, n_rust, n_c)
+    for variant in ("TooBig", "BufferTooSmall", "Empty", "Header",
+                    "HeaderMismatch", "Literal", "CopyRead", "CopyWrite",
+                    "Offset", "StreamHeader", "StreamHeaderMismatch",
+                    "UnsupportedChunkType", "UnsupportedChunkLength",
+                    "Checksum"):
+        assert f"Error::{variant}" in gpu, variant
+        assert variant in (ROOT / "shim" / "src" / "error.rs").read_text()
+    # the public surface of the reference (SURVEY 8b)
+    for f, items in (("raw.rs", ["pub fn max_compress_len",
+                                 "pub fn decompress_len", "pub struct Encoder",
+                                 "pub fn compress_vec", "pub struct Decoder",
+                                 "pub fn decompress_vec"]),
+                     ("write.rs", ["pub struct FrameEncoder", "pub fn into_inner",
+                                   "pub fn get_ref", "pub fn get_mut",
+                                   "impl<W: io::Write> io::Write for",
+                                   "impl<W: io::Write> Drop for"]),
+                     ("read.rs", ["pub struct FrameDecoder",
+                                  "pub struct FrameEncoder", "pub fn into_inner",
+                                  "impl<R: io::Read> io::Read for FrameDecoder",
+                                  "impl<R: io::Read> io::Read for FrameEncoder"])):
+        text = (ROOT / "shim" / "src" / f).read_text()
+        for item in items:
+            assert item in text, (f, item)
