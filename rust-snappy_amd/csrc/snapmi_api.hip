@@ -161,7 +161,15 @@ int snapmi_ctx_create(int device, void *hip_stream, snapmi_ctx **out)
             snapmi_ctx_destroy(ctx);
             return SNAPMI_E_DEVICE;
         }
-        ctx->lds_order_ok = ctx->lds_order_hw = bad == 0;
+        ctx->lds_order_ok = ctx->lds_order_hw = (bad & 1) == 0;
+        if (bad & 2) { // the element-major decoder needs ordered DS stores
+            ctx->lds_store_order_ok = false;
+            ctx->decode_kernel = 1;
+            fprintf(stderr,
+                    "snapmi: this device does not apply overlapping lanes of "
+                    "one DS store in ascending lane order; the byte-per-lane "
+                    "decoder is used\n");
+        }
         if (!ctx->lds_order_ok)
             fprintf(stderr,
                     "snapmi: this device does not apply the lanes of one DS "
@@ -236,7 +244,7 @@ int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value)
     else if (strcmp(name, "frame_parallel_walk_min") == 0 && value >= 0)
         ctx->frame_parallel_walk_min = (uint64_t)value;
     else if (strcmp(name, "decode_kernel") == 0 && value >= 1 && value <= 2)
-        ctx->decode_kernel = (int)value;
+        ctx->decode_kernel = ctx->lds_store_order_ok ? (int)value : 1;
     else if (strcmp(name, "lane_table_tries") == 0 && value >= 1 &&
              value <= 16)
         ctx->lane_table_tries = (uint32_t)value;

@@ -679,7 +679,39 @@ __global__ __launch_bounds__(64) void k_probe_lds_order(uint32_t *bad)
         __builtin_amdgcn_wave_barrier();
     }
     if (__ballot(fails != 0) != 0 && lane == 0)
-        *bad = 1;
+        atomicOr(bad, 1u);
+    // Second property (k_decompress_streams2): overlapping lanes of ONE plain
+    // DS store are applied in ascending lane order too, so a lane may store a
+    // whole 16 bytes for a shorter element and the lanes above it repair the
+    // excess.  64 layouts: lane strides 1..23 and pseudo-random gaps, every
+    // alignment.  bit 1 of *bad.
+    {
+        typedef __attribute__((address_space(3))) uint8_t l_u8;
+        l_u8 *m = (l_u8 *)tab; // 4 KiB
+        uint32_t sfail = 0;
+        for (uint32_t t = 0; t < 64; t++) {
+            const uint32_t gap =
+                t < 23 ? t + 1
+                       : 1 + ((lane * 2654435761u + t * 40503u) >> 7) % 20;
+            uint32_t pos = wave_inclusive_scan(gap) + 3 * t;
+            const uint32_t nextpos = (uint32_t)__builtin_amdgcn_ds_bpermute(
+                (int)(((lane + 1) & 63) << 2), (int)pos);
+            u32x4 x;
+            x.x = x.y = x.z = x.w = 0x01010101u * (lane + 1);
+            __builtin_amdgcn_wave_barrier();
+            __builtin_memcpy(m + pos, &x, 16);
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t k = 0; k < 16; k++) {
+                const uint32_t b = pos + k;
+                if ((lane == 63 || b < nextpos) &&
+                    m[b] != (uint8_t)(lane + 1))
+                    sfail++;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (__ballot(sfail != 0) != 0 && lane == 0)
+            atomicOr(bad, 2u);
+    }
 }
 
 // ---------------------------------------------------------------------

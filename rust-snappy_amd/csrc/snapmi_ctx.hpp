@@ -79,7 +79,10 @@ struct snapmi_ctx {
     // this device (checked by k_probe_lds_order at context creation); the
     // wavefront-per-block kernel is only used when this holds
     bool lds_order_ok = false;
-    bool lds_order_hw = false; // what the self-check found (the option can only lower it)
+    bool lds_order_hw = false;
+    // overlapping lanes of one plain DS store land in ascending lane order
+    // (same self-check): k_decompress_streams2 needs it
+    bool lds_store_order_ok = true; // what the self-check found (the option can only lower it)
     bool timing_valid = false;
     bool timing_is_compress = false;
     bool dominant_split = false; // ev[4]/ev[5] bracket k_match_blocks

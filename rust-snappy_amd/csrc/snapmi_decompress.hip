@@ -687,8 +687,10 @@ __global__ __launch_bounds__(64) void k_decompress_streams(DecompressArgs a)
 //      before the window (literals; copies from in front of it) is copied by
 //      its lane, 16 bytes per trip - source: the speculative literal bytes,
 //      the ring (two unaligned ds_read_b64), or HBM for what the ring no
-//      longer holds - and written to the ring with exactly its length
-//      (8 + 4 + 2 + 1 decomposition, unaligned DS stores);
+//      longer holds - and stored to the ring as WHOLE 16-byte pieces, last
+//      piece first: overlapping lanes of one DS store are applied in
+//      ascending lane order, so the excess bytes of a short element are
+//      overwritten by the elements that follow it;
 //   5. the few elements that read the window's own output (1.3 per window on
 //      the corpus) or repeat a short period are swept in stream order, each
 //      by the whole wave (lane k = byte k, k mod offset for overlaps);
@@ -967,7 +969,9 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
         // ---- 4. the lane-parallel copy step --------------------------------
         const uint32_t q = dstp - off;               // copy source (if cpy)
         const uint32_t n = olen < off ? olen : off;  // bytes a copy reads
-        const uint32_t dW = d + W;
+        // (whole 16-byte pieces are stored: up to 15 bytes behind the window's
+        // output may be clobbered too)
+        const uint32_t dW = d + W + 16;
         uint32_t safe_lo = dW > kRing2 ? dW - kRing2 : 0;
         safe_lo = safe_lo > ring_lo ? safe_lo : ring_lo;
         const bool ring_ok = q >= safe_lo;
@@ -984,9 +988,8 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
             olen <= 16 &&
 #endif
             ((is_lit && inner && lane + hd + pad <= rem) ||
-             (cpy && q + n <= d &&
-              (ring_ok ? (olen <= off || off >= 16)
-                       : (far_ok && olen <= off && pad <= dst_lim - q))));
+             (cpy && q + n <= d && olen <= off &&
+              (ring_ok || (far_ok && pad <= dst_lim - q))));
         const bool far = lw && cpy && !ring_ok;
         {
             const uint64_t farm = __ballot(far);
@@ -999,70 +1002,63 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
                     COUNT(n_fence);
                 }
             }
+            // Every lane stores WHOLE 16-byte pieces with one ds_write_b128:
+            // the bytes past an element's end land on the following elements,
+            // whose lanes are higher and whose stores of the same instruction
+            // therefore win (overlapping lanes of one DS store are applied in
+            // ascending lane order: tests/hw/lds_write_order.hip, checked at
+            // context creation).  The pieces go last to first, so the excess
+            // of an element's last piece is repaired by the first pieces of
+            // its successors, which are all written by the last trip.
+            const uint32_t top =
+                __ballot(lw && olen > 48)
+                    ? 48
+                    : (__ballot(lw && olen > 32)
+                           ? 32
+                           : (__ballot(lw && olen > 16) ? 16 : 0));
+            for (uint32_t c = top;; c -= 16) {
 #ifdef SNAPMI_DEC2_NOTRIP
-            if (0)
+                break;
 #endif
-            for (uint32_t c = 0;; c += 16) {
                 const bool act = lw && c < olen;
-                if (__ballot(act) == 0)
+                if (__ballot(act) != 0) {
+                    COUNT(n_trip);
+                    const uint32_t m = olen - c < 16 ? olen - c : 16;
+                    // source: 16 bytes from the literal, the ring, or HBM
+                    B16x v;
+                    v.lo = v.hi = 0;
+                    if (c == 0) {
+                        v = lit16;
+                    } else if (act && is_lit) {
+                        __builtin_memcpy(&v, src + s + lane + hd + c, 16);
+                    }
+                    if (farm && act && far)
+                        __builtin_memcpy(&v, dst + q + c, 16);
+                    if (act && cpy && ring_ok) {
+                        // (only the lanes that need it: the LDS serves a wave's
+                        // scattered unaligned reads a few lanes per cycle)
+                        v.lo = lds_ld64(rg + ((q + c) & (kRing2 - 1)));
+                        v.hi = lds_ld64(rg + ((q + c + 8) & (kRing2 - 1)));
+                    }
+                    const uint32_t wa = (dstp + c) & (kRing2 - 1);
+                    // (rare) the element's own bytes wrap around the ring's
+                    // end: those lanes store bytewise, after the others
+                    const bool strad = act && wa + m > kRing2;
+                    if (act && !strad)
+                        __builtin_memcpy(rg + wa, &v, 16); // may reach the mirror
+                    if (__ballot(strad) != 0 && strad) {
+                        for (uint32_t j = 0; j < m; j++) {
+                            const uint64_t part = j < 8 ? v.lo : v.hi;
+                            rg[(wa + j) & (kRing2 - 1)] =
+                                (uint8_t)(part >> (8 * (j & 7)));
+                        }
+                    }
+                    // ring[0,16) or its mirror behind the end were written
+                    if (__ballot(act && (wa < 16 || wa + 16 > kRing2)) != 0)
+                        R.mirror();
+                }
+                if (c == 0)
                     break;
-                COUNT(n_trip);
-                const uint32_t m = olen - c < 16 ? olen - c : 16;
-                // source: 16 bytes from the literal, the ring, or HBM
-                B16x v;
-                v.lo = v.hi = 0;
-                if (c == 0) {
-                    v = lit16;
-                } else if (act && is_lit) {
-                    __builtin_memcpy(&v, src + s + lane + hd + c, 16);
-                }
-                if (farm && act && far)
-                    __builtin_memcpy(&v, dst + q + c, 16);
-                if (act && cpy && ring_ok) {
-                    // (only the lanes that need it: the LDS serves a wave's
-                    // scattered unaligned reads a few lanes per cycle)
-                    v.lo = lds_ld64(rg + ((q + c) & (kRing2 - 1)));
-                    v.hi = lds_ld64(rg + ((q + c + 8) & (kRing2 - 1)));
-                }
-                // destination: exactly m bytes at the element's position
-                const uint32_t wa = (dstp + c) & (kRing2 - 1);
-                const bool strad = act && wa + m > kRing2;
-                if (act && !strad) {
-                    l_u8 *p = rg + wa;
-                    uint64_t lo = v.lo, hi = v.hi;
-                    if (m & 16) {
-                        lds_st64(p, lo);
-                        lds_st64(p + 8, hi);
-                    }
-                    if (m & 8) {
-                        lds_st64(p, lo);
-                        p += 8;
-                        lo = hi;
-                    }
-                    if (m & 4) {
-                        lds_st32(p, (uint32_t)lo);
-                        p += 4;
-                        lo >>= 32;
-                    }
-                    if (m & 2) {
-                        lds_st16(p, (uint16_t)lo);
-                        p += 2;
-                        lo >>= 16;
-                    }
-                    if (m & 1)
-                        *p = (uint8_t)lo;
-                }
-                if (__ballot(strad) != 0 && strad) {
-                    // (rare) the write wraps around the ring's end: bytewise
-                    for (uint32_t j = 0; j < m; j++) {
-                        const uint64_t part = j < 8 ? v.lo : v.hi;
-                        rg[(wa + j) & (kRing2 - 1)] =
-                            (uint8_t)(part >> (8 * (j & 7)));
-                    }
-                }
-                // a write reached ring[0,16): mirror it behind the end
-                if (__ballot(act && (wa < 16 || strad)) != 0)
-                    R.mirror();
             }
         }
         // ---- 5. the sweep: elements that depend on this window -------------

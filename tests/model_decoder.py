@@ -179,15 +179,16 @@ def decode(comp, stats=None):
         # byte k), so every source is complete when its element's turn comes.
         q = dstp - off                       # copy source position
         n = np.minimum(olen, off)            # source bytes a copy reads
-        safe_lo = max(ring_lo, d + W - R)    # ring history that no write of
-        ring_ok = q >= safe_lo               # this window can clobber
+        # (a lane stores whole 16-byte pieces: up to 15 bytes past the
+        # window's output may be clobbered as well)
+        safe_lo = max(ring_lo, d + W + 16 - R)   # ring history that no write
+        ring_ok = q >= safe_lo                   # of this window can clobber
         far_ok = q + n <= gflush
         pad = (olen + 15) & ~15              # 16-byte loads stay in bounds
         lanewise = keep & np.where(
             is_lit, inner & (LANE + hd + pad <= rem),
-            (q + n <= d) & np.where(ring_ok, (olen <= off) | (off >= 16),
-                                    far_ok & (olen <= off) &
-                                    (q + pad <= dst_len)))
+            (q + n <= d) & (olen <= off) &
+            np.where(ring_ok, True, far_ok & (q + pad <= dst_len)))
         far = lanewise & ~is_lit & ~ring_ok
 
         def fence_for(limit):
@@ -201,23 +202,43 @@ def decode(comp, stats=None):
         if far.any():
             st.far += int(far.sum())
             fence_for(int((q + n)[far].max()))
+        # Every lane stores WHOLE 16-byte pieces with one DS instruction; the
+        # bytes past an element's end land on the following elements, whose
+        # lanes are higher and whose stores of the same instruction therefore
+        # win (tests/hw/lds_write_order.hip).  The pieces go last to first,
+        # so the excess of an element's last piece is repaired by the first
+        # pieces of its successors, which are written in the last trip.
         cmax = int(((olen[lanewise] + 15) // 16).max()) if lanewise.any() else 0
-        for c in range(cmax):
+        for c in range(cmax - 1, -1, -1):
             act = lanewise & (16 * c < olen)
-            for i in LANE[act]:
-                m = min(int(olen[i]) - 16 * c, 16)
+            reads = {}
+            for i in LANE[act]:              # all loads of the trip first
                 if is_lit[i]:
                     a = s + i + int(hd[i]) + 16 * c
                     assert a + 16 <= src_len
-                    data = src[a:a + 16]
+                    reads[i] = src[a:a + 16].copy()
                 elif ring_ok[i]:
-                    data = ring_read16(int(q[i]) + 16 * c)
+                    reads[i] = ring_read16(int(q[i]) + 16 * c)
                 else:
                     a = int(q[i]) + 16 * c
                     assert a + 16 <= dst_len
-                    data = out[a:a + 16]
-                ring_write(int(dstp[i]) + 16 * c, data[:m])
-            mirror()
+                    reads[i] = out[a:a + 16].copy()
+            touched = False
+            for i in LANE[act]:              # one store instruction, lanes
+                m = min(int(olen[i]) - 16 * c, 16)   # in ascending order
+                wa = (int(dstp[i]) + 16 * c) & (R - 1)
+                if wa + m > R:
+                    continue                 # the element's bytes wrap: below
+                ring[wa:wa + 16] = reads[i]  # may spill into the mirror
+                touched |= wa < 16 or wa + 16 > R
+            for i in LANE[act]:              # (rare) exact, bytewise, wrapped
+                m = min(int(olen[i]) - 16 * c, 16)
+                wa = (int(dstp[i]) + 16 * c) & (R - 1)
+                if wa + m > R:
+                    ring_write(int(dstp[i]) + 16 * c, reads[i][:m])
+                    touched = True
+            if touched:
+                mirror()
         st.rounds += 1
         for i in LANE[keep & ~lanewise]:     # the sweep, in stream order
             st.wide += 1

@@ -297,6 +297,21 @@ def test_hw_lds_unaligned_access(built):
     assert "PASS unaligned DS access is bytewise" in out, out
 
 
+def test_hw_lds_store_lane_order(built):
+    """k_decompress_streams2 lets a lane store a whole 16 bytes for a shorter
+    element: the lanes above it (the following elements) must win where the
+    ranges overlap, i.e. one DS store instruction must apply its lanes in
+    ascending order (tests/hw/lds_write_order.hip; also self-checked at
+    context creation, which falls back to the byte-per-lane decoder)."""
+    import subprocess
+    from conftest import ROOT
+    exe = ROOT / "tests" / "hw" / "lds_write_order"
+    assert exe.exists(), "run __graft_entry__.build() first"
+    out = subprocess.run([str(exe)], capture_output=True, text=True,
+                         timeout=60).stdout
+    assert "PASS overlapping stores" in out, out
+
+
 def test_decode_streams_that_end_at_the_allocation_end(ctx):
     """Compressed input and decoded output both end exactly where their
     device allocations end: the decoder's 16-byte loads (speculative literal
