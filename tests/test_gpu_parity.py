@@ -195,6 +195,54 @@ def test_decompress_corrupt_never_faults_and_matches_oracle(ctx):
             assert (oe.kind, oe.a, oe.b, oe.c) == e, (e, oe)
 
 
+def test_decompress_fuzz_against_oracle(ctx):
+    """2 400 mutated streams in one batch - corpus files, RLE, incompressible
+    data and foreign-encoder streams (copy-4, far offsets, overlapping copies,
+    non-minimal literal lengths), each with 1-6 bytes changed, bytes inserted
+    or removed, or truncated: the decoded bytes or the error variant with all
+    its fields must be the oracle's, stream by stream."""
+    import foreign
+    rng = random.Random(77)
+    rnd = O.corpus_round()
+    base = [O.compress(d[:200000]) for _, d in rnd]
+    base += [O.compress(bytes(70000)), O.compress(b"abcd" * 30000),
+             O.compress(bytes(rng.randrange(256) for _ in range(70000)))]
+    base += [c for c, _ in foreign.cases()[:6]]
+    muts = []
+    for _ in range(2400):
+        b = bytearray(rng.choice(base))
+        kind = rng.random()
+        if kind < 0.6:
+            for _ in range(rng.randrange(1, 7)):
+                b[rng.randrange(len(b))] = rng.randrange(256)
+        elif kind < 0.75:
+            p = rng.randrange(len(b))
+            b[p:p] = bytes(rng.randrange(256) for _ in range(rng.randrange(1, 5)))
+        elif kind < 0.9:
+            p = rng.randrange(len(b))
+            del b[p:p + rng.randrange(1, 5)]
+        else:
+            b = b[:rng.randrange(1, len(b))]
+        muts.append(bytes(b))
+    caps = []
+    for m in muts:
+        try:
+            caps.append(min(O.decompress_len(m), 1 << 20))
+        except O.SnapError:
+            caps.append(1024)
+    got, errs = gpu_decompress(ctx, muts, caps)
+    bad = ok = 0
+    for m, cap, g, e in zip(muts, caps, got, errs):
+        try:
+            want = O.decompress(m, cap)
+            assert e[0] == 0 and g == want
+            ok += 1
+        except O.SnapError as oe:
+            assert (oe.kind, oe.a, oe.b, oe.c) == e, (e, oe)
+            bad += 1
+    assert bad > 1000 and ok > 20      # both outcomes are well represented
+
+
 def test_buffer_too_small_batch(ctx):
     from rust_snappy_amd import batch
     import torch
