@@ -726,3 +726,27 @@ def test_frame_decoder_output_larger_than_its_buffer(ctx):
     with pytest.raises(R.Error):
         frame.decode_host(ctx, f[10:1 << 20], small, True, False,
                           bytearray(10))
+
+
+def test_frame_compress_chunks_on_device_buffers(ctx):
+    """snapmi_frame_compress_chunks with device-resident input: chunk
+    boundaries chosen by the caller (here: what a reader with short reads
+    gives read::FrameEncoder), with and without the stream identifier."""
+    from rust_snappy_amd import frame
+    data = (O.CORPUS / "lcet10.txt").read_bytes()[:300000]
+    rng = random.Random(2)
+    lens, left = [], len(data)
+    while left:
+        n = min(left, rng.choice([1, 17, 4096, 65535, 65536]))
+        lens.append(n)
+        left -= n
+    chunks, pos = [], 0
+    for n in lens:
+        chunks.append(data[pos:pos + n])
+        pos += n
+    want = frame_of_chunks(chunks)
+    d_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    out, n = frame.compress_chunks_device(ctx, d_in, lens, ident=True)
+    assert out[:n].cpu().numpy().tobytes() == want
+    out, n = frame.compress_chunks_device(ctx, d_in, lens, ident=False)
+    assert out[:n].cpu().numpy().tobytes() == want[10:]
