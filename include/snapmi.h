@@ -4,7 +4,7 @@
  * This is the drop-in boundary for the hot path of BurntSushi/rust-snappy:
  *   snap::raw::Encoder::compress   (reference src/compress.rs:99-154)
  *   snap::raw::Decoder::decompress (reference src/decompress.rs:75-95)
- * and the functions beside them.  Three groups of entry points:
+ * and the functions beside them.  Groups of entry points:
  *
  *  1. The libsnappy C API (snappy-c.h) -- exactly the symbols the reference's
  *     own native seam binds (snappy-cpp/src/lib.rs:66-88, linked by
@@ -13,9 +13,14 @@
  *     run against the GPU codec unchanged.
  *  2. Scalar mirrors of snap::raw::* that carry the full snap::Error
  *     (variant + fields, reference src/error.rs:72-180) across the ABI.
- *  3. The batched, device-resident API the Rust shim / a GPU pipeline calls:
- *     arrays of independent raw streams in HBM in, arrays of compressed
- *     streams in HBM out.  This is the form that is benchmarked.
+ *  3. The batched, device-resident API a GPU pipeline calls: arrays of
+ *     independent raw streams in HBM in, arrays of compressed streams in HBM
+ *     out.  This is the form that is benchmarked.
+ *  4. The Snappy frame format (reference src/frame.rs, src/crc32.rs,
+ *     src/write.rs, src/read.rs): on device buffers (asynchronous), and on
+ *     host buffers one batch of chunks per call - what a host-language
+ *     FrameEncoder / FrameDecoder (shim/, rust-snappy_amd/frame.py,
+ *     tools/szip.cpp) makes per batch.
  *
  * Plain pointers and sizes only; no C++ or torch types.  All functions are
  * blocking unless stated otherwise.  Every compute entry point runs HIP
