@@ -134,6 +134,11 @@ const char *snapmi_version(void);
  *   "lane_waves_per_cu"    lanes in flight = 64 x this x CUs (default 6)
  *   "lane_segment_blocks"  blocks per lane-kernel launch (default 262144 =
  *                          16 GiB of input; bounds the token scratch)
+ *   "lane_overlap_encode"  0 (default) never; 1: a lane-kernel segment with
+ *                          at least 1.4 blocks per lane is matched in two
+ *                          halves, the first half's tokens encoded on a side
+ *                          stream meanwhile (measured slower); 2: whenever it
+ *                          has two blocks (tests)
  *   "lane_table_spread"    1 (default): the lane kernel's hash tables are
  *                          spread over up to 4x their size, within a third of
  *                          the free device memory (HBM sustains more random

@@ -236,6 +236,9 @@ int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value)
     else if (strcmp(name, "lane_max_waves") == 0 && value >= 0 &&
              value <= 0x7FFFFFFF)
         ctx->lane_max_waves = (uint32_t)value;
+    else if (strcmp(name, "lane_overlap_encode") == 0 && value >= 0 &&
+             value <= 2)
+        ctx->lane_overlap_encode = (int)value;
     else if (strcmp(name, "small_batch_kernel") == 0 && value >= 0 &&
              value <= 2)
         ctx->small_batch_kernel = (int)value;
@@ -424,6 +427,7 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     a.lane_epochs = nullptr;
     a.lane_stride = kMaxTable;
     a.n_lanes = 0;
+    a.tok_base = 0;
     // Small batches are latency-bound: the wavefront kernel finishes a block
     // in ~2 ms, a lane needs tens of ms.  Large batches are throughput-bound
     // and go to the lane-per-block kernel.
@@ -633,22 +637,55 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
             for (uint64_t lo = 0; lo < blocks; lo += seg_blocks) {
                 const uint64_t hi =
                     lo + seg_blocks < blocks ? lo + seg_blocks : blocks;
+                // Option lane_overlap_encode (off by default): the segment is
+                // matched in two halves and the first half's tokens are
+                // encoded on the side stream while the second half is
+                // matched.  Two halves alone cost the match finder nothing
+                // (114.2 vs 115 ms), but the encoder's streaming traffic under
+                // it does: 121.6 -> 135 ms at cfg2.  Kept as a measured dead
+                // end that the encoder tests still run through.
+                uint64_t mid = hi;
+                if (!waves_mode &&
+                    (ctx->lane_overlap_encode == 2
+                         ? hi - lo >= 2
+                         : (ctx->lane_overlap_encode == 1 &&
+                            (hi - lo) * 10 >= (uint64_t)a.n_lanes * 14)))
+                    mid = lo + (hi - lo) / 2;
+                a.tok_base = (uint32_t)lo;
                 a.blk_lo = (uint32_t)lo;
-                a.blk_hi = (uint32_t)hi;
+                a.blk_hi = (uint32_t)mid;
                 if (!waves_mode) // (shared with the wavefront kernel if on)
                     HIP_TRY(ctx, hipMemsetAsync(ctx->ticket.p, 0, 64, s));
                 hipLaunchKernelGGL(k_match_blocks, dim3(a.n_lanes / 64),
                                    dim3(64), 0, s, a);
+                if (mid < hi) {
+                    HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
+                    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2,
+                                                    ctx->ev_fork, 0));
+                    hipLaunchKernelGGL(k_encode_tokens,
+                                       dim3((uint32_t)(mid - lo)), dim3(64),
+                                       0, ctx->stream2, a);
+                    HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+                    a.blk_lo = (uint32_t)mid;
+                    a.blk_hi = (uint32_t)hi;
+                    HIP_TRY(ctx, hipMemsetAsync(ctx->ticket.p, 0, 64, s));
+                    hipLaunchKernelGGL(k_match_blocks, dim3(a.n_lanes / 64),
+                                       dim3(64), 0, s, a);
+                }
                 if (hi == blocks) // dominant_ms: first match start .. last end
                     HIP_TRY(ctx, hipEventRecord(ctx->ev[5], s));
                 if (waves_mode) {
                     HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
                     HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
                 }
-                hipLaunchKernelGGL(k_encode_tokens, dim3((uint32_t)(hi - lo)),
-                                   dim3(64), 0, s, a);
+                hipLaunchKernelGGL(k_encode_tokens,
+                                   dim3((uint32_t)(hi - a.blk_lo)), dim3(64),
+                                   0, s, a);
+                if (mid < hi) // the side stream's half is done as well
+                    HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
             }
             a.blk_lo = 0;
+            a.tok_base = 0;
             a.blk_hi = (uint32_t)blocks;
         }
     }

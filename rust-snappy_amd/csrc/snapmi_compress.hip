@@ -938,7 +938,8 @@ __global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
                 src = (gcptr)a.in_ptrs[lo] + boff;
                 n = total - boff < kMaxBlock ? (uint32_t)(total - boff)
                                              : kMaxBlock;
-                tok = (g_u64 *)a.tokens + (uint64_t)(b - a.blk_lo) * kMaxTokens;
+                tok = (g_u64 *)a.tokens +
+                      (uint64_t)(b - a.tok_base) * kMaxTokens;
                 ntok = 0;
                 next_emit = 0;
                 have = true;
@@ -1210,7 +1211,7 @@ __global__ __launch_bounds__(64) void k_encode_tokens(CompressArgs a)
     out.init(src, n, dst, lane);
     typedef __attribute__((address_space(1))) unsigned long long g_u64;
     const g_u64 *tok =
-        (const g_u64 *)a.tokens + (uint64_t)(b - a.blk_lo) * kMaxTokens;
+        (const g_u64 *)a.tokens + (uint64_t)(b - a.tok_base) * kMaxTokens;
     const uint32_t count = a.ntok[b];
     uint32_t pos_base = 0;
     for (uint32_t t0 = 0; t0 < count; t0 += kWave) {

@@ -41,6 +41,13 @@ struct snapmi_ctx {
     // 1 = for batches of at most two blocks per CU (default), 0 = never,
     // 2 = whenever the wavefront kernel would run (tests)
     int small_batch_kernel = 1;
+    // the lane kernel's segment is matched in two halves and the first
+    // half's tokens are encoded on the side stream meanwhile: 1 = when the
+    // segment has at least 1.4 blocks per lane, 0 = never (default: measured
+    // SLOWER, 121.6 -> 135 ms at cfg2 - the encoder's streaming traffic under
+    // the match finder costs its random accesses far more than the 3.3 ms
+    // it hides), 2 = whenever the segment has two blocks (tests)
+    int lane_overlap_encode = 0;
     // 2: element-major decoder k_decompress_streams2 (default); 1: the
     // first-generation byte-per-lane kernel, kept as a cross-check
     int decode_kernel = 2;

@@ -31,6 +31,7 @@ struct CompressArgs {
     unsigned long long *tokens; // [(blk_hi - blk_lo) * kMaxTokens]
     uint32_t *ntok;             // [blocks]
     uint32_t blk_lo, blk_hi;    // blocks this lane/encode launch covers
+    uint32_t tok_base;          // block whose tokens lie at tokens[0]
     unsigned long long *lane_tables; // lane g: 16-byte entries from g * lane_stride
     unsigned long long lane_stride;  // >= kMaxTable (tables are spread out)
     uint32_t *lane_epochs;      // [lanes]

@@ -36,7 +36,7 @@ def ctx(request, built):
 
 @pytest.fixture(scope="session",
                 params=["waves", "waves_lds", "lanes", "lanes_segmented",
-                        "both"])
+                        "lanes_overlap", "both"])
 def cctx(request, built):
     """A context per compressor kernel: the two wavefront-per-block kernels,
     the lane-per-block kernel (one launch, and split into segments of 64
@@ -48,7 +48,8 @@ def cctx(request, built):
     import rust_snappy_amd as R
     c = R.raw.Context(0)
     c.set_option("compress_mode", {"waves": 0, "waves_lds": 0, "lanes": 1,
-                                   "lanes_segmented": 1, "both": 2}[
+                                   "lanes_segmented": 1, "lanes_overlap": 1,
+                                   "both": 2}[
         request.param])
     # waves: five tables per CU, input from L2; waves_lds: one block per CU,
     # table and input block in LDS (the kernel of the smallest batches)
@@ -57,5 +58,8 @@ def cctx(request, built):
     c.set_option("lane_min_blocks", 1)
     if request.param == "lanes_segmented":
         c.set_option("lane_segment_blocks", 64)
+    # matched in two halves, the first half encoded on the side stream
+    c.set_option("lane_overlap_encode",
+                 2 if request.param == "lanes_overlap" else 0)
     yield c
     c.close()
