@@ -104,6 +104,8 @@ int snapmi_ctx_create(int device, void *hip_stream, snapmi_ctx **out)
             const long v = atol(e);
             ctx->lane_min_blocks = (uint32_t)(v < 1 ? 1 : v);
         }
+        if (const char *e = getenv("SNAPMI_FRAME_CRC_SIDE"))
+            ctx->frame_crc_side_stream = atoi(e) != 0;
         if (const char *e = getenv("SNAPMI_DECODE_KERNEL"))
             ctx->decode_kernel = atoi(e) == 1 ? 1 : 2;
         if (const char *m = getenv("SNAPMI_COMPRESS"))
@@ -236,6 +238,9 @@ int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value)
     else if (strcmp(name, "lane_max_waves") == 0 && value >= 0 &&
              value <= 0x7FFFFFFF)
         ctx->lane_max_waves = (uint32_t)value;
+    else if (strcmp(name, "frame_crc_side_stream") == 0 && value >= 0 &&
+             value <= 1)
+        ctx->frame_crc_side_stream = value != 0;
     else if (strcmp(name, "lane_overlap_encode") == 0 && value >= 0 &&
              value <= 2)
         ctx->lane_overlap_encode = (int)value;

@@ -54,6 +54,7 @@ struct snapmi_ctx {
     hipStream_t stream2 = nullptr; // the wavefront kernel's side stream
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_crc[2] = {nullptr, nullptr}; // frame encode: CRC on stream2
+    bool frame_crc_side_stream = true;
     // staging for the host-pointer (scalar) entry points
     snapmi::DevBuf st_in, st_out, st_desc, st_prof, ticket, order;
     // long-stream decode scratch (snapmi_decompress_stream)

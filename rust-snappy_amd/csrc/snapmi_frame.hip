@@ -1012,18 +1012,23 @@ static int frame_compress_impl(snapmi_ctx *ctx, const void *d_in,
         // the CRC into the match finder's own block loads would add ~380
         // vector instructions per 128-byte line to a loop of ~150 per round
         // to save a kernel of 1 % of the pass: not done.
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_crc[0], s));
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_crc[0], 0));
-        hipLaunchKernelGGL(k_crc32c, dim3(cnt), dim3(64), 0, ctx->stream2,
-                           a.in_ptrs, a.in_lens, a.crcs, cnt,
-                           (const CrcTables *)ctx->fr_tables.p);
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_crc[1], ctx->stream2));
+        const bool side = ctx->frame_crc_side_stream;
+        if (side) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_crc[0], s));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_crc[0], 0));
+        }
+        hipLaunchKernelGGL(k_crc32c, dim3(cnt), dim3(64), 0,
+                           side ? ctx->stream2 : s, a.in_ptrs, a.in_lens,
+                           a.crcs, cnt, (const CrcTables *)ctx->fr_tables.p);
+        if (side)
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_crc[1], ctx->stream2));
         // every chunk is a one-block raw stream: cnt blocks, no scratch slots
         rc = launch_compress(ctx, a.in_ptrs, a.in_lens, a.slot_ptrs, nullptr,
                              a.clens, nullptr, cnt, cnt, 0);
         if (rc)
             return rc;
-        HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_crc[1], 0));
+        if (side)
+            HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_crc[1], 0));
         hipLaunchKernelGGL(k_frame_sizes, dim3(gb), dim3(tb), 0, s, a);
         hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, s, a.sizes,
                            a.offs, cnt);
