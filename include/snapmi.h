@@ -134,6 +134,10 @@ const char *snapmi_version(void);
  *   "lane_waves_per_cu"    lanes in flight = 64 x this x CUs (default 6)
  *   "lane_segment_blocks"  blocks per lane-kernel launch (default 262144 =
  *                          16 GiB of input; bounds the token scratch)
+ *   "lane_direct_encode"   1 (default): the lane kernel's encoder writes every
+ *                          block at its final position (the match finder adds
+ *                          up the encoded sizes); 0: scratch slot per block +
+ *                          a compaction pass, as the wavefront kernel needs
  *   "lane_overlap_encode"  0 (default) never; 1: a lane-kernel segment with
  *                          at least 1.4 blocks per lane is matched in two
  *                          halves, the first half's tokens encoded on a side

@@ -106,6 +106,8 @@ int snapmi_ctx_create(int device, void *hip_stream, snapmi_ctx **out)
         }
         if (const char *e = getenv("SNAPMI_FRAME_CRC_SIDE"))
             ctx->frame_crc_side_stream = atoi(e) != 0;
+        if (const char *e = getenv("SNAPMI_LANE_DIRECT"))
+            ctx->lane_direct_encode = atoi(e) != 0;
         if (const char *e = getenv("SNAPMI_DECODE_KERNEL"))
             ctx->decode_kernel = atoi(e) == 1 ? 1 : 2;
         if (const char *m = getenv("SNAPMI_COMPRESS"))
@@ -241,6 +243,9 @@ int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value)
     else if (strcmp(name, "frame_crc_side_stream") == 0 && value >= 0 &&
              value <= 1)
         ctx->frame_crc_side_stream = value != 0;
+    else if (strcmp(name, "lane_direct_encode") == 0 && value >= 0 &&
+             value <= 1)
+        ctx->lane_direct_encode = (int)value;
     else if (strcmp(name, "lane_overlap_encode") == 0 && value >= 0 &&
              value <= 2)
         ctx->lane_overlap_encode = (int)value;
@@ -406,7 +411,6 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
         (rc = reserve(ctx, ctx->slot_first, (n + 1) * sizeof(uint32_t))) ||
         (rc = reserve(ctx, ctx->blk_size, (blocks + 1) * sizeof(uint32_t))) ||
         (rc = reserve(ctx, ctx->blk_off, (blocks + 2) * sizeof(uint64_t))) ||
-        (rc = reserve(ctx, ctx->slots, (slots + 1) * (size_t)kSlotBytes)) ||
         (rc = reserve(ctx, ctx->ticket, 64)))
         return rc;
 
@@ -421,7 +425,6 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     a.slot_first = (uint32_t *)ctx->slot_first.p;
     a.blk_size = (uint32_t *)ctx->blk_size.p;
     a.blk_off = (uint64_t *)ctx->blk_off.p;
-    a.scratch = (uint8_t *)ctx->slots.p;
     a.n_streams = (uint32_t)n;
     a.host_blocks = (uint32_t)blocks;
     a.host_slots = (uint32_t)slots;
@@ -450,6 +453,17 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
         blocks > 0 && ctx->lds_order_ok &&
         (!lanes_mode || ctx->compress_mode == 0 ||
          (ctx->compress_mode == 2 && seg_blocks == blocks));
+    // The lane kernel knows every block's encoded size before a byte of it
+    // is written, so its encoder puts the blocks where they belong; only the
+    // wavefront kernel (which encodes while it matches) needs a scratch slot
+    // per block and the k_compact pass.
+    const bool direct = lanes_mode && !waves_mode && ctx->lane_direct_encode &&
+                        ctx->lane_overlap_encode == 0;
+    a.direct = direct ? 1 : 0;
+    if (!direct &&
+        (rc = reserve(ctx, ctx->slots, (slots + 1) * (size_t)kSlotBytes)))
+        return rc;
+    a.scratch = (uint8_t *)ctx->slots.p;
     a.blk_lo = 0;
     a.blk_hi = (uint32_t)blocks;
     if (lanes_mode) {
@@ -683,6 +697,9 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                     HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
                     HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
                 }
+                if (direct)
+                    hipLaunchKernelGGL(k_scan_sizes, dim3(1), dim3(1024), 0,
+                                       s, a);
                 hipLaunchKernelGGL(k_encode_tokens,
                                    dim3((uint32_t)(hi - a.blk_lo)), dim3(64),
                                    0, s, a);
@@ -695,7 +712,10 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
         }
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], s));
-    if (blocks) {
+    if (blocks && direct) {
+        hipLaunchKernelGGL(k_stream_lens, dim3((uint32_t)((n + 255) / 256)),
+                           dim3(256), 0, s, a);
+    } else if (blocks) {
         hipLaunchKernelGGL(k_scan_sizes, dim3(1), dim3(1024), 0, s, a);
         hipLaunchKernelGGL(k_compact, dim3((uint32_t)blocks), dim3(256), 0,
                            s, a);

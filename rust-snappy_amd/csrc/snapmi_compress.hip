@@ -161,6 +161,22 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
 // A token with neither literal nor copy is never recorded, so the pattern
 // "both zero" encodes the one length that does not fit 16 bits: a 65536-byte
 // literal (a whole block without a single match).
+// Encoded size of one token = literal of L bytes, then a copy of C bytes at
+// offset O (C = 0: none): reference emit_literal (src/compress.rs:433-474)
+// and emit_copy (:323-369).  The match finder adds these up per block so the
+// encoder can write every block at its final position.
+__device__ __forceinline__ uint32_t token_bytes(uint32_t L, uint32_t C,
+                                                uint32_t O)
+{
+    const uint32_t lt = L == 0 ? 0 : (L <= 60 ? 1 : (L <= 256 ? 2 : 3));
+    const uint32_t n64 = C >= 68 ? (C - 4) >> 6 : 0;
+    const uint32_t rem = C - (n64 << 6);
+    const uint32_t mid = rem > 64 ? 1 : 0;
+    const uint32_t fin_len = rem - 60 * mid;
+    const uint32_t fin = C == 0 ? 0 : (fin_len <= 11 && O <= 2047 ? 2 : 3);
+    return lt + L + 3 * (n64 + mid) + fin;
+}
+
 struct TokenSink {
     gcptr src;          // block input
     uint32_t n;         // block length
@@ -909,6 +925,7 @@ __global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
     uint32_t s = 0, s_next = 0, skip = 0, next_emit = 0;
     uint32_t mpos = 0, mcand = 0, p = 0, c = 0; // the open match
     uint32_t ntok = 0;
+    uint32_t csize = 0; // encoded bytes of the block's tokens so far
     // input window: the bytes [hi - 256, hi) of the 128-byte aligned view of
     // the block (src_al = src - mis) are in `win`, at their offset mod 256
     uint32_t mis = 0, hi = 0;
@@ -941,11 +958,13 @@ __global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
                 tok = (g_u64 *)a.tokens +
                       (uint64_t)(b - a.tok_base) * kMaxTokens;
                 ntok = 0;
+                csize = 0;
                 next_emit = 0;
                 have = true;
                 if (n < kMinNonLiteral) { // src/compress.rs:140-146
                     tok[0] = (unsigned long long)n;
                     a.ntok[b] = 1;
+                    a.blk_size[b] = token_bytes(n, 0, 0);
                     have = false;
                 } else {
                     // fresh table = new epoch (src/compress.rs:491-518)
@@ -1120,6 +1139,19 @@ __global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
                               ((unsigned long long)(mend - mpos) << 17) |
                               ((unsigned long long)(mpos - mcand) << 33);
             ntok++;
+#ifndef SNAPMI_NO_CSIZE // (ablation: only valid with lane_direct_encode 0)
+            {
+                // token_bytes(), short form for the usual token (literal of
+                // at most 60 bytes, copy of at most 64): the round loop is
+                // not free of VALU cost
+                const uint32_t tl = mpos - next_emit, tc = mend - mpos,
+                               to = mpos - mcand;
+                if (tl > 60 || tc > 64)
+                    csize += token_bytes(tl, tc, to);
+                else
+                    csize += tl + 3 + (tl != 0) - (tc <= 11 && to <= 2047);
+            }
+#endif
             flush = (ntok & 15) == 0;
             s = mend;
             next_emit = mend;
@@ -1147,9 +1179,12 @@ __global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
             to[4] = t4; to[5] = t5; to[6] = t6; to[7] = t7;
         }
         if (finished) { // done(): src/compress.rs:417-426
-            if (next_emit < n)
+            if (next_emit < n) {
                 tok[ntok++] = (unsigned long long)(n - next_emit);
+                csize += token_bytes(n - next_emit, 0, 0);
+            }
             a.ntok[b] = ntok;
+            a.blk_size[b] = csize;
             have = false;
         }
     }
@@ -1201,6 +1236,15 @@ __global__ __launch_bounds__(64) void k_encode_tokens(CompressArgs a)
             dst[i] = (uint8_t)v;
         }
         dst += varint_len(total);
+    } else if (a.direct) {
+        // the sizes of the blocks in front are known (k_match_blocks added
+        // them up, k_scan_sizes ran over this segment): final position
+        const uint32_t first = a.blk_first[st];
+        const uint64_t nb = (total + kMaxBlock - 1) / kMaxBlock;
+        if (first + nb > a.host_blocks)
+            return; // rejected by k_plan_compress (E_ARGUMENT)
+        dst = (gptr)a.out_ptrs[st] + varint_len(total) +
+              (a.blk_off[b] - a.blk_off[first]);
     } else {
         const uint32_t slot = a.slot_first[st] + k - 1;
         if (slot >= a.host_slots)
@@ -1232,7 +1276,7 @@ __global__ __launch_bounds__(64) void k_encode_tokens(CompressArgs a)
         out.t = m;
         out.flush();
     }
-    if (lane == 0)
+    if (lane == 0 && !a.direct)
         a.blk_size[b] = out.d;
 }
 
@@ -1320,7 +1364,9 @@ __global__ __launch_bounds__(1024) void k_plan_compress(CompressArgs a)
     }
 }
 
-// Exclusive scan of blk_size (u32) into blk_off (u64), one workgroup.
+// Exclusive scan of blk_size (u32) into blk_off (u64) over the blocks
+// [blk_lo, blk_hi), one workgroup; blk_off[blk_lo] carries over from the
+// segment in front.
 __global__ __launch_bounds__(1024) void k_scan_sizes(CompressArgs a)
 {
     __shared__ uint64_t wave_tot[16];
@@ -1329,9 +1375,12 @@ __global__ __launch_bounds__(1024) void k_scan_sizes(CompressArgs a)
     uint32_t nblocks = a.blk_first[a.n_streams];
     if (nblocks > a.host_blocks)
         nblocks = a.host_blocks;
+    if (nblocks > a.blk_hi)
+        nblocks = a.blk_hi;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint64_t carry = 0;
-    for (uint32_t base = 0; base < nblocks; base += blockDim.x) {
+    uint64_t carry = a.blk_lo ? blk_off[a.blk_lo] : 0;
+    __syncthreads(); // (blk_off[blk_lo] is rewritten below)
+    for (uint32_t base = a.blk_lo; base < nblocks; base += blockDim.x) {
         const uint32_t i = base + threadIdx.x;
         const uint64_t x = i < nblocks ? blk_size[i] : 0;
         uint64_t sx = x;
@@ -1355,8 +1404,23 @@ __global__ __launch_bounds__(1024) void k_scan_sizes(CompressArgs a)
             blk_off[i] = carry + before + sx - x;
         carry += all;
     }
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0 && nblocks >= a.blk_lo)
         blk_off[nblocks] = carry;
+}
+
+// Direct encoding (k_encode_tokens wrote every block at its final position):
+// what is left of k_compact is the compressed length of every stream.
+__global__ __launch_bounds__(256) void k_stream_lens(CompressArgs a)
+{
+    const uint32_t st = blockIdx.x * 256 + threadIdx.x;
+    if (st >= a.n_streams)
+        return;
+    const uint32_t first = a.blk_first[st];
+    const uint32_t nb = a.blk_first[st + 1] - first;
+    if (nb == 0 || (uint64_t)first + nb > a.host_blocks)
+        return; // empty, in error or rejected: k_plan_compress wrote out_lens
+    a.out_lens[st] = varint_len(a.in_lens[st]) +
+                     (a.blk_off[first + nb] - a.blk_off[first]);
 }
 
 // ---------------------------------------------------------------------

@@ -48,6 +48,9 @@ struct snapmi_ctx {
     // the match finder costs its random accesses far more than the 3.3 ms
     // it hides), 2 = whenever the segment has two blocks (tests)
     int lane_overlap_encode = 0;
+    // 1: the lane kernel's encoder writes every block at its final position
+    // (sizes are known after matching); 0: scratch slots + k_compact
+    int lane_direct_encode = 1;
     // 2: element-major decoder k_decompress_streams2 (default); 1: the
     // first-generation byte-per-lane kernel, kept as a cross-check
     int decode_kernel = 2;

@@ -32,6 +32,7 @@ struct CompressArgs {
     uint32_t *ntok;             // [blocks]
     uint32_t blk_lo, blk_hi;    // blocks this lane/encode launch covers
     uint32_t tok_base;          // block whose tokens lie at tokens[0]
+    uint32_t direct; // k_encode_tokens writes final positions (no slots)
     unsigned long long *lane_tables; // lane g: 16-byte entries from g * lane_stride
     unsigned long long lane_stride;  // >= kMaxTable (tables are spread out)
     uint32_t *lane_epochs;      // [lanes]
@@ -81,6 +82,7 @@ __global__ void k_match_blocks(CompressArgs a);
 __global__ void k_encode_tokens(CompressArgs a);
 __global__ void k_scan_sizes(CompressArgs a);
 __global__ void k_compact(CompressArgs a);
+__global__ void k_stream_lens(CompressArgs a);
 
 // One long raw stream decoded by many wavefronts (snapmi_decompress_stream).
 // The element chain is sequential, so it is resolved hierarchically first:

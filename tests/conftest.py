@@ -41,7 +41,10 @@ def cctx(request, built):
     """A context per compressor kernel: the two wavefront-per-block kernels,
     the lane-per-block kernel (one launch, and split into segments of 64
     blocks) and both at once, each forced for every batch size, so every
-    parity test of the encoder runs through all of them."""
+    parity test of the encoder runs through all of them.  "lanes" and
+    "lanes_segmented" encode every block at its final position
+    (lane_direct_encode); "lanes_overlap" and "both" go through the scratch
+    slots and k_compact."""
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
