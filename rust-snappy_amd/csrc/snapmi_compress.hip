@@ -42,7 +42,7 @@
 //     each lane sizes its own elements, a DPP wave scan places them, and the
 //     lanes write their tags and copy their literal bytes in parallel.  No
 //     store (and no vmcnt wait for one) sits on the per-copy dependency
-//     chain; literals longer than 64 bytes are copied 256 B per instruction.
+//     chain; literals longer than 64 bytes are copied 1 KiB per instruction.
 //
 // Blocks 0 of every stream are written straight into the caller's output
 // (after the varint); later blocks go to scratch slots and are moved into
@@ -306,7 +306,7 @@ struct TokenSink {
             oc[1] = olo;
             oc[2] = ohi;
         }
-        // long literals: the whole wave copies each, 256 B per instruction
+        // long literals: the whole wave copies each (wave_copy)
         uint64_t longs = __ballot(L > 64);
         while (longs) {
             const uint32_t j = (uint32_t)__builtin_ctzll(longs);
@@ -315,13 +315,7 @@ struct TokenSink {
             const uint32_t Pj = rdlane(P, j);
             const uint64_t oj = ((uint64_t)rdlane((uint32_t)((uintptr_t)o >> 32), j) << 32) |
                                 rdlane((uint32_t)(uintptr_t)o, j);
-            gptr to = (gptr)(uintptr_t)oj;
-            gcptr from = src + Pj;
-            for (uint32_t i = 4 * lane; i + 4 <= Lj; i += 4 * kWave)
-                st32u(to + i, ld32u(from + i));
-            const uint32_t tb = Lj & ~3u;
-            if (lane < (Lj & 3u))
-                to[tb + lane] = from[tb + lane];
+            wave_copy<true>((gptr)(uintptr_t)oj, src + Pj, Lj, lane);
         }
     }
 };

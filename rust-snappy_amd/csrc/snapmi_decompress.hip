@@ -29,7 +29,7 @@
 // fence = s_waitcnt vmcnt(0) on gfx950) at most once per ring length.
 //
 // Anything irregular -- a failed check, a literal longer than 64 bytes --
-// leaves the wide path: long literals are copied 256 B per instruction, and
+// leaves the wide path: long literals are copied 1 KiB per instruction, and
 // on the first failed check the stream is finished by the sequential decoder
 // below, which is a direct restatement of the reference's loop and produces
 // the exact snap::Error variant and field values.
@@ -370,16 +370,11 @@ __global__ __launch_bounds__(64) void k_decompress_streams(DecompressArgs a)
 
     if (a.modes && a.modes[st] == 1) {
         // stored frame chunk (reference src/read.rs:173-199): the payload is
-        // the data; 256 bytes per instruction
+        // the data (wave_copy)
         const uint64_t cap0 = a.out_caps[st];
         if (in_len > cap0)
             SNAPMI_FAIL(SNAPMI_BUFFER_TOO_SMALL, cap0, in_len, 0);
-        gptr to = (gptr)a.out_ptrs[st];
-        for (uint64_t i = 4 * lane; i + 4 <= in_len; i += 4 * kWave)
-            st32u(to + i, ld32u(in + i));
-        const uint64_t t = in_len & ~3ull;
-        if (lane < (in_len & 3))
-            to[t + lane] = in[t + lane];
+        wave_copy<false>((gptr)a.out_ptrs[st], in, in_len, lane);
         if (lane == 0) {
             set_error(a.errs, st, SNAPMI_OK, 0, 0, 0);
             a.out_lens[st] = in_len;
@@ -614,7 +609,7 @@ __global__ __launch_bounds__(64) void k_decompress_streams(DecompressArgs a)
         s += cur;
         w = w_next;
 
-        // ---- long literal: 256 bytes per instruction ----------------------
+        // ---- long literal: wave_copy ---------------------------------------
         if (hit_long) {
             const uint32_t ll = xE; // its lane in this window
             const uint64_t Lq = ((uint64_t)rdlane((uint32_t)(L >> 32), ll)
@@ -626,13 +621,7 @@ __global__ __launch_bounds__(64) void k_decompress_streams(DecompressArgs a)
                 irregular = true;
                 break;
             }
-            gcptr from = src + s + hd;
-            gptr to = dst + d;
-            for (uint64_t i = 4 * lane; i + 4 <= Lq; i += 4 * kWave)
-                st32u(to + i, ld32u(from + i));
-            const uint64_t t = Lq & ~3ull;
-            if (lane < (Lq & 3))
-                to[t + lane] = from[t + lane];
+            wave_copy<false>(dst + d, src + s + hd, Lq, lane);
             s += hd + Lq;
             d += Lq;
             ring_lo = d; // these bytes are not in the ring
@@ -794,16 +783,11 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
 
     if (a.modes && a.modes[st] == 1) {
         // stored frame chunk (reference src/read.rs:173-199): the payload is
-        // the data; 256 bytes per instruction
+        // the data (wave_copy)
         const uint64_t cap0 = a.out_caps[st];
         if (in_len > cap0)
             SNAPMI_FAIL(SNAPMI_BUFFER_TOO_SMALL, cap0, in_len, 0);
-        gptr to = (gptr)a.out_ptrs[st];
-        for (uint64_t i = 4 * lane; i + 4 <= in_len; i += 4 * kWave)
-            st32u(to + i, ld32u(in + i));
-        const uint64_t t = in_len & ~3ull;
-        if (lane < (in_len & 3))
-            to[t + lane] = in[t + lane];
+        wave_copy<false>((gptr)a.out_ptrs[st], in, in_len, lane);
         if (lane == 0) {
             set_error(a.errs, st, SNAPMI_OK, 0, 0, 0);
             a.out_lens[st] = in_len;
@@ -923,7 +907,7 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
             stop ? ((1ull << __builtin_ctzll(stop)) - 1) : ~0ull;
         const uint64_t K = __ballot(elem && incl <= kWinMax) & below;
         if (K == 0) {
-            // lane 0 is a literal of more than 64 bytes: 256 B per instruction
+            // lane 0 is a literal of more than 64 bytes: wave_copy
             const uint32_t lng0 = rdlane(lng ? 1u : 0u, 0);
             const uint64_t Lq = (uint64_t)rdlane(lraw, 0) + 1;
             const uint32_t h0 = rdlane(hd, 0);
@@ -933,13 +917,7 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
                 break;
             }
             R.flush_partial(d);
-            gcptr from = src + s + h0;
-            gptr to = dst + d;
-            for (uint64_t i = 4 * lane; i + 4 <= Lq; i += 4 * kWave)
-                st32u(to + i, ld32u(from + i));
-            const uint64_t t = Lq & ~3ull;
-            if (lane < (Lq & 3))
-                to[t + lane] = from[t + lane];
+            wave_copy<false>(dst + d, src + s + h0, Lq, lane);
             s += h0 + Lq;
             d += (uint32_t)Lq;
             R.gflush = d;

@@ -66,6 +66,51 @@ __device__ __forceinline__ void st32u(gptr p, uint32_t v)
     __builtin_memcpy(p, &v, 4);
 }
 
+// 16 bytes from global memory at any alignment (one global_load_dwordx4)
+__device__ __forceinline__ u32x4 ld128g(gcptr p)
+{
+    u32x4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+
+// The whole wave copies len bytes (a long literal), touching exactly
+// from[0..len) and to[0..len): the destination is brought to a 16-byte
+// boundary, then 16 bytes per lane, 1 KiB per instruction - and with kRows4
+// four such rows in flight per trip, for a kernel that has the registers (the
+// decoders run 8 waves per SIMD and get their loads in flight from that) -
+// the rest bytewise.  Long literals are the whole of an incompressible
+// stream.  The source may have any alignment.
+template <bool kRows4>
+__device__ __forceinline__ void wave_copy(gptr to, gcptr from, uint64_t len,
+                                          uint32_t lane)
+{
+    uint32_t head = (uint32_t)((16 - ((uintptr_t)to & 15)) & 15);
+    if (head > len)
+        head = (uint32_t)len;
+    if (lane < head)
+        to[lane] = from[lane];
+    const uint64_t body = (len - head) & ~15ull;
+    gptr t = to + head;
+    gcptr f = from + head;
+    typedef __attribute__((address_space(1))) u32x4 g_u32x4;
+    uint64_t i = 16 * lane;
+    for (; kRows4 && i + 3072 < body; i += 4096) {
+        const u32x4 v0 = ld128g(f + i), v1 = ld128g(f + i + 1024),
+                    v2 = ld128g(f + i + 2048), v3 = ld128g(f + i + 3072);
+        *(g_u32x4 *)(t + i) = v0;
+        *(g_u32x4 *)(t + i + 1024) = v1;
+        *(g_u32x4 *)(t + i + 2048) = v2;
+        *(g_u32x4 *)(t + i + 3072) = v3;
+    }
+    for (; i < body; i += 1024) {
+        *(g_u32x4 *)(t + i) = ld128g(f + i);
+    }
+    const uint32_t tail = (uint32_t)(len - head - body);
+    if (lane < tail)
+        t[body + lane] = f[body + lane];
+}
+
 // Dword at base[pos..pos+4) where only base[0..avail) may be touched; bytes
 // past `avail` read as zero.
 __device__ __forceinline__ uint32_t ld32g(gcptr base, uint64_t pos,
