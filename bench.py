@@ -186,8 +186,9 @@ def run_extras(args, local_rank, dev, rank, world):
     per-file rates, one long raw stream and cfg4 at N = 1 - in a child
     process (bench_configs.py --plan), so that nothing they do can take the
     headline line down; at N > 1 cfg4 only (the framed stream sharded over
-    the ranks, gathered on rank 0), in this process group.  Each config is
-    parity-checked inside bench_configs.py; a failure is recorded."""
+    the ranks, gathered on rank 0), one child per rank with a process group
+    of their own.  Each config is parity-checked inside bench_configs.py; a
+    failure is recorded."""
     import subprocess
     out = {}
     if world == 1:
@@ -208,21 +209,74 @@ def run_extras(args, local_rank, dev, rank, world):
         except subprocess.TimeoutExpired:
             out["error"] = "bench_configs.py --plan timed out (420 s)"
         return out
-    import types
-    import bench_configs as BC
-    from rust_snappy_amd import raw
-    ctx = raw.Context(local_rank)
-    a = types.SimpleNamespace(gib=8.0 * world, period_mib=256.0, steps=2)
+    # N > 1: every rank starts one child (bench_configs.py --plan cfg4) and
+    # the children form a process group of their own on a fresh port.  The
+    # sharded encode + gather has never met a multi-GPU box in this repo's
+    # own runs; in a child with a time limit, whatever goes wrong there is a
+    # recorded error and not a lost headline line.
+    res = rank_children([sys.executable, str(ROOT / "bench_configs.py"),
+                         "--plan", f"cfg4:{8 * world}"],
+                        rank, local_rank, world, 300)
+    if res is not None:
+        out["cfg4"] = res
+    return out if rank == 0 else None
+
+
+def rank_children(cmd, rank, local_rank, world, limit_s):
+    """Every rank of this process group runs `cmd` as a child; the children
+    rendezvous on a fresh port that rank 0 picks and broadcasts.  Returns the
+    last JSON line of this rank's child (None if it printed none), or an
+    {"error"} record - after limit_s the child is killed."""
+    import subprocess
+    import torch.distributed as dist
+    port = [0]
+    if rank == 0:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port[0] = sk.getsockname()[1]
+    dist.broadcast_object_list(port, src=0)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port[0]),
+               RANK=str(rank), LOCAL_RANK=str(local_rank),
+               WORLD_SIZE=str(world))
+    for k in list(env):
+        if k.startswith("TORCHELASTIC_"):
+            env.pop(k)  # the child group has a TCP store of its own
     t0 = time.perf_counter()
+    res = None
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, text=True)
     try:
-        res = BC.cfg4(a, ctx, dev)
-    except Exception as e:  # noqa: BLE001 - recorded, not hidden
-        res = {"error": f"{type(e).__name__}: {e}"[:300]}
+        so, se = child.communicate(timeout=limit_s)
+        for ln in so.splitlines():
+            if ln.startswith("{"):
+                res = json.loads(ln)
+                res.pop("name", None)
+        if child.returncode != 0:
+            res = {"error": (f"rank {rank} child exit {child.returncode}: "
+                             + se.strip()[-300:])}
+    except subprocess.TimeoutExpired:
+        child.kill()
+        child.communicate()
+        res = {"error": f"rank {rank} child timed out ({limit_s} s)"}
+    if rank == 0 and res is None:
+        res = {"error": "no record from rank 0's child"}
     if res is not None:
         res["wall_s"] = round(time.perf_counter() - t0, 1)
-        out["cfg4"] = res
-    ctx.close()
-    return out if rank == 0 else None
+    return res
+
+
+# what plumbing_check's children do: a process group of their own (gloo),
+# one all_reduce, one JSON line from rank 0
+_CHILD_STUB = (
+    "import os, json, torch, torch.distributed as dist\n"
+    "dist.init_process_group('gloo')\n"
+    "t = torch.tensor([1.0 + dist.get_rank()])\n"
+    "dist.all_reduce(t)\n"
+    "if dist.get_rank() == 0:\n"
+    "    print(json.dumps({'name': 'stub', 'sum': t.item(),\n"
+    "                      'port': os.environ['MASTER_PORT']}))\n"
+    "dist.destroy_process_group()\n")
 
 
 def maybe_spawn(args):
@@ -266,14 +320,19 @@ def plumbing_check(rank, world):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         seen = [None] * world
         dist.all_gather_object(seen, rank)
+        # the N > 1 extras: a child per rank, a process group of their own
+        child = rank_children([sys.executable, "-c", _CHILD_STUB], rank,
+                              int(os.environ.get("LOCAL_RANK", "0")), world,
+                              120)
         dist.barrier()
         dist.destroy_process_group()
     else:
-        t, seen = torch.tensor([1.0]), [0]
+        t, seen, child = torch.tensor([1.0]), [0], None
     if rank == 0:
         print(json.dumps({"metric": "plumbing check", "n_gpus": world,
                           "ranks_seen": sorted(seen),
                           "max_over_ranks": float(t[0]),
+                          "children": child,
                           "INVALID": "plumbing check, no GPU work"}),
               flush=True)
 
@@ -458,7 +517,10 @@ def main():
         del src, comp, back, data, per, d_round
         ctx.close()
         torch.cuda.empty_cache()
-        extras = run_extras(args, local_rank, dev, rank, world)
+        try:
+            extras = run_extras(args, local_rank, dev, rank, world)
+        except Exception as e:  # noqa: BLE001 - recorded, not hidden
+            extras = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank == 0:
         K = args.steps

@@ -34,6 +34,11 @@ def test_gpus_n_spawns_n_ranks():
     assert lines[0]["n_gpus"] == 2 and lines[0]["ranks_seen"] == [0, 1]
     assert lines[0]["max_over_ranks"] == 2.0   # MAX over ranks, not rank 0's
     assert "spawning 2 ranks" in p.stderr
+    # the N > 1 extras: one child per rank, a process group of their own on
+    # a port of their own (rank_children); rank 0's child reports
+    child = lines[0]["children"]
+    assert "error" not in child, child
+    assert child["sum"] == 3.0                  # 1 + 2: both children met
 
 
 def test_single_rank_needs_no_launcher():
