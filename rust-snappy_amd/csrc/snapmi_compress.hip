@@ -253,30 +253,54 @@ struct TokenSink {
             }
         }
         o += lt;
-        // literal bytes, one lane per literal while they are short
+        // literal bytes, one lane per literal while they are short: up to
+        // four 16-byte pieces, ALL loads first (one memory latency for the
+        // whole literal instead of one per 4 bytes: the encoder's passes are
+        // a chain of such latencies), then the stores - whole pieces as one
+        // 16-byte store, the last one dword- and bytewise
         gcptr in = src + P;
-        if (L && L <= 16 && P + 16 <= n) {
-            uint32_t w[4];
-            __builtin_memcpy(w, in, 16);
-            if (L >= 4)
-                st32u(o, w[0]);
-            if (L >= 8)
-                st32u(o + 4, w[1]);
-            if (L >= 12)
-                st32u(o + 8, w[2]);
+        const uint32_t Lp = (L + 15u) & ~15u;
+        if (L && L <= 64 && P + Lp <= n) {
+            u32x4 v0 = {0, 0, 0, 0}, v1 = v0, v2 = v0, v3 = v0;
+            v0 = ld128g(in);
+            if (L > 16)
+                v1 = ld128g(in + 16);
+            if (L > 32)
+                v2 = ld128g(in + 32);
+            if (L > 48)
+                v3 = ld128g(in + 48);
+            typedef __attribute__((address_space(1))) u32x4 g_u32x4;
+            typedef g_u32x4 __attribute__((aligned(1))) g_u32x4u;
             if (L >= 16)
-                st32u(o + 12, w[3]);
-            const uint32_t tl = L & 3u, tb = L & ~3u;
-            const uint32_t ti = (L >> 2) & 3u; // dword holding the tail
+                *(g_u32x4u *)o = v0;
+            if (L >= 32)
+                *(g_u32x4u *)(o + 16) = v1;
+            if (L >= 48)
+                *(g_u32x4u *)(o + 32) = v2;
+            if (L >= 64)
+                *(g_u32x4u *)(o + 48) = v3;
+            // the last, partial piece (L & 15 bytes at o + (L & ~15))
+            const uint32_t pk = L >> 4; // piece that holds it
+            const u32x4 pv = pk == 0 ? v0 : (pk == 1 ? v1 : (pk == 2 ? v2 : v3));
+            gptr po = o + (L & ~15u);
+            const uint32_t r = L & 15u;
+            if (r >= 4)
+                st32u(po, pv.x);
+            if (r >= 8)
+                st32u(po + 4, pv.y);
+            if (r >= 12)
+                st32u(po + 8, pv.z);
+            const uint32_t tl = r & 3u, tb = r & ~3u;
+            const uint32_t ti = r >> 2; // dword holding the tail
             const uint32_t tw =
-                ti == 0 ? w[0] : (ti == 1 ? w[1] : (ti == 2 ? w[2] : w[3]));
+                ti == 0 ? pv.x : (ti == 1 ? pv.y : (ti == 2 ? pv.z : pv.w));
             if (tl >= 1)
-                o[tb] = (uint8_t)tw;
+                po[tb] = (uint8_t)tw;
             if (tl >= 2)
-                o[tb + 1] = (uint8_t)(tw >> 8);
+                po[tb + 1] = (uint8_t)(tw >> 8);
             if (tl >= 3)
-                o[tb + 2] = (uint8_t)(tw >> 16);
-        } else if (L && L <= 64) {
+                po[tb + 2] = (uint8_t)(tw >> 16);
+        } else if (L && L <= 64) { // within 16 bytes of the block's end
             uint32_t i = 0;
             for (; i + 4 <= L; i += 4)
                 st32u(o + i, ld32u(in + i));
@@ -1252,11 +1276,16 @@ __global__ __launch_bounds__(64) void k_encode_tokens(CompressArgs a)
         (const g_u64 *)a.tokens + (uint64_t)(b - a.tok_base) * kMaxTokens;
     const uint32_t count = a.ntok[b];
     uint32_t pos_base = 0;
+    // (the next pass's tokens are loaded before this pass is encoded: one
+    // memory latency less on the chain of every pass)
+    unsigned long long tnext = lane < count ? tok[lane] : 0;
     for (uint32_t t0 = 0; t0 < count; t0 += kWave) {
         const uint32_t m = count - t0 < kWave ? count - t0 : kWave;
         uint32_t L = 0, C = 0, O = 0;
+        const unsigned long long t = tnext;
+        if (t0 + kWave + lane < count)
+            tnext = tok[t0 + kWave + lane];
         if (lane < m) {
-            const unsigned long long t = tok[t0 + lane];
             L = (uint32_t)t & 0x1FFFFu;
             C = (uint32_t)(t >> 17) & 0xFFFFu;
             O = (uint32_t)(t >> 33) & 0xFFFFu;
