@@ -1054,22 +1054,22 @@ __global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
         gcptr pa = mode == kExtend ? src + c : (gcptr)(tab + hcur);
         pa = stall ? src_al + hi : pa;
         B16 A = ld128u(pa);
-        u32x4 f0, f1, f2, f3, f4, f5, f6, f7;
+        // (the load is issued HERE, in front of the window's line: a compiler
+        // barrier, or it may be sunk behind the fill's wait - two latencies
+        // in every round that fills)
+        asm volatile("" ::: "memory");
         if (fill) {
             const g_u32x4 *lp = (const g_u32x4 *)(src_al + hi);
-            f0 = lp[0]; f1 = lp[1]; f2 = lp[2]; f3 = lp[3];
-            f4 = lp[4]; f5 = lp[5]; f6 = lp[6]; f7 = lp[7];
-        }
-        // one wait for the whole round: keep the compiler from sinking a load
-        // into the branch that uses it
-        asm volatile("" : "+v"(A.w[0]), "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3),
-                          "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7));
-        if (fill) {
+            const u32x4 f0 = lp[0], f1 = lp[1], f2 = lp[2], f3 = lp[3],
+                        f4 = lp[4], f5 = lp[5], f6 = lp[6], f7 = lp[7];
             l_u32x4 *dst = (l_u32x4 *)(win + ((hi >> 2) & 63));
             dst[0] = f0; dst[1] = f1; dst[2] = f2; dst[3] = f3;
             dst[4] = f4; dst[5] = f5; dst[6] = f6; dst[7] = f7;
             hi += 128;
         }
+        // one wait for the whole round: A is materialised before the branch
+        // that uses it (the fill's wait, when there was one, covered it)
+        asm volatile("" : "+v"(A.w[0]));
         if (stall)
             continue;
 
