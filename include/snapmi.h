@@ -134,6 +134,8 @@ const char *snapmi_version(void);
  *   "lane_waves_per_cu"    lanes in flight = 64 x this x CUs (default 6)
  *   "lane_segment_blocks"  blocks per lane-kernel launch (default 262144 =
  *                          16 GiB of input; bounds the token scratch)
+ *   "lane_tables_uncached" 1: the lane tables come from an uncached
+ *                          allocation (measured: no gain; default 0)
  *   "lane_direct_encode"   1 (default): the lane kernel's encoder writes every
  *                          block at its final position (the match finder adds
  *                          up the encoded sizes); 0: scratch slot per block +

@@ -106,6 +106,8 @@ int snapmi_ctx_create(int device, void *hip_stream, snapmi_ctx **out)
         }
         if (const char *e = getenv("SNAPMI_FRAME_CRC_SIDE"))
             ctx->frame_crc_side_stream = atoi(e) != 0;
+        if (const char *e = getenv("SNAPMI_LANE_UNCACHED"))
+            ctx->lane_tables_uncached = atoi(e) != 0;
         if (const char *e = getenv("SNAPMI_LANE_DIRECT"))
             ctx->lane_direct_encode = atoi(e) != 0;
         if (const char *e = getenv("SNAPMI_DECODE_KERNEL"))
@@ -243,6 +245,9 @@ int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value)
     else if (strcmp(name, "frame_crc_side_stream") == 0 && value >= 0 &&
              value <= 1)
         ctx->frame_crc_side_stream = value != 0;
+    else if (strcmp(name, "lane_tables_uncached") == 0 && value >= 0 &&
+             value <= 1)
+        ctx->lane_tables_uncached = (int)value;
     else if (strcmp(name, "lane_direct_encode") == 0 && value >= 0 &&
              value <= 1)
         ctx->lane_direct_encode = (int)value;
@@ -530,7 +535,12 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                     ? ctx->lane_table_tries : 1;
             for (uint32_t t = 0; t < tries; t++) {
                 void *cand = nullptr;
-                if (hipMalloc(&cand, bytes) != hipSuccess) {
+                // (uncached: MTYPE UC - the tables never hit in L2 anyway,
+                // tests/hw/random_policy.hip)
+                if ((ctx->lane_tables_uncached
+                         ? hipExtMallocWithFlags(&cand, bytes,
+                                                 hipDeviceMallocUncached)
+                         : hipMalloc(&cand, bytes)) != hipSuccess) {
                     (void)hipGetLastError();
                     break; // no room for another candidate: keep the best
                 }

@@ -51,6 +51,8 @@ struct snapmi_ctx {
     // 1: the lane kernel's encoder writes every block at its final position
     // (sizes are known after matching); 0: scratch slots + k_compact
     int lane_direct_encode = 1;
+    // 1: the lane tables come from hipExtMallocWithFlags(hipDeviceMallocUncached)
+    int lane_tables_uncached = 0;
     // 2: element-major decoder k_decompress_streams2 (default); 1: the
     // first-generation byte-per-lane kernel, kept as a cross-check
     int decode_kernel = 2;
