@@ -848,17 +848,21 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
         const uint32_t b14 = (uint32_t)(w >> 8); // the 4 bytes after the tag
         const uint32_t type = tag & 3, n6 = tag >> 2;
         const bool is_lit = type == 0;
-        // literal (reference read_literal, src/decompress.rs:161-228)
-        const uint32_t lnb = n6 >= 60 ? n6 - 59 : 0; // extra length bytes
-        const uint32_t lmask = lnb == 4 ? 0xFFFFFFFFu : ((1u << (8 * lnb)) - 1);
-        const uint32_t lraw = lnb ? (b14 & lmask) : n6; // length - 1
+        // The bytes behind the tag hold a little-endian number of nb bytes:
+        // the rest of a literal's length (nb = 0..4, reference read_literal,
+        // src/decompress.rs:161-228) or a copy's offset (nb = 1, 2, 4,
+        // TagEntry::offset / read_copy, :233-250,433-474) - one extraction
+        // for both (this loop is bound by VALU issue: every instruction that
+        // goes is 0.4 % of the kernel)
+        const uint32_t lnb = (n6 > 59 ? n6 : 59) - 59; // extra length bytes
+        const uint32_t cnb = type + (type == 3);        // 1, 2, 4
+        const uint32_t sh = 32 - 8 * (is_lit ? lnb : cnb);
+        const uint32_t ext = (b14 << (sh & 31)) >> (sh & 31); // (nb = 0: unused)
+        const uint32_t lraw = lnb ? ext : n6; // length - 1
         const uint32_t hd = 1 + lnb;
         const bool lng = is_lit && lraw >= 64; // > 64 bytes: not in a window
-        // copy (reference TagEntry::offset / read_copy, :233-250,433-474)
-        const uint32_t cnb = type == 1 ? 1 : (type == 2 ? 2 : 4);
         const uint32_t clen = type == 1 ? 4 + (n6 & 7) : 1 + n6;
-        const uint32_t off = type == 1 ? (((tag >> 5) << 8) | (b14 & 0xFF))
-                                       : (type == 2 ? (b14 & 0xFFFF) : b14);
+        const uint32_t off = ext | (type == 1 ? (tag & 0xE0u) << 3 : 0);
         const uint32_t olen = is_lit ? lraw + 1 : clen;      // if !lng
         const uint32_t enc = is_lit ? hd + lraw + 1 : 1 + cnb; // if !lng
         // the whole element lies inside the input (:189-217 src side, CopyRead)
