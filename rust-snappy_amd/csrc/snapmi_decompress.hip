@@ -207,12 +207,19 @@ __device__ __forceinline__ uint32_t dpp_get(uint32_t v)
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK,
                                                  0xF, false);
 }
+// row_shr with all rows enabled: lanes without a source read zero
+// (bound_ctrl), so the move folds into the add (v_add_u32_dpp)
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_shr0(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF,
+                                                 true);
+}
 __device__ __forceinline__ uint32_t wave_inclusive_add(uint32_t v)
 {
-    v += dpp_get<0x111, 0xF>(v);
-    v += dpp_get<0x112, 0xF>(v);
-    v += dpp_get<0x114, 0xF>(v);
-    v += dpp_get<0x118, 0xF>(v);
+    v += dpp_shr0<0x111>(v);
+    v += dpp_shr0<0x112>(v);
+    v += dpp_shr0<0x114>(v);
+    v += dpp_shr0<0x118>(v);
     v += dpp_get<0x142, 0xA>(v);
     v += dpp_get<0x143, 0xC>(v);
     return v;
@@ -877,28 +884,28 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
             __builtin_memcpy(&lit16, src + s + lane + hd, 16);
         }
         // ---- 2. element starts: the orbit of lane 0 under "next" ----------
-        uint32_t nk = (lng || lane >= rem) ? kWave
-                                           : (lane + enc < kWave ? lane + enc
-                                                                 : kWave);
+        // (a lane whose element ends the chain - it reaches past the window,
+        // or is a long literal - points at itself: the doubling then needs no
+        // "is there a next" select, 3 VALU per round instead of 8)
+        const uint32_t nx = (lng || lane >= rem) ? kWave : lane + enc;
+        const bool term = nx >= kWave;
+        const uint64_t T = __ballot(term);
+        uint32_t nk = term ? lane : nx;
         uint32_t rlo = lane < 32 ? 1u << lane : 0;
         uint32_t rhi = lane >= 32 ? 1u << (lane - 32) : 0;
 #pragma unroll
         for (uint32_t k = 0; k < 5; k++) {
-            const int sel = (int)((nk & 63) << 2);
-            const uint32_t glo =
-                (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)rlo);
-            const uint32_t ghi =
-                (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)rhi);
-            const uint32_t gnk =
-                (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)nk);
-            const bool ok = nk < kWave;
-            rlo |= ok ? glo : 0;
-            rhi |= ok ? ghi : 0;
-            nk = ok ? gnk : kWave;
-            if (k >= 2 && rdlane(nk, 0) >= kWave)
-                break; // lane 0's chain has left the window
+            const int sel = (int)(nk << 2);
+            rlo |= (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)rlo);
+            rhi |= (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)rhi);
+            nk = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)nk);
+            if (k >= 2 && ((T >> rdlane(nk, 0)) & 1))
+                break; // lane 0's chain has reached its last element
         }
-        const uint64_t S = ((uint64_t)rdlane(rhi, 0) << 32) | rdlane(rlo, 0);
+        // (after k rounds a lane's set holds the first 2^k lanes of its chain
+        // and nk the one behind them - which the early exit must not lose)
+        const uint64_t S = ((uint64_t)rdlane(rhi, 0) << 32) | rdlane(rlo, 0) |
+                           (1ull << rdlane(nk, 0));
         const bool is_start = (S >> lane) & 1;
         // ---- 3. placement, window cut, checks ------------------------------
         const bool elem = is_start && fits;
@@ -946,7 +953,13 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
         n_elem += __builtin_popcountll(K);
 #endif
         // next window's bytes: issued now, consumed after the expand
-        const uint64_t w_next = ld64c(src, s + cur + lane, src_len);
+        // (plain unaligned loads while the next window lies inside the
+        // input - a uniform test; the clamped form only at the stream's end)
+        uint64_t w_next;
+        if (s + cur + kWave + 8 <= src_len)
+            __builtin_memcpy(&w_next, src + (s + cur) + lane, 8);
+        else
+            w_next = ld64c(src, s + cur + lane, src_len);
 
         // ---- 4. the lane-parallel copy step --------------------------------
         const uint32_t q = dstp - off;               // copy source (if cpy)

@@ -118,14 +118,20 @@ def decode(comp, stats=None):
         nx = np.where(long_ | (LANE >= rem), WAVE,
                       np.minimum(LANE + enc, WAVE))
         # ---- element starts: S = orbit of lane 0 under nx (mask doubling) --
+        # A lane that ends the chain points at itself, so the doubling needs
+        # no "is there a next" select.  After k rounds a lane's set holds the
+        # first 2^k lanes of its chain and nk the one behind them; lane 0's
+        # rounds stop early once its nk is a chain end, and that lane is
+        # added to the set (it may be hop 2^k exactly).
+        term = nx >= WAVE
         reach = (np.uint64(1) << LANE.astype(np.uint64))
-        nk = nx.copy()
-        for _ in range(5):      # 2^5 = 32 hops >= elements per window
-            ok = nk < WAVE
-            nki = np.where(ok, nk, 0)
-            reach = np.where(ok, reach | reach[nki], reach)
-            nk = np.where(ok, nk[nki], WAVE)
-        S = int(reach[0])
+        nk = np.where(term, LANE, nx)
+        for k in range(5):      # 2^5 = 32 hops >= elements per window
+            reach = reach | reach[nk]
+            nk = nk[nk]
+            if k >= 2 and term[nk[0]]:
+                break
+        S = int(reach[0]) | (1 << int(nk[0]))
         is_start = np.array([(S >> i) & 1 for i in range(WAVE)], dtype=bool)
         # reference walk, to check the doubling
         p, walk = 0, 0
