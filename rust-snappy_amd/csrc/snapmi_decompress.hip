@@ -874,8 +874,13 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
         const uint32_t enc = is_lit ? hd + lraw + 1 : 1 + cnb; // if !lng
         // the whole element lies inside the input (:189-217 src side, CopyRead)
         // (an extended literal length is read as 4 bytes: :189-198)
-        const bool fits = lane < rem && !lng && enc <= rem - lane &&
-                          !(is_lit && lnb && lane + 5 > rem);
+        // (a window with 160 bytes of input in front of it - all but the
+        // last two or three of a stream - needs none of the per-lane tests:
+        // lane + 5 + 64 + 16 <= rem whatever the element)
+        const bool deep = rem >= 160;
+        const bool fits = deep ? !lng
+                               : (lane < rem && !lng && enc <= rem - lane &&
+                                  !(is_lit && lnb && lane + 5 > rem));
         // 16 literal bytes, speculatively (only windows well inside the input)
         const bool inner = rem >= 64 + 5 + 16;
         B16x lit16;
@@ -887,7 +892,8 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
         // (a lane whose element ends the chain - it reaches past the window,
         // or is a long literal - points at itself: the doubling then needs no
         // "is there a next" select, 3 VALU per round instead of 8)
-        const uint32_t nx = (lng || lane >= rem) ? kWave : lane + enc;
+        const uint32_t nx =
+            (lng || (!deep && lane >= rem)) ? kWave : lane + enc;
         const bool term = nx >= kWave;
         const uint64_t T = __ballot(term);
         uint32_t nk = term ? lane : nx;
@@ -906,7 +912,7 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
         // and nk the one behind them - which the early exit must not lose)
         const uint64_t S = ((uint64_t)rdlane(rhi, 0) << 32) | rdlane(rlo, 0) |
                            (1ull << rdlane(nk, 0));
-        const bool is_start = (S >> lane) & 1;
+        const bool is_start = __builtin_amdgcn_inverse_ballot_w64(S);
         // ---- 3. placement, window cut, checks ------------------------------
         const bool elem = is_start && fits;
         const uint32_t o = elem ? olen : 0;
@@ -937,7 +943,7 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
                 w = ld64c(src, s + lane, src_len);
             continue;
         }
-        const bool keep = (K >> lane) & 1;
+        const bool keep = __builtin_amdgcn_inverse_ballot_w64(K);
         const uint32_t last = 63 - (uint32_t)__builtin_clzll(K);
         const uint32_t W = rdlane(incl, last);         // output of the window
         const uint32_t cur = last + rdlane(enc, last); // input consumed
@@ -982,7 +988,7 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
 #ifdef SNAPMI_DEC2_ONETRIP
             olen <= 16 &&
 #endif
-            ((is_lit && inner && lane + hd + pad <= rem) ||
+            ((is_lit && (deep || (inner && lane + hd + pad <= rem))) ||
              (cpy && q + n <= d && olen <= off &&
               (ring_ok || (far_ok && pad <= dst_lim - q))));
         const bool far = lw && cpy && !ring_ok;
@@ -1048,9 +1054,6 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
                                 (uint8_t)(part >> (8 * (j & 7)));
                         }
                     }
-                    // ring[0,16) or its mirror behind the end were written
-                    if (__ballot(act && (wa < 16 || wa + 16 > kRing2)) != 0)
-                        R.mirror();
                 }
                 if (c == 0)
                     break;
@@ -1098,8 +1101,16 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
             }
             if (lane < ni)
                 rg[(di + lane) & (kRing2 - 1)] = (uint8_t)val;
-            const uint32_t wa = di & (kRing2 - 1);
-            if (wa < 16 || wa + ni > kRing2)
+        }
+        // The mirror of ring[0,16) behind the ring's end, once per window (a
+        // uniform test): the window's stores - whole 16-byte pieces, so up to
+        // d + W + 16 - touched ring[0,16), or spilled over the end into the
+        // mirror.  Within the window nobody reads through it what these
+        // stores changed: such a source lies below safe_lo; the sweep and the
+        // flush address the ring bytewise / dword-aligned.
+        {
+            const uint32_t a0 = d & (kRing2 - 1);
+            if (a0 < 16 || a0 + W + 16 > kRing2)
                 R.mirror();
         }
         // ---- 6. advance; whole 256-byte pieces go to HBM -------------------

@@ -114,6 +114,11 @@ def decode(comp, stats=None):
         # length is read as 4 bytes (src/decompress.rs:189-198)
         fits = (LANE < rem) & ~long_ & (enc <= rem - LANE) & \
             ~(is_lit & (lnb > 0) & (LANE + 5 > rem))
+        # a window with 160 bytes of input in front of it needs none of the
+        # per-lane tests (the kernel's uniform fast path)
+        deep = rem >= 160
+        if deep:
+            assert (fits == ~long_).all()
         inner = rem >= 64 + 5 + 16      # speculative 16-byte literal loads
         nx = np.where(long_ | (LANE >= rem), WAVE,
                       np.minimum(LANE + enc, WAVE))
@@ -191,6 +196,8 @@ def decode(comp, stats=None):
         ring_ok = q >= safe_lo                   # of this window can clobber
         far_ok = q + n <= gflush
         pad = (olen + 15) & ~15              # 16-byte loads stay in bounds
+        if deep:
+            assert (~(keep & is_lit) | (inner & (LANE + hd + pad <= rem))).all()
         lanewise = keep & np.where(
             is_lit, inner & (LANE + hd + pad <= rem),
             (q + n <= d) & (olen <= off) &
@@ -229,29 +236,23 @@ def decode(comp, stats=None):
                     a = int(q[i]) + 16 * c
                     assert a + 16 <= dst_len
                     reads[i] = out[a:a + 16].copy()
-            touched = False
             for i in LANE[act]:              # one store instruction, lanes
                 m = min(int(olen[i]) - 16 * c, 16)   # in ascending order
                 wa = (int(dstp[i]) + 16 * c) & (R - 1)
                 if wa + m > R:
                     continue                 # the element's bytes wrap: below
                 ring[wa:wa + 16] = reads[i]  # may spill into the mirror
-                touched |= wa < 16 or wa + 16 > R
             for i in LANE[act]:              # (rare) exact, bytewise, wrapped
                 m = min(int(olen[i]) - 16 * c, 16)
                 wa = (int(dstp[i]) + 16 * c) & (R - 1)
                 if wa + m > R:
                     ring_write(int(dstp[i]) + 16 * c, reads[i][:m])
-                    touched = True
-            if touched:
-                mirror()
         st.rounds += 1
         for i in LANE[keep & ~lanewise]:     # the sweep, in stream order
             st.wide += 1
             if is_lit[i]:                    # only at the end of the input
                 a = s + i + int(hd[i])
                 ring_write(int(dstp[i]), src[a:a + int(olen[i])])
-                mirror()
                 continue
             qi, oi, ni = int(q[i]), int(off[i]), int(olen[i])
             in_ring = qi >= safe_lo
@@ -267,6 +268,12 @@ def decode(comp, stats=None):
                 fence_for(qi + min(ni, oi))
                 data = out[srcpos].copy()
             ring_write(int(dstp[i]), data)
+        # the mirror once per window: its stores (whole 16-byte pieces, up to
+        # d + W + 16) touched ring[0,16) or spilled over the ring's end.
+        # Within the window nothing reads through the mirror what they
+        # changed: such a source lies below safe_lo.
+        a0 = d & (R - 1)
+        if a0 < 16 or a0 + W + 16 > R:
             mirror()
         d += W
         s += cur
