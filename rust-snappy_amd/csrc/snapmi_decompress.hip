@@ -867,7 +867,13 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
         const uint32_t ext = (b14 << (sh & 31)) >> (sh & 31); // (nb = 0: unused)
         const uint32_t lraw = lnb ? ext : n6; // length - 1
         const uint32_t hd = 1 + lnb;
-        const bool lng = is_lit && lraw >= 64; // > 64 bytes: not in a window
+        // Predicates live as 64-bit lane masks in SGPRs and are combined
+        // there: a __ballot of a compound per-lane bool costs two VALU
+        // instructions on top of its compares (the bool is materialised and
+        // compared again), a scalar AND of two simple ballots costs none.
+        const uint64_t M_lit = __ballot(is_lit);
+        // literals of more than 64 bytes: not in a window
+        const uint64_t M_lng = M_lit & __ballot(lraw >= 64);
         const uint32_t clen = type == 1 ? 4 + (n6 & 7) : 1 + n6;
         const uint32_t off = ext | (type == 1 ? (tag & 0xE0u) << 3 : 0);
         const uint32_t olen = is_lit ? lraw + 1 : clen;      // if !lng
@@ -878,9 +884,10 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
         // last two or three of a stream - needs none of the per-lane tests:
         // lane + 5 + 64 + 16 <= rem whatever the element)
         const bool deep = rem >= 160;
-        const bool fits = deep ? !lng
-                               : (lane < rem && !lng && enc <= rem - lane &&
-                                  !(is_lit && lnb && lane + 5 > rem));
+        const uint64_t M_fits =
+            deep ? ~M_lng
+                 : ~M_lng & __ballot(lane < rem && enc <= rem - lane &&
+                                     !(is_lit && lnb && lane + 5 > rem));
         // 16 literal bytes, speculatively (only windows well inside the input)
         const bool inner = rem >= 64 + 5 + 16;
         B16x lit16;
@@ -892,11 +899,10 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
         // (a lane whose element ends the chain - it reaches past the window,
         // or is a long literal - points at itself: the doubling then needs no
         // "is there a next" select, 3 VALU per round instead of 8)
-        const uint32_t nx =
-            (lng || (!deep && lane >= rem)) ? kWave : lane + enc;
-        const bool term = nx >= kWave;
-        const uint64_t T = __ballot(term);
-        uint32_t nk = term ? lane : nx;
+        const uint32_t nx = lane + enc;
+        const uint64_t T = M_lng | __ballot(nx >= kWave) |
+                           (deep ? 0 : __ballot(lane >= rem));
+        uint32_t nk = __builtin_amdgcn_inverse_ballot_w64(T) ? lane : nx;
         uint32_t rlo = lane < 32 ? 1u << lane : 0;
         uint32_t rhi = lane >= 32 ? 1u << (lane - 32) : 0;
 #pragma unroll
@@ -912,20 +918,20 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
         // and nk the one behind them - which the early exit must not lose)
         const uint64_t S = ((uint64_t)rdlane(rhi, 0) << 32) | rdlane(rlo, 0) |
                            (1ull << rdlane(nk, 0));
-        const bool is_start = __builtin_amdgcn_inverse_ballot_w64(S);
         // ---- 3. placement, window cut, checks ------------------------------
-        const bool elem = is_start && fits;
-        const uint32_t o = elem ? olen : 0;
+        const uint64_t M_elem = S & M_fits;
+        const uint32_t o =
+            __builtin_amdgcn_inverse_ballot_w64(M_elem) ? olen : 0;
         const uint32_t incl = wave_inclusive_add(o);
         // the window ends in front of the first start that is a long literal
         // or does not fit, and after kWinMax output bytes
-        const uint64_t stop = __ballot(is_start && !fits);
+        const uint64_t stop = S & ~M_fits;
         const uint64_t below =
             stop ? ((1ull << __builtin_ctzll(stop)) - 1) : ~0ull;
-        const uint64_t K = __ballot(elem && incl <= kWinMax) & below;
+        const uint64_t K = M_elem & __ballot(incl <= kWinMax) & below;
         if (K == 0) {
             // lane 0 is a literal of more than 64 bytes: wave_copy
-            const uint32_t lng0 = rdlane(lng ? 1u : 0u, 0);
+            const uint32_t lng0 = (uint32_t)M_lng & 1u;
             const uint64_t Lq = (uint64_t)rdlane(lraw, 0) + 1;
             const uint32_t h0 = rdlane(hd, 0);
             if (!lng0 || rem < h0 || src_len - (s + h0) < Lq ||
@@ -943,15 +949,14 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
                 w = ld64c(src, s + lane, src_len);
             continue;
         }
-        const bool keep = __builtin_amdgcn_inverse_ballot_w64(K);
         const uint32_t last = 63 - (uint32_t)__builtin_clzll(K);
         const uint32_t W = rdlane(incl, last);         // output of the window
         const uint32_t cur = last + rdlane(enc, last); // input consumed
         const uint32_t dstp = d + (incl - o);          // element's position
         // reference checks :209-217 (dst side), :245-250, :327-332
-        const bool cpy = keep && !is_lit;
+        const uint64_t M_cpy = K & ~M_lit;
         if ((uint64_t)d + W > dst_len ||
-            __ballot(cpy && (off == 0 || off > dstp)) != 0) {
+            (M_cpy & (__ballot(off == 0) | __ballot(off > dstp))) != 0) {
             irregular = true;
             break;
         }
@@ -975,30 +980,36 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
         const uint32_t dW = d + W + 16;
         uint32_t safe_lo = dW > kRing2 ? dW - kRing2 : 0;
         safe_lo = safe_lo > ring_lo ? safe_lo : ring_lo;
-        const bool ring_ok = q >= safe_lo;
-        const bool far_ok = q + n <= R.gflush;
+        const uint64_t M_ring = __ballot(q >= safe_lo);
         // 16-byte loads from HBM must stay inside the buffers: an element
         // that ends within 15 bytes of the input's / the output's end is
         // left to the sweep, which moves exactly its bytes
         const uint32_t pad = (olen + 15) & ~15u;
         const uint32_t dst_lim =
             dst_len < 0xFFFFFFFFull ? (uint32_t)dst_len : 0xFFFFFFFFu;
-        const bool lw =
-            keep &&
+        // lanes that copy their element themselves: literals (with their 16
+        // speculative bytes inside the input), copies whose whole source lies
+        // in front of the window, in the ring's safe part or stored already
+        const uint64_t M_litok =
+            deep ? M_lit
+                 : (inner ? M_lit & __ballot(lane + hd + pad <= rem) : 0);
+        const uint64_t M_src = __ballot(q + n <= d) & __ballot(olen <= off);
+        const uint64_t M_farok =
+            __ballot(q + n <= R.gflush) & __ballot(pad <= dst_lim - q);
+        const uint64_t M_lw =
+            K &
 #ifdef SNAPMI_DEC2_ONETRIP
-            olen <= 16 &&
+            __ballot(olen <= 16) &
 #endif
-            ((is_lit && (deep || (inner && lane + hd + pad <= rem))) ||
-             (cpy && q + n <= d && olen <= off &&
-              (ring_ok || (far_ok && pad <= dst_lim - q))));
-        const bool far = lw && cpy && !ring_ok;
+            (M_litok | (~M_lit & M_src & (M_ring | M_farok)));
+        const uint64_t M_far = M_lw & ~M_lit & ~M_ring; // source in HBM
+        const uint64_t M_rng = M_lw & ~M_lit & M_ring;  // source in the ring
         {
-            const uint64_t farm = __ballot(far);
-            if (farm) {
+            if (M_far) {
 #ifdef SNAPMI_PROFILE
-                n_far += __builtin_popcountll(farm);
+                n_far += __builtin_popcountll(M_far);
 #endif
-                if (__ballot(far && q + n > R.fenced) != 0) {
+                if ((M_far & __ballot(q + n > R.fenced)) != 0) {
                     R.fence_for(0xFFFFFFFFu);
                     COUNT(n_fence);
                 }
@@ -1011,31 +1022,35 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
             // context creation).  The pieces go last to first, so the excess
             // of an element's last piece is repaired by the first pieces of
             // its successors, which are all written by the last trip.
+            const uint64_t M_g16 = M_lw & __ballot(olen > 16);
             const uint32_t top =
-                __ballot(lw && olen > 48)
-                    ? 48
-                    : (__ballot(lw && olen > 32)
-                           ? 32
-                           : (__ballot(lw && olen > 16) ? 16 : 0));
+                M_g16 == 0 ? 0
+                           : ((M_g16 & __ballot(olen > 48))
+                                  ? 48
+                                  : ((M_g16 & __ballot(olen > 32)) ? 32 : 16));
+            // an element's own bytes wrap around the ring's end only in a
+            // window whose output does (uniform)
+            const bool wraps = (d & (kRing2 - 1)) + W > kRing2;
             for (uint32_t c = top;; c -= 16) {
 #ifdef SNAPMI_DEC2_NOTRIP
                 break;
 #endif
-                const bool act = lw && c < olen;
-                if (__ballot(act) != 0) {
+                const uint64_t M_act = c == 0 ? M_lw : M_lw & __ballot(c < olen);
+                if (M_act != 0) {
                     COUNT(n_trip);
-                    const uint32_t m = olen - c < 16 ? olen - c : 16;
                     // source: 16 bytes from the literal, the ring, or HBM
                     B16x v;
                     v.lo = v.hi = 0;
                     if (c == 0) {
                         v = lit16;
-                    } else if (act && is_lit) {
+                    } else if (__builtin_amdgcn_inverse_ballot_w64(M_act &
+                                                                   M_lit)) {
                         __builtin_memcpy(&v, src + s + lane + hd + c, 16);
                     }
-                    if (farm && act && far)
+                    if ((M_act & M_far) != 0 &&
+                        __builtin_amdgcn_inverse_ballot_w64(M_act & M_far))
                         __builtin_memcpy(&v, dst + q + c, 16);
-                    if (act && cpy && ring_ok) {
+                    if (__builtin_amdgcn_inverse_ballot_w64(M_act & M_rng)) {
                         // (only the lanes that need it: the LDS serves a wave's
                         // scattered unaligned reads a few lanes per cycle)
                         v.lo = lds_ld64(rg + ((q + c) & (kRing2 - 1)));
@@ -1044,10 +1059,16 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
                     const uint32_t wa = (dstp + c) & (kRing2 - 1);
                     // (rare) the element's own bytes wrap around the ring's
                     // end: those lanes store bytewise, after the others
-                    const bool strad = act && wa + m > kRing2;
-                    if (act && !strad)
+                    uint64_t M_strad = 0;
+                    uint32_t m = 16;
+                    if (wraps) {
+                        m = olen - c < 16 ? olen - c : 16;
+                        M_strad = M_act & __ballot(wa + m > kRing2);
+                    }
+                    if (__builtin_amdgcn_inverse_ballot_w64(M_act & ~M_strad))
                         __builtin_memcpy(rg + wa, &v, 16); // may reach the mirror
-                    if (__ballot(strad) != 0 && strad) {
+                    if (M_strad != 0 &&
+                        __builtin_amdgcn_inverse_ballot_w64(M_strad)) {
                         for (uint32_t j = 0; j < m; j++) {
                             const uint64_t part = j < 8 ? v.lo : v.hi;
                             rg[(wa + j) & (kRing2 - 1)] =
@@ -1060,7 +1081,7 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
             }
         }
         // ---- 5. the sweep: elements that depend on this window -------------
-        uint64_t dep = K & ~__ballot(lw);
+        uint64_t dep = K & ~M_lw;
 #ifdef SNAPMI_DEC2_NOSWEEP
         dep = 0;
 #endif
@@ -1070,7 +1091,7 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
             dep &= dep - 1;
             const uint32_t ni = rdlane(olen, i), di = rdlane(dstp, i);
             uint32_t val = 0;
-            if (rdlane(is_lit ? 1u : 0u, i)) {
+            if ((M_lit >> i) & 1) {
                 // (only windows at the very end of the input, `inner` false)
                 if (lane < ni)
                     val = src[s + i + rdlane(hd, i) + lane];
