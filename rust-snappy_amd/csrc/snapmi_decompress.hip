@@ -826,8 +826,13 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
     const uint64_t src_len = in_len - hdr;
     gptr dst = (gptr)a.out_ptrs[st];
 
-    uint64_t s = 0;       // position in src (uniform)
+    // Positions are 32-bit: there is no scalar 64-bit compare, each one in
+    // the window loop would be two VALU instructions.  dst_len < 2^32 by the
+    // format; a compressed stream of 4 GiB or more (legal, if every element
+    // is tiny) is left to the sequential decoder as a whole.
+    uint32_t s = 0;       // position in src (uniform)
     uint32_t d = 0;       // position in dst (uniform; dst_len < 2^32)
+    const uint32_t slen = (uint32_t)src_len, dlen = (uint32_t)dst_len;
     uint32_t ring_lo = 0; // the ring holds dst[max(ring_lo, d - 4096), d)
     Ring2 R;
     R.rg = (l_u8 *)ring_mem;
@@ -839,17 +844,16 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
 
     // streams too short for the 8-byte window loads go to the sequential
     // decoder at once; so does the first failed check
-    bool irregular = src_len < 8;
+    bool irregular = src_len < 8 || src_len > 0xFFE00000ull;
     uint64_t w = irregular ? 0 : ld64c(src, lane, src_len); // src[s+lane..]
 #ifdef SNAPMI_PROFILE
     uint64_t n_win = 0, n_elem = 0, n_dep = 0, n_fence = 0, n_far = 0,
              n_trip = 0;
 #endif
-    while (!irregular && s < src_len) {
+    while (!irregular && s < slen) {
         COUNT(n_win);
         // bytes of input left, as far as this window can see (<= 2^20)
-        const uint32_t rem =
-            src_len - s < (1u << 20) ? (uint32_t)(src_len - s) : 1u << 20;
+        const uint32_t rem = slen - s < (1u << 20) ? slen - s : 1u << 20;
         // ---- 1. the element that would start at src[s + lane] ------------
         const uint32_t tag = (uint32_t)w & 0xFF;
         const uint32_t b14 = (uint32_t)(w >> 8); // the 4 bytes after the tag
@@ -934,19 +938,18 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
             const uint32_t lng0 = (uint32_t)M_lng & 1u;
             const uint64_t Lq = (uint64_t)rdlane(lraw, 0) + 1;
             const uint32_t h0 = rdlane(hd, 0);
-            if (!lng0 || rem < h0 || src_len - (s + h0) < Lq ||
-                dst_len - d < Lq) {
+            if (!lng0 || rem < h0 || slen - (s + h0) < Lq || dlen - d < Lq) {
                 irregular = true; // the sequential decoder names the error
                 break;
             }
             R.flush_partial(d);
             wave_copy<false>(dst + d, src + s + h0, Lq, lane);
-            s += h0 + Lq;
+            s += h0 + (uint32_t)Lq;
             d += (uint32_t)Lq;
             R.gflush = d;
             ring_lo = d; // these bytes are not in the ring
-            if (s < src_len)
-                w = ld64c(src, s + lane, src_len);
+            if (s < slen)
+                w = ld64c(src, (uint64_t)s + lane, src_len);
             continue;
         }
         const uint32_t last = 63 - (uint32_t)__builtin_clzll(K);
@@ -955,7 +958,7 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
         const uint32_t dstp = d + (incl - o);          // element's position
         // reference checks :209-217 (dst side), :245-250, :327-332
         const uint64_t M_cpy = K & ~M_lit;
-        if ((uint64_t)d + W > dst_len ||
+        if (W > dlen - d ||
             (M_cpy & (__ballot(off == 0) | __ballot(off > dstp))) != 0) {
             irregular = true;
             break;
@@ -967,10 +970,10 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
         // (plain unaligned loads while the next window lies inside the
         // input - a uniform test; the clamped form only at the stream's end)
         uint64_t w_next;
-        if (s + cur + kWave + 8 <= src_len)
+        if (slen - s >= cur + kWave + 8)
             __builtin_memcpy(&w_next, src + (s + cur) + lane, 8);
         else
-            w_next = ld64c(src, s + cur + lane, src_len);
+            w_next = ld64c(src, (uint64_t)s + cur + lane, src_len);
 
         // ---- 4. the lane-parallel copy step --------------------------------
         const uint32_t q = dstp - off;               // copy source (if cpy)
@@ -985,8 +988,7 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
         // that ends within 15 bytes of the input's / the output's end is
         // left to the sweep, which moves exactly its bytes
         const uint32_t pad = (olen + 15) & ~15u;
-        const uint32_t dst_lim =
-            dst_len < 0xFFFFFFFFull ? (uint32_t)dst_len : 0xFFFFFFFFu;
+        const uint32_t dst_lim = dlen;
         // lanes that copy their element themselves: literals (with their 16
         // speculative bytes inside the input), copies whose whole source lies
         // in front of the window, in the ring's safe part or stored already
