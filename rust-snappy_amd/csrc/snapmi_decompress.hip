@@ -207,21 +207,27 @@ __device__ __forceinline__ uint32_t dpp_get(uint32_t v)
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK,
                                                  0xF, false);
 }
-// row_shr with all rows enabled: lanes without a source read zero
-// (bound_ctrl), so the move folds into the add (v_add_u32_dpp)
-template <int CTRL> __device__ __forceinline__ uint32_t dpp_shr0(uint32_t v)
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF,
-                                                 true);
-}
+// Inclusive prefix sum over the wave: six v_add_u32_dpp.  (Through the
+// update_dpp builtin every step is a v_mov_dpp plus an add - the compiler
+// does not fold them - and the decoders' window loop is bound by VALU issue.)
+// A DPP operand written by the instruction in front needs two wait states.
 __device__ __forceinline__ uint32_t wave_inclusive_add(uint32_t v)
 {
-    v += dpp_shr0<0x111>(v);
-    v += dpp_shr0<0x112>(v);
-    v += dpp_shr0<0x114>(v);
-    v += dpp_shr0<0x118>(v);
-    v += dpp_get<0x142, 0xA>(v);
-    v += dpp_get<0x143, 0xC>(v);
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
     return v;
 }
 // OR of v over all lanes (uniform result)
@@ -977,7 +983,9 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
 
         // ---- 4. the lane-parallel copy step --------------------------------
         const uint32_t q = dstp - off;               // copy source (if cpy)
-        const uint32_t n = olen < off ? olen : off;  // bytes a copy reads
+        // (a copy that a lane moves by itself does not overlap its source:
+        // olen <= off, it reads olen bytes)
+        const uint32_t qe = q + olen;
         // (whole 16-byte pieces are stored: up to 15 bytes behind the window's
         // output may be clobbered too)
         const uint32_t dW = d + W + 16;
@@ -987,17 +995,20 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
         // 16-byte loads from HBM must stay inside the buffers: an element
         // that ends within 15 bytes of the input's / the output's end is
         // left to the sweep, which moves exactly its bytes
-        const uint32_t pad = (olen + 15) & ~15u;
-        const uint32_t dst_lim = dlen;
+        // (for a literal near the end of the input the exact figure, for a
+        // copy from HBM 64: elements of a window have at most 64 bytes)
         // lanes that copy their element themselves: literals (with their 16
         // speculative bytes inside the input), copies whose whole source lies
         // in front of the window, in the ring's safe part or stored already
         const uint64_t M_litok =
             deep ? M_lit
-                 : (inner ? M_lit & __ballot(lane + hd + pad <= rem) : 0);
-        const uint64_t M_src = __ballot(q + n <= d) & __ballot(olen <= off);
+                 : (inner ? M_lit & __ballot(lane + hd + ((olen + 15) & ~15u) <=
+                                             rem)
+                          : 0);
+        const uint64_t M_src = __ballot(qe <= d) & __ballot(olen <= off);
         const uint64_t M_farok =
-            __ballot(q + n <= R.gflush) & __ballot(pad <= dst_lim - q);
+            dlen >= 64 ? __ballot(qe <= R.gflush) & __ballot(q <= dlen - 64)
+                       : 0;
         const uint64_t M_lw =
             K &
 #ifdef SNAPMI_DEC2_ONETRIP
@@ -1011,7 +1022,7 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
 #ifdef SNAPMI_PROFILE
                 n_far += __builtin_popcountll(M_far);
 #endif
-                if ((M_far & __ballot(q + n > R.fenced)) != 0) {
+                if ((M_far & __ballot(qe > R.fenced)) != 0) {
                     R.fence_for(0xFFFFFFFFu);
                     COUNT(n_fence);
                 }

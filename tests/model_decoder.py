@@ -201,7 +201,7 @@ def decode(comp, stats=None):
         lanewise = keep & np.where(
             is_lit, inner & (LANE + hd + pad <= rem),
             (q + n <= d) & (olen <= off) &
-            np.where(ring_ok, True, far_ok & (q + pad <= dst_len)))
+            np.where(ring_ok, True, far_ok & (q + 64 <= dst_len)))
         far = lanewise & ~is_lit & ~ring_ok
 
         def fence_for(limit):
