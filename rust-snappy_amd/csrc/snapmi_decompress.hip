@@ -901,9 +901,13 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
         // 16 literal bytes, speculatively (only windows well inside the input)
         const bool inner = rem >= 64 + 5 + 16;
         B16x lit16;
-        lit16.lo = lit16.hi = 0;
+        // (uniform base + 32-bit lane offset: the load takes the base from
+        // SGPRs and no 64-bit vector adds are spent on the address)
+        const gcptr win_src = src + s;
         if (inner) {
-            __builtin_memcpy(&lit16, src + s + lane + hd, 16);
+            __builtin_memcpy(&lit16, win_src + (lane + hd), 16);
+        } else {
+            lit16.lo = lit16.hi = 0;
         }
         // ---- 2. element starts: the orbit of lane 0 under "next" ----------
         // (a lane whose element ends the chain - it reaches past the window,
@@ -1052,17 +1056,17 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
                 if (M_act != 0) {
                     COUNT(n_trip);
                     // source: 16 bytes from the literal, the ring, or HBM
-                    B16x v;
-                    v.lo = v.hi = 0;
-                    if (c == 0) {
-                        v = lit16;
-                    } else if (__builtin_amdgcn_inverse_ballot_w64(M_act &
-                                                                   M_lit)) {
-                        __builtin_memcpy(&v, src + s + lane + hd + c, 16);
+                    // (a lane that loads nothing below stores nothing either:
+                    // whatever v starts with - the literal bytes of trip 0 -
+                    // is never seen)
+                    B16x v = lit16;
+                    if (c != 0 && __builtin_amdgcn_inverse_ballot_w64(
+                                      M_act & M_lit)) {
+                        __builtin_memcpy(&v, win_src + (lane + hd + c), 16);
                     }
                     if ((M_act & M_far) != 0 &&
                         __builtin_amdgcn_inverse_ballot_w64(M_act & M_far))
-                        __builtin_memcpy(&v, dst + q + c, 16);
+                        __builtin_memcpy(&v, dst + (q + c), 16);
                     if (__builtin_amdgcn_inverse_ballot_w64(M_act & M_rng)) {
                         // (only the lanes that need it: the LDS serves a wave's
                         // scattered unaligned reads a few lanes per cycle)
