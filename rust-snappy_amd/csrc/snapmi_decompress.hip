@@ -782,7 +782,10 @@ struct Ring2 {
 // 8 waves per SIMD (64 VGPRs, 5 KiB of LDS each): the kernel waits on a chain
 // of LDS / HBM round trips per window, and two more waves to switch to are
 // worth more than the 9 spilled dwords (36.0 -> 32.2 ms at cfg2).
-__attribute__((amdgpu_waves_per_eu(8, 8)))
+#ifndef SNAPMI_DEC2_WAVES
+#define SNAPMI_DEC2_WAVES 8
+#endif
+__attribute__((amdgpu_waves_per_eu(SNAPMI_DEC2_WAVES, SNAPMI_DEC2_WAVES)))
 __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t ring_mem[kRing2 + 16];
