@@ -1073,8 +1073,12 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
                     if (__builtin_amdgcn_inverse_ballot_w64(M_act & M_rng)) {
                         // (only the lanes that need it: the LDS serves a wave's
                         // scattered unaligned reads a few lanes per cycle)
+#ifdef SNAPMI_DEC2_RD128 // experiment: one unaligned 16-byte read
+                        __builtin_memcpy(&v, rg + ((q + c) & (kRing2 - 1)), 16);
+#else
                         v.lo = lds_ld64(rg + ((q + c) & (kRing2 - 1)));
                         v.hi = lds_ld64(rg + ((q + c + 8) & (kRing2 - 1)));
+#endif
                     }
                     const uint32_t wa = (dstp + c) & (kRing2 - 1);
                     // (rare) the element's own bytes wrap around the ring's
