@@ -525,7 +525,16 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
             // with k_probe_tables (the kernel's own access pattern: dependent
             // random 16-byte read + write per lane), and the fastest is kept.
             const size_t bytes = (size_t)lanes * stride;
-            void *best = nullptr, *loser = nullptr;
+            // (an error on the way out frees what was allocated here)
+            struct Regions {
+                void *best = nullptr, *loser = nullptr, *cand = nullptr;
+                ~Regions()
+                {
+                    for (void *p : {best, loser, cand})
+                        if (p)
+                            (void)hipFree(p);
+                }
+            } rg;
             float best_ms = 0;
             ctx->probe_log.clear();
             // (only worth it for a launch that fills the chip: a small
@@ -534,7 +543,9 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                 lanes >= 16384 && ctx->lane_table_tries
                     ? ctx->lane_table_tries : 1;
             for (uint32_t t = 0; t < tries; t++) {
-                void *cand = nullptr;
+                void *&cand = rg.cand;
+                void *&best = rg.best, *&loser = rg.loser;
+                cand = nullptr;
                 // (uncached: MTYPE UC - the tables never hit in L2 anyway,
                 // tests/hw/random_policy.hip)
                 if ((ctx->lane_tables_uncached
@@ -545,8 +556,9 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                     break; // no room for another candidate: keep the best
                 }
                 if (loser) {
-                    HIP_TRY(ctx, hipFree(loser));
+                    void *gone = loser;
                     loser = nullptr;
+                    HIP_TRY(ctx, hipFree(gone));
                 }
                 // (the probe runs on the memory as it comes: only the region
                 // that is kept gets zeroed, 50 ms for 25 GB of tables)
@@ -577,10 +589,14 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                 } else {
                     loser = cand;
                 }
+                cand = nullptr;
             }
+            void *&best = rg.best, *&loser = rg.loser;
             if (loser) {
                 HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-                HIP_TRY(ctx, hipFree(loser));
+                void *gone = loser;
+                loser = nullptr;
+                HIP_TRY(ctx, hipFree(gone));
             }
             if (!best)
                 return fail_ctx(ctx, SNAPMI_E_DEVICE,
@@ -590,6 +606,7 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
             HIP_TRY(ctx, hipMemset2DAsync(best, stride, 0, tbytes, lanes,
                                           ctx->stream));
             ctx->lane_tables.p = best;
+            best = nullptr; // the context owns it now
             ctx->lane_tables.cap = bytes;
             ctx->lane_stride = stride / 16;
             HIP_TRY(ctx, hipMemsetAsync(ctx->lane_epochs.p, 0,
