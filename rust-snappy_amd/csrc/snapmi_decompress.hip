@@ -699,6 +699,15 @@ __global__ __launch_bounds__(64) void k_decompress_streams(DecompressArgs a)
 //   6. the ring goes to HBM 256 bytes at a time (one dword per lane), so
 //      global stores are whole aligned lines instead of 64 byte stores.
 //
+// The window loop is bound by instruction issue - VALU (a wave64 integer
+// instruction holds its SIMD for four cycles) and the CU's one scalar unit
+// about equally - so it is written for few instructions: predicates are
+// 64-bit lane masks in SGPRs, combined with scalar ALU operations and handed
+// back to the vector side as they are (inverse ballot); positions are 32-bit
+// (no scalar 64-bit compare exists); tests that only matter near the end of
+// the input sit behind one uniform branch (`deep`); addresses are a uniform
+// base plus a 32-bit lane offset.
+//
 // Everything irregular - a failed check, an element cut off by the end of
 // the input - stops the wide path at a window boundary: the ring is stored
 // and the sequential decoder above finishes the stream from (s, d) with the
