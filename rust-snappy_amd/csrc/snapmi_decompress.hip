@@ -922,28 +922,41 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
             lit16.lo = lit16.hi = 0;
         }
         // ---- 2. element starts: the orbit of lane 0 under "next" ----------
-        // (a lane whose element ends the chain - it reaches past the window,
-        // or is a long literal - points at itself: the doubling then needs no
-        // "is there a next" select, 3 VALU per round instead of 8)
+        // A ds_bpermute costs the CU's one LDS pipeline about as much as
+        // seven VALU instructions cost its four SIMDs (tests/hw/lds_cost.hip:
+        // 6.4 cycles), so the discovery moves ONE dword per round: the wave
+        // is two halves of 32 positions, and a lane's set R (32 bits, its own
+        // half) holds the first nodes of its chain INCLUDING the frontier -
+        // the node not yet expanded, which is the set's highest bit because
+        // chains run forward.  One round: R |= R[frontier].  After k rounds a
+        // set holds 2^k + 1 nodes; a half has at most 16 (every element has
+        // two bytes or more), so four rounds finish it.  A lane whose element
+        // ends its chain - long literal, behind the input, or reaching into
+        // the other half / out of the window - has no frontier beyond itself
+        // and fetches its own set.  The two halves are strung together by
+        // the scalar unit afterwards.
         const uint32_t nx = lane + enc;
-        const uint64_t T = M_lng | __ballot(nx >= kWave) |
-                           (deep ? 0 : __ballot(lane >= rem));
-        uint32_t nk = __builtin_amdgcn_inverse_ballot_w64(T) ? lane : nx;
-        uint32_t rlo = lane < 32 ? 1u << lane : 0;
-        uint32_t rhi = lane >= 32 ? 1u << (lane - 32) : 0;
+        const uint64_t T = M_lng | (deep ? 0 : __ballot(lane >= rem));
+        const uint64_t M_stay = ~T & __ballot((nx ^ lane) < 32);
+        uint32_t Rr = (1u << (lane & 31)) |
+                      (__builtin_amdgcn_inverse_ballot_w64(M_stay)
+                           ? 1u << (nx & 31)
+                           : 0);
+        const int c4 = (int)((lane | 31) << 2);
 #pragma unroll
-        for (uint32_t k = 0; k < 5; k++) {
-            const int sel = (int)(nk << 2);
-            rlo |= (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)rlo);
-            rhi |= (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)rhi);
-            nk = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)nk);
-            if (k >= 2 && ((T >> rdlane(nk, 0)) & 1))
-                break; // lane 0's chain has reached its last element
+        for (uint32_t k = 0; k < 4; k++) {
+            const int sel = c4 - 4 * (int)__builtin_clz(Rr);
+            Rr |= (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)Rr);
         }
-        // (after k rounds a lane's set holds the first 2^k lanes of its chain
-        // and nk the one behind them - which the early exit must not lose)
-        const uint64_t S = ((uint64_t)rdlane(rhi, 0) << 32) | rdlane(rlo, 0) |
-                           (1ull << rdlane(nk, 0));
+        uint64_t S = rdlane(Rr, 0);
+        {
+            // the last start of the lower half: does its element lead into
+            // the upper half?
+            const uint32_t t0 = 31 - (uint32_t)__builtin_clz((uint32_t)S);
+            const uint32_t nx0 = rdlane(nx, t0);
+            if (!((T >> t0) & 1) && nx0 < kWave)
+                S |= (uint64_t)rdlane(Rr, nx0) << 32;
+        }
         // ---- 3. placement, window cut, checks ------------------------------
         const uint64_t M_elem = S & M_fits;
         const uint32_t o =
@@ -1082,11 +1095,14 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
                     if (__builtin_amdgcn_inverse_ballot_w64(M_act & M_rng)) {
                         // (only the lanes that need it: the LDS serves a wave's
                         // scattered unaligned reads a few lanes per cycle)
-#ifdef SNAPMI_DEC2_RD128 // experiment: one unaligned 16-byte read
-                        __builtin_memcpy(&v, rg + ((q + c) & (kRing2 - 1)), 16);
-#else
+                        // (one unaligned 16-byte read costs the LDS one
+                        // cycle per lane, two 8-byte reads two:
+                        // tests/hw/lds_cost.hip; it may run into the mirror)
+#ifdef SNAPMI_DEC2_RD64
                         v.lo = lds_ld64(rg + ((q + c) & (kRing2 - 1)));
                         v.hi = lds_ld64(rg + ((q + c + 8) & (kRing2 - 1)));
+#else
+                        __builtin_memcpy(&v, rg + ((q + c) & (kRing2 - 1)), 16);
 #endif
                     }
                     const uint32_t wa = (dstp + c) & (kRing2 - 1);

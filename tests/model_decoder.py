@@ -122,21 +122,27 @@ def decode(comp, stats=None):
         inner = rem >= 64 + 5 + 16      # speculative 16-byte literal loads
         nx = np.where(long_ | (LANE >= rem), WAVE,
                       np.minimum(LANE + enc, WAVE))
-        # ---- element starts: S = orbit of lane 0 under nx (mask doubling) --
-        # A lane that ends the chain points at itself, so the doubling needs
-        # no "is there a next" select.  After k rounds a lane's set holds the
-        # first 2^k lanes of its chain and nk the one behind them; lane 0's
-        # rounds stop early once its nk is a chain end, and that lane is
-        # added to the set (it may be hop 2^k exactly).
-        term = nx >= WAVE
-        reach = (np.uint64(1) << LANE.astype(np.uint64))
-        nk = np.where(term, LANE, nx)
-        for k in range(5):      # 2^5 = 32 hops >= elements per window
-            reach = reach | reach[nk]
-            nk = nk[nk]
-            if k >= 2 and term[nk[0]]:
-                break
-        S = int(reach[0]) | (1 << int(nk[0]))
+        # ---- element starts: S = orbit of lane 0 under nx ------------------
+        # One dword per round (a ds_bpermute is what costs): the wave is two
+        # halves of 32 positions; a lane's set R (32 bits, its own half)
+        # holds the first nodes of its chain INCLUDING the frontier, which is
+        # the set's highest bit because chains run forward.  One round:
+        # R |= R[frontier].  After k rounds a set has 2^k + 1 nodes; a half
+        # has at most 16 (an element has two bytes or more): four rounds.  A
+        # lane whose element ends the chain (long literal, behind the input,
+        # or leaving its half) fetches its own set.  The halves are strung
+        # together afterwards.
+        term = long_ | (LANE >= rem)
+        nxl = LANE + enc
+        stay = ~term & ((nxl ^ LANE) < 32)
+        Rr = (1 << (LANE & 31)) | np.where(stay, 1 << (nxl & 31), 0)
+        for k in range(4):
+            top = np.array([int(x).bit_length() - 1 for x in Rr])
+            Rr = Rr | Rr[(LANE & 32) + top]
+        S = int(Rr[0])
+        t0 = S.bit_length() - 1
+        if not term[t0] and nxl[t0] < WAVE:
+            S |= int(Rr[int(nxl[t0])]) << 32
         is_start = np.array([(S >> i) & 1 for i in range(WAVE)], dtype=bool)
         # reference walk, to check the doubling
         p, walk = 0, 0
