@@ -111,7 +111,7 @@ int snapmi_ctx_create(int device, void *hip_stream, snapmi_ctx **out)
         if (const char *e = getenv("SNAPMI_LANE_DIRECT"))
             ctx->lane_direct_encode = atoi(e) != 0;
         if (const char *e = getenv("SNAPMI_DECODE_KERNEL"))
-            ctx->decode_kernel = atoi(e) == 1 ? 1 : 2;
+            ctx->decode_kernel = atoi(e) == 0 ? 0 : (atoi(e) == 2 ? 2 : 3);
         if (const char *m = getenv("SNAPMI_COMPRESS"))
             ctx->compress_mode = strcmp(m, "waves") == 0
                                      ? 0
@@ -170,11 +170,11 @@ int snapmi_ctx_create(int device, void *hip_stream, snapmi_ctx **out)
         ctx->lds_order_ok = ctx->lds_order_hw = (bad & 1) == 0;
         if (bad & 2) { // the element-major decoder needs ordered DS stores
             ctx->lds_store_order_ok = false;
-            ctx->decode_kernel = 1;
+            ctx->decode_kernel = 0;
             fprintf(stderr,
                     "snapmi: this device does not apply overlapping lanes of "
-                    "one DS store in ascending lane order; the byte-per-lane "
-                    "decoder is used\n");
+                    "one DS store in ascending lane order; streams are "
+                    "decoded one element at a time\n");
         }
         if (!ctx->lds_order_ok)
             fprintf(stderr,
@@ -261,8 +261,9 @@ int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value)
         ctx->frame_walk_segment = (uint64_t)value;
     else if (strcmp(name, "frame_parallel_walk_min") == 0 && value >= 0)
         ctx->frame_parallel_walk_min = (uint64_t)value;
-    else if (strcmp(name, "decode_kernel") == 0 && value >= 1 && value <= 2)
-        ctx->decode_kernel = ctx->lds_store_order_ok ? (int)value : 1;
+    else if (strcmp(name, "decode_kernel") == 0 &&
+             (value == 0 || value == 2 || value == 3))
+        ctx->decode_kernel = ctx->lds_store_order_ok ? (int)value : 0;
     else if (strcmp(name, "lane_table_tries") == 0 && value >= 1 &&
              value <= 16)
         ctx->lane_table_tries = (uint32_t)value;
@@ -798,11 +799,14 @@ int launch_decompress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], s));
     hipLaunchKernelGGL(k_plan_decompress, dim3(1), dim3(1024), 0, s, a);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], s));
-    if (ctx->decode_kernel == 1)
-        hipLaunchKernelGGL(k_decompress_streams, dim3((uint32_t)n), dim3(64),
+    if (ctx->decode_kernel == 0)
+        hipLaunchKernelGGL(k_decompress_sequential, dim3((uint32_t)n),
+                           dim3(64), 0, s, a);
+    else if (ctx->decode_kernel == 2)
+        hipLaunchKernelGGL(k_decompress_streams2, dim3((uint32_t)n), dim3(64),
                            0, s, a);
     else
-        hipLaunchKernelGGL(k_decompress_streams2, dim3((uint32_t)n), dim3(64),
+        hipLaunchKernelGGL(k_decompress_streams3, dim3((uint32_t)n), dim3(64),
                            0, s, a);
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], s));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[3], s));

@@ -53,9 +53,10 @@ struct snapmi_ctx {
     int lane_direct_encode = 1;
     // 1: the lane tables come from hipExtMallocWithFlags(hipDeviceMallocUncached)
     int lane_tables_uncached = 0;
-    // 2: element-major decoder k_decompress_streams2 (default); 1: the
-    // first-generation byte-per-lane kernel, kept as a cross-check
-    int decode_kernel = 2;
+    // 3: k_decompress_streams3 (element per lane, 128-byte windows; default);
+    // 2: k_decompress_streams2 (64-byte windows), kept as a cross-check;
+    // 0: the sequential decoder alone
+    int decode_kernel = 3;
     hipStream_t stream2 = nullptr; // the wavefront kernel's side stream
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_crc[2] = {nullptr, nullptr}; // frame encode: CRC on stream2

@@ -210,11 +210,13 @@ __device__ __forceinline__ uint32_t dpp_get(uint32_t v)
 // Inclusive prefix sum over the wave: six v_add_u32_dpp.  (Through the
 // update_dpp builtin every step is a v_mov_dpp plus an add - the compiler
 // does not fold them - and the decoders' window loop is bound by VALU issue.)
-// A DPP operand written by the instruction in front needs two wait states.
+// A DPP operand written by the instruction in front needs two wait states;
+// the compiler cannot see into the asm, so the first pad also covers the
+// worst case in front of it (a VALU write of EXEC: five wait states).
 __device__ __forceinline__ uint32_t wave_inclusive_add(uint32_t v)
 {
     asm volatile(
-        "s_nop 1\n\t"
+        "s_nop 4\n\t"
         "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "s_nop 1\n\t"
         "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
@@ -362,325 +364,20 @@ __global__ __launch_bounds__(1024) void k_plan_decompress(DecompressArgs a)
 }
 
 // ---------------------------------------------------------------------
-// K2: one wavefront per raw stream.
-// ---------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_decompress_streams(DecompressArgs a)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t ring[kRing];
-    // one bit per output byte of the current window (at most 64 elements of
-    // at most 64 bytes): set where an element starts
-    __shared__ __attribute__((aligned(8))) uint32_t starts[kWave * kWave / 32];
-
-    const uint32_t lane = threadIdx.x;
-    if (a.gate && uni64(*a.gate) != a.gate_value)
-        return;
-    starts[lane] = 0;
-    starts[lane + kWave] = 0;
-    const uint64_t st = a.order[blockIdx.x];
-    gcptr in = (gcptr)a.in_ptrs[st];
-    const uint64_t in_len = a.in_lens[st];
-    const bool piece = a.modes && a.modes[st] == 2;
-
-    if (a.modes && a.modes[st] == 1) {
-        // stored frame chunk (reference src/read.rs:173-199): the payload is
-        // the data (wave_copy)
-        const uint64_t cap0 = a.out_caps[st];
-        if (in_len > cap0)
-            SNAPMI_FAIL(SNAPMI_BUFFER_TOO_SMALL, cap0, in_len, 0);
-        wave_copy<false>((gptr)a.out_ptrs[st], in, in_len, lane);
-        if (lane == 0) {
-            set_error(a.errs, st, SNAPMI_OK, 0, 0, 0);
-            a.out_lens[st] = in_len;
-        }
-        return;
-    }
-    // reference Decoder::decompress, src/decompress.rs:75-95
-    uint32_t hdr = 0;
-    uint64_t dst_len = 0;
-    if (piece) { // elements [in, in + in_len) produce exactly out_caps bytes
-        dst_len = a.out_caps[st];
-    } else {
-        if (in_len == 0)
-            SNAPMI_FAIL(SNAPMI_EMPTY, 0, 0, 0);
-        snapmi_error *e = lane == 0 ? a.errs : nullptr;
-        if (read_header(in, in_len, &hdr, &dst_len, e, st) != SNAPMI_OK) {
-            if (lane == 0)
-                a.out_lens[st] = 0;
-            return;
-        }
-    }
-    // the header came through vector loads: pin it (and everything derived
-    // from it) to SGPRs so the decoder state is scalar
-    hdr = uni(hdr);
-    dst_len = uni64(dst_len);
-    const uint64_t cap = a.out_caps[st];
-    if (dst_len > cap)
-        SNAPMI_FAIL(SNAPMI_BUFFER_TOO_SMALL, cap, dst_len, 0);
-
-    gcptr src = in + hdr;
-    const uint64_t src_len = in_len - hdr;
-    gptr dst = (gptr)a.out_ptrs[st];
-
-    uint64_t s = 0;       // position in src (uniform)
-    uint64_t d = 0;       // position in dst (uniform)
-    uint64_t done_lo = 0; // stores to dst[0..done_lo) have completed
-    uint64_t ring_lo = 0; // ring holds dst[max(ring_lo, d-kRing+64) .. d)
-
-    // Leaves the wide path: streams too short for the 8-byte window loads,
-    // and the first failed check (the sequential decoder then reproduces the
-    // exact snap::Error, resuming at the current (s, d)).
-    bool irregular = src_len < 8;
-#ifdef SNAPMI_PROFILE
-    uint64_t pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    uint64_t t_last = __builtin_readcyclecounter();
-    uint64_t n_win = 0, n_pass = 0, n_elem = 0, n_fence = 0, n_res = 0;
-#endif
-    uint64_t w = irregular ? 0 : ld64c(src, lane, src_len); // src[s+lane..]
-    while (!irregular && s < src_len) {
-        COUNT(n_win);
-        TICK(0);
-        // ---- 1. PARSE: the element that would start at src[s + lane] ----
-        const uint64_t pos = s + lane;
-        const uint32_t limit =
-            src_len - s < kWave ? (uint32_t)(src_len - s) : kWave;
-        const uint32_t tag = (uint32_t)w & 0xFF;
-        const uint32_t b14 = (uint32_t)(w >> 8); // the 4 bytes after the tag
-        const uint32_t type = tag & 3;
-        const bool is_lit = type == 0;
-        // literal view (reference read_literal, src/decompress.rs:161-228)
-        const uint32_t n6 = tag >> 2;
-        const uint32_t lnb = n6 >= 60 ? n6 - 59 : 0; // extra length bytes
-        const uint32_t lmask = lnb == 4 ? 0xFFFFFFFFu : ((1u << (8 * lnb)) - 1);
-        const uint64_t L = lnb ? (uint64_t)(b14 & lmask) + 1 : n6 + 1;
-        const uint32_t lhd = 1 + lnb;
-        const bool lbad = (lnb && pos + 5 > src_len) ||      // :189-198
-                          (src_len - (pos + lhd) < L);       // :209-217 (src)
-        // copy view (reference TagEntry::offset / read_copy, :233-250,433-474)
-        const uint32_t cnb = type == 1 ? 1 : (type == 2 ? 2 : 4);
-        const uint32_t clen = type == 1 ? 4 + ((tag >> 2) & 7) : 1 + (tag >> 2);
-        const uint32_t coff = type == 1 ? (((tag >> 5) << 8) | (b14 & 0xFF))
-                                        : (type == 2 ? (b14 & 0xFFFF) : b14);
-        const bool cbad = pos + 1 + cnb > src_len; // CopyRead
-        // merged
-        const bool lng = is_lit && L > 64;
-        const bool in_stream = lane < limit;
-        const bool elem_pos = in_stream && !lng; // may start a window element
-        const uint32_t olen = is_lit ? (lng ? 0 : (uint32_t)L) : clen;
-        const uint32_t enc = is_lit ? (lng ? 0 : lhd + (uint32_t)L) : 1 + cnb;
-        const uint32_t key = is_lit ? lane + lhd : coff;
-        const bool sbad = is_lit ? lbad : cbad;
-        // record gathered per element: enc | olen<<7 | lit<<14 | bad<<15 |
-        // elem_pos<<16 | lng<<17
-        const uint32_t rec = enc | (olen << 7) | (is_lit ? 1u << 14 : 0) |
-                             (sbad ? 1u << 15 : 0) |
-                             (elem_pos ? 1u << 16 : 0) | (lng ? 1u << 17 : 0);
-        TICK(1);
-        TICK(2);
-        // Element starts by pointer jumping: x = position (0..63, 64 = out)
-        // of the t-th element in lane t; nk = 2^k-fold successor.
-        uint32_t nk = elem_pos ? (lane + enc < kWave ? lane + enc : kWave)
-                               : kWave;
-        uint32_t x = lane == 0 ? 0 : kWave;
-#pragma unroll
-        for (uint32_t k = 0; k < 6; k++) {
-            const uint32_t sh = 1u << k;
-            const uint32_t xp = (uint32_t)__builtin_amdgcn_ds_bpermute(
-                (int)(((lane - sh) & 63) << 2), (int)x);
-            const uint32_t g = (uint32_t)__builtin_amdgcn_ds_bpermute(
-                (int)((xp & 63) << 2), (int)nk);
-            const uint32_t sq = (uint32_t)__builtin_amdgcn_ds_bpermute(
-                (int)((nk & 63) << 2), (int)nk);
-            if (lane >= sh && lane < 2 * sh)
-                x = xp >= kWave ? kWave : g;
-            nk = nk >= kWave ? kWave : sq;
-            if (k < 5 && rdlane(x, 2 * sh - 1) >= kWave)
-                break; // the chain has left the window
-        }
-        // element t's record, from the lane of its first byte
-        const uint32_t xr = (uint32_t)__builtin_amdgcn_ds_bpermute(
-            (int)((x & 63) << 2), (int)rec);
-        const uint32_t xkey = (uint32_t)__builtin_amdgcn_ds_bpermute(
-            (int)((x & 63) << 2), (int)key);
-        const bool is_elem = x < kWave && ((xr >> 16) & 1);
-        const uint64_t emask = __ballot(is_elem); // a prefix of the lanes
-        const uint32_t E = (uint32_t)__builtin_popcountll(emask);
-        // what follows the last element: end of window, or a long literal
-        const uint32_t xE = E < kWave ? rdlane(x, E) : kWave;
-        const bool hit_long =
-            E < kWave && xE < kWave && ((rdlane(xr, E) >> 17) & 1);
-        uint32_t cur = 0; // bytes of the stream consumed by this window
-        if (E) {
-            const uint32_t lr = rdlane(xr, E - 1);
-            cur = rdlane(x, E - 1) + (lr & 0x7F);
-        }
-        TICK(3);
-        const uint32_t e_olen = is_elem ? (xr >> 7) & 0x7F : 0;
-        const bool e_lit = (xr >> 14) & 1;
-        // output position of every element: DPP scan of the lengths
-        const uint32_t incl = wave_inclusive_add(e_olen);
-        const uint32_t W = rdlane(incl, kWave - 1); // window output bytes
-        const uint32_t f_rel = incl - e_olen;       // element's offset in it
-        const uint64_t de = d + f_rel;
-        // the reference's remaining checks, per element (:209-217,:245-250,
-        // :327-332); de + olen cannot wrap: both are < 2^33
-        bool bad = (xr >> 15) & 1;
-        bad = bad || (de + e_olen > dst_len) ||
-              (!e_lit && de <= (uint64_t)xkey - 1);
-        if (__ballot(is_elem && bad) != 0) {
-            irregular = true; // first failed check, in this window
-            break;
-        }
-        const uint32_t f_info = e_olen | (e_lit ? 0x80000000u : 0);
-        const uint32_t f_key = xkey;
-        if (is_elem) // element-start bits of this window (cleared pass by pass)
-            atomicOr(&starts[f_rel >> 5], 1u << (f_rel & 31));
-        TICK(4);
-#ifdef SNAPMI_PROFILE
-        n_elem += E;
-#endif
-        // next window's bytes: issued now, consumed after the expand
-        uint64_t w_next = 0;
-        if (!hit_long)
-            w_next = ld64c(src, s + cur + lane, src_len);
-        TICK(5);
-
-        // ---- 2. EXPAND: 64 output bytes per pass --------------------------
-        for (uint32_t c0 = 0; c0 < W; c0 += kWave) {
-            COUNT(n_pass);
-            const uint64_t cs = d + c0; // absolute position of lane 0's byte
-            const uint32_t r = c0 + lane;
-            const bool act = r < W;
-            // element of each byte: starts inside this pass as a bit mask
-            const uint64_t M = uni64(*(const uint64_t *)&starts[c0 >> 5]);
-            if (lane == 0)
-                *(uint64_t *)&starts[c0 >> 5] = 0;
-            const uint32_t nbefore = (uint32_t)__builtin_popcountll(
-                __ballot(is_elem && f_rel < c0));
-            const uint32_t idx = nbefore - 1 + popc_below(M) +
-                                 (uint32_t)((M >> lane) & 1);
-            const uint32_t e_rel = (uint32_t)__builtin_amdgcn_ds_bpermute(
-                (int)(idx << 2), (int)f_rel);
-            const uint32_t e_info = (uint32_t)__builtin_amdgcn_ds_bpermute(
-                (int)(idx << 2), (int)f_info);
-            const uint32_t e_key = (uint32_t)__builtin_amdgcn_ds_bpermute(
-                (int)(idx << 2), (int)f_key);
-            const uint32_t k = r - e_rel; // byte index inside the element
-            const bool lit = (e_info >> 31) != 0;
-            const uint32_t elen = e_info & 0x7FFFFFFFu;
-            TICK(6);
-
-            // where the byte comes from
-            const uint32_t off = e_key;
-            uint32_t back = off; // copy: distance from this byte to its source
-            if (__ballot(off < elen) != 0 && off < elen) {
-                // overlapping copy: pattern index k mod off (exact for
-                // k, off < 64); the source lies before the element start
-                const uint32_t q = (uint32_t)(
-                    ((float)k + 0.5f) * __builtin_amdgcn_rcpf((float)off));
-                back = off + q * off;
-            }
-            const uint64_t sp = cs + lane - back; // copy source position
-            const bool cpy = act && !lit;
-            bool from_pass = cpy && back <= lane; // written by this very pass
-            const bool from_ring = cpy && !from_pass && sp >= ring_lo &&
-                                   back <= kRing - kWave;
-            const bool from_hbm = cpy && !from_pass && !from_ring;
-            // far sources must be completed stores
-            if (__ballot(from_hbm && sp >= done_lo) != 0) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                done_lo = cs;
-                COUNT(n_fence);
-            }
-            // one global load (literal bytes and far sources) and one LDS
-            // read (near sources), both unconditional at safe addresses
-            gcptr gp = (act && lit) ? src + s + e_key + k
-                                    : (from_hbm ? (gcptr)(dst + sp) : src);
-            const uint32_t vg = *gp;
-            const uint32_t vr = ring[(uint32_t)sp & (kRing - 1)];
-            uint32_t val = from_ring ? vr : vg;
-            TICK(7);
-            // sources inside this pass: take the value from the lane that
-            // produces it, once that lane has its own value
-            uint64_t ready = __ballot(!from_pass);
-            const uint32_t src_lane = lane - back;
-            while (~ready != 0) {
-                COUNT(n_res);
-                const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute(
-                    (int)((src_lane & 63) << 2), (int)val);
-                const bool can = from_pass && ((ready >> (src_lane & 63)) & 1);
-                val = can ? got : val;
-                from_pass = from_pass && !can;
-                ready = __ballot(!from_pass);
-            }
-            if (act) {
-                dst[cs + lane] = (uint8_t)val;
-                ring[(uint32_t)(cs + lane) & (kRing - 1)] = (uint8_t)val;
-            }
-            TICK(8);
-        }
-        d += W;
-        s += cur;
-        w = w_next;
-
-        // ---- long literal: wave_copy ---------------------------------------
-        if (hit_long) {
-            const uint32_t ll = xE; // its lane in this window
-            const uint64_t Lq = ((uint64_t)rdlane((uint32_t)(L >> 32), ll)
-                                 << 32) |
-                                rdlane((uint32_t)L, ll);
-            const uint32_t hd = rdlane(lhd, ll);
-            const bool qbad = __ballot(lbad && lane == ll) != 0;
-            if (qbad || dst_len - d < Lq) {
-                irregular = true;
-                break;
-            }
-            wave_copy<false>(dst + d, src + s + hd, Lq, lane);
-            s += hd + Lq;
-            d += Lq;
-            ring_lo = d; // these bytes are not in the ring
-            if (s < src_len)
-                w = ld64c(src, s + lane, src_len);
-        }
-    }
-    if (irregular) {
-        decode_sequential(a, st, lane, src, src_len, dst, dst_len, s, d);
-        return;
-    }
-#ifdef SNAPMI_PROFILE
-    TICK(9);
-    if (lane == 0 && a.prof) {
-        for (int i = 0; i < 10; i++)
-            atomicAdd(&a.prof[i], (unsigned long long)pt[i]);
-        atomicAdd(&a.prof[10], (unsigned long long)n_win);
-        atomicAdd(&a.prof[11], (unsigned long long)n_pass);
-        atomicAdd(&a.prof[12], (unsigned long long)n_elem);
-        atomicAdd(&a.prof[13], (unsigned long long)n_fence);
-        atomicAdd(&a.prof[14], (unsigned long long)n_res);
-        atomicAdd(&a.prof[15], 1ull);
-    }
-#endif
-    if (d != dst_len)
-        SNAPMI_FAIL(SNAPMI_HEADER_MISMATCH, dst_len, d, 0);
-    if (lane == 0) {
-        set_error(a.errs, st, SNAPMI_OK, 0, 0, 0);
-        a.out_lens[st] = dst_len;
-    }
-}
-
-// ---------------------------------------------------------------------
-// K2 (second generation): one wavefront per raw stream, element-major.
+// One wavefront per raw stream: the wide path.
 //
-// The first-generation kernel above produces output one BYTE per lane and
-// pass; two thirds of its instructions find, for every output byte, the
-// element it belongs to.  Here a lane that sits on an element's first
-// compressed byte copies that whole element itself:
+// Two window loops share the stream prologue, a 4 KiB ring of recent output
+// in LDS and the hand-over to the sequential decoder:
+//
+// decode_windows2 (second generation; k_decompress_streams2 and the last
+// bytes of every stream in k_decompress_streams3) - 64 compressed bytes per
+// window, an element is copied by the lane that sits on its first byte:
 //
 //   1. every lane decodes the element that would start at its byte of the
-//      64-byte window (as before), and loads 16 literal bytes speculatively;
-//   2. the real element starts are the orbit of lane 0 under "next element":
-//      five rounds of mask doubling (reach |= reach[next]; next = next[next]),
-//      three ds_bpermute each, leave the 64-bit set in lane 0 - no compaction,
-//      no per-element gather, the records stay where they were decoded;
+//      64-byte window, and loads 16 literal bytes speculatively;
+//   2. the real element starts are the orbit of lane 0 under "next element"
+//      (one ds_bpermute per round, see the loop) - no compaction, the
+//      records stay where they were decoded;
 //   3. a DPP scan of the output lengths over the start lanes places every
 //      element; the window is cut after 2048 output bytes (kWinMax), so a
 //      4 KiB ring of recent output in LDS always keeps 2 KiB of history that
@@ -688,31 +385,34 @@ __global__ __launch_bounds__(64) void k_decompress_streams(DecompressArgs a)
 //   4. ONE lane-parallel copy step: every element whose source is complete
 //      before the window (literals; copies from in front of it) is copied by
 //      its lane, 16 bytes per trip - source: the speculative literal bytes,
-//      the ring (two unaligned ds_read_b64), or HBM for what the ring no
-//      longer holds - and stored to the ring as WHOLE 16-byte pieces, last
-//      piece first: overlapping lanes of one DS store are applied in
-//      ascending lane order, so the excess bytes of a short element are
-//      overwritten by the elements that follow it;
-//   5. the few elements that read the window's own output (1.3 per window on
-//      the corpus) or repeat a short period are swept in stream order, each
-//      by the whole wave (lane k = byte k, k mod offset for overlaps);
+//      the ring, or HBM for what the ring no longer holds - and stored to
+//      the ring as WHOLE 16-byte pieces, last piece first: overlapping lanes
+//      of one DS store are applied in ascending lane order, so the excess
+//      bytes of a short element are overwritten by the elements that follow;
+//   5. the few elements that read the window's own output or repeat a short
+//      period are swept in stream order, each by the whole wave (lane k =
+//      byte k, k mod offset for overlaps);
 //   6. the ring goes to HBM 256 bytes at a time (one dword per lane), so
 //      global stores are whole aligned lines instead of 64 byte stores.
 //
-// The window loop is bound by instruction issue - VALU (a wave64 integer
+// decode_windows3 (third generation, the default) - 128 compressed bytes per
+// window and one ELEMENT per lane; described at the function.
+//
+// Both loops are bound by instruction issue - VALU (a wave64 integer
 // instruction holds its SIMD for four cycles) and the CU's one scalar unit
-// about equally - so it is written for few instructions: predicates are
-// 64-bit lane masks in SGPRs, combined with scalar ALU operations and handed
-// back to the vector side as they are (inverse ballot); positions are 32-bit
-// (no scalar 64-bit compare exists); tests that only matter near the end of
-// the input sit behind one uniform branch (`deep`); addresses are a uniform
-// base plus a 32-bit lane offset.
+// about equally, the LDS pipeline third (tests/hw/lds_cost.hip) - so they are
+// written for few instructions: predicates are 64-bit lane masks in SGPRs,
+// combined with scalar ALU operations and handed back to the vector side as
+// they are (inverse ballot); positions are 32-bit (no scalar 64-bit compare
+// exists); tests that only matter near the end of the input sit behind one
+// uniform branch; addresses are a uniform base plus a 32-bit lane offset.
 //
 // Everything irregular - a failed check, an element cut off by the end of
 // the input - stops the wide path at a window boundary: the ring is stored
 // and the sequential decoder above finishes the stream from (s, d) with the
-// reference's exact error.  tests/model_decoder.py restates this algorithm
-// lane by lane on the CPU (test infrastructure, not used here).
+// reference's exact error.  tests/model_decoder.py and tests/model_decoder3.py
+// restate the two loops lane by lane on the CPU (test infrastructure, not
+// used here).
 // ---------------------------------------------------------------------
 namespace {
 constexpr uint32_t kRing2 = 4096;
@@ -788,19 +488,49 @@ struct Ring2 {
 };
 } // namespace
 
-// 8 waves per SIMD (64 VGPRs, 5 KiB of LDS each): the kernel waits on a chain
-// of LDS / HBM round trips per window, and two more waves to switch to are
-// worth more than the 9 spilled dwords (36.0 -> 32.2 ms at cfg2).
-#ifndef SNAPMI_DEC2_WAVES
-#define SNAPMI_DEC2_WAVES 8
+namespace {
+#define SNAPMI_FAIL_V(ret, kind, fa, fb, fc)                                  \
+    do {                                                                      \
+        if (lane == 0) {                                                      \
+            set_error(a.errs, st, (kind), (fa), (fb), (fc));                  \
+            a.out_lens[st] = 0;                                               \
+        }                                                                     \
+        return ret;                                                           \
+    } while (0)
+
+// The wide path's state: everything uniform (SGPRs).
+struct Wide {
+    gcptr src;        // elements (behind the varint header)
+    gptr dst;
+    uint64_t src_len, dst_len;
+    uint64_t st;      // stream index
+    // Positions are 32-bit: there is no scalar 64-bit compare, each one in
+    // a window loop would be two VALU instructions.  dst_len < 2^32 by the
+    // format; a compressed stream of 4 GiB or more (legal, if every element
+    // is tiny) is left to the sequential decoder as a whole, and so is an
+    // output within 4 KiB of 2^32 (window arithmetic like d + W + 16 must
+    // not wrap).
+    uint32_t slen, dlen;
+    uint32_t s, d;    // positions in src / dst
+    uint32_t ring_lo; // the ring holds dst[max(ring_lo, d - 4096), d)
+    Ring2 R;
+#ifdef SNAPMI_PROFILE
+    uint64_t n_win = 0, n_elem = 0, n_dep = 0, n_fence = 0, n_far = 0,
+             n_trip = 0, n_run = 0, n_win3 = 0;
 #endif
-__attribute__((amdgpu_waves_per_eu(SNAPMI_DEC2_WAVES, SNAPMI_DEC2_WAVES)))
-__global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
+    __device__ __forceinline__ bool too_big() const
+    {
+        return src_len > 0xFFE00000ull || dst_len > 0xFFFFF000ull;
+    }
+};
+
+// Stored chunk, header, capacity (reference Decoder::decompress,
+// src/decompress.rs:75-95).  False: the stream is finished (copied, or its
+// error is written).
+__device__ __forceinline__ bool open_stream(const DecompressArgs &a,
+                                            const uint32_t lane, Wide &x,
+                                            l_u8 *ring_mem)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t ring_mem[kRing2 + 16];
-    const uint32_t lane = threadIdx.x;
-    if (a.gate && uni64(*a.gate) != a.gate_value)
-        return;
     const uint64_t st = a.order[blockIdx.x];
     gcptr in = (gcptr)a.in_ptrs[st];
     const uint64_t in_len = a.in_lens[st];
@@ -811,65 +541,105 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
         // the data (wave_copy)
         const uint64_t cap0 = a.out_caps[st];
         if (in_len > cap0)
-            SNAPMI_FAIL(SNAPMI_BUFFER_TOO_SMALL, cap0, in_len, 0);
+            SNAPMI_FAIL_V(false, SNAPMI_BUFFER_TOO_SMALL, cap0, in_len, 0);
         wave_copy<false>((gptr)a.out_ptrs[st], in, in_len, lane);
         if (lane == 0) {
             set_error(a.errs, st, SNAPMI_OK, 0, 0, 0);
             a.out_lens[st] = in_len;
         }
-        return;
+        return false;
     }
-    // reference Decoder::decompress, src/decompress.rs:75-95
     uint32_t hdr = 0;
     uint64_t dst_len = 0;
     if (piece) { // elements [in, in + in_len) produce exactly out_caps bytes
         dst_len = a.out_caps[st];
     } else {
         if (in_len == 0)
-            SNAPMI_FAIL(SNAPMI_EMPTY, 0, 0, 0);
+            SNAPMI_FAIL_V(false, SNAPMI_EMPTY, 0, 0, 0);
         snapmi_error *e = lane == 0 ? a.errs : nullptr;
         if (read_header(in, in_len, &hdr, &dst_len, e, st) != SNAPMI_OK) {
             if (lane == 0)
                 a.out_lens[st] = 0;
-            return;
+            return false;
         }
     }
+    // the header came through vector loads: pin it (and everything derived
+    // from it) to SGPRs so the decoder state is scalar
     hdr = uni(hdr);
     dst_len = uni64(dst_len);
     const uint64_t cap = a.out_caps[st];
     if (dst_len > cap)
-        SNAPMI_FAIL(SNAPMI_BUFFER_TOO_SMALL, cap, dst_len, 0);
+        SNAPMI_FAIL_V(false, SNAPMI_BUFFER_TOO_SMALL, cap, dst_len, 0);
+    x.st = st;
+    x.src = in + hdr;
+    x.src_len = in_len - hdr;
+    x.dst = (gptr)a.out_ptrs[st];
+    x.dst_len = dst_len;
+    x.slen = (uint32_t)x.src_len;
+    x.dlen = (uint32_t)dst_len;
+    x.s = x.d = x.ring_lo = 0;
+    x.R.rg = ring_mem;
+    x.R.dst = x.dst;
+    x.R.lane = lane;
+    x.R.gflush = 0;
+    x.R.fenced = 0;
+    return true;
+}
 
-    gcptr src = in + hdr;
-    const uint64_t src_len = in_len - hdr;
-    gptr dst = (gptr)a.out_ptrs[st];
+// The end of a stream: what the wide path has in the ring is stored; an
+// irregular stream is finished (and its error named) by the sequential
+// decoder; HeaderMismatch, reference src/decompress.rs:149-157.
+__device__ __forceinline__ void close_stream(const DecompressArgs &a,
+                                             const uint32_t lane, Wide &x,
+                                             const bool irregular)
+{
+    const uint64_t st = x.st;
+    x.R.flush_partial(x.d);
+    if (irregular) {
+        decode_sequential(a, st, lane, x.src, x.src_len, x.dst, x.dst_len,
+                          x.s, x.d);
+        return;
+    }
+#ifdef SNAPMI_PROFILE
+    if (lane == 0 && a.prof) {
+        atomicAdd(&a.prof[7], (unsigned long long)x.n_win3);
+        atomicAdd(&a.prof[8], (unsigned long long)x.n_run);
+        atomicAdd(&a.prof[9], (unsigned long long)x.n_far);
+        atomicAdd(&a.prof[10], (unsigned long long)x.n_win);
+        atomicAdd(&a.prof[11], (unsigned long long)x.n_trip);
+        atomicAdd(&a.prof[12], (unsigned long long)x.n_elem);
+        atomicAdd(&a.prof[13], (unsigned long long)x.n_fence);
+        atomicAdd(&a.prof[14], (unsigned long long)x.n_dep);
+        atomicAdd(&a.prof[15], 1ull);
+    }
+#endif
+    if (x.d != x.dst_len)
+        SNAPMI_FAIL(SNAPMI_HEADER_MISMATCH, x.dst_len, x.d, 0);
+    if (lane == 0) {
+        set_error(a.errs, st, SNAPMI_OK, 0, 0, 0);
+        a.out_lens[st] = x.dst_len;
+    }
+}
 
-    // Positions are 32-bit: there is no scalar 64-bit compare, each one in
-    // the window loop would be two VALU instructions.  dst_len < 2^32 by the
-    // format; a compressed stream of 4 GiB or more (legal, if every element
-    // is tiny) is left to the sequential decoder as a whole.
-    uint32_t s = 0;       // position in src (uniform)
-    uint32_t d = 0;       // position in dst (uniform; dst_len < 2^32)
-    const uint32_t slen = (uint32_t)src_len, dlen = (uint32_t)dst_len;
-    uint32_t ring_lo = 0; // the ring holds dst[max(ring_lo, d - 4096), d)
-    Ring2 R;
-    R.rg = (l_u8 *)ring_mem;
-    R.dst = dst;
-    R.lane = lane;
-    R.gflush = 0;
-    R.fenced = 0;
+// The second-generation window loop from (x.s, x.d) to the end of the
+// input.  True: something irregular, the sequential decoder takes over.
+__device__ __forceinline__ bool decode_windows2(Wide &x, const uint32_t lane)
+{
+    gcptr src = x.src;
+    gptr dst = x.dst;
+    const uint64_t src_len = x.src_len;
+    const uint32_t slen = x.slen, dlen = x.dlen;
+    uint32_t s = x.s, d = x.d, ring_lo = x.ring_lo;
+    Ring2 &R = x.R;
     l_u8 *const rg = R.rg;
-
     // streams too short for the 8-byte window loads go to the sequential
     // decoder at once; so does the first failed check
-    bool irregular = src_len < 8 || src_len > 0xFFE00000ull;
-    uint64_t w = irregular ? 0 : ld64c(src, lane, src_len); // src[s+lane..]
-#ifdef SNAPMI_PROFILE
-    uint64_t n_win = 0, n_elem = 0, n_dep = 0, n_fence = 0, n_far = 0,
-             n_trip = 0;
-#endif
+    bool irregular = src_len < 8;
+    uint64_t w = irregular || s >= slen
+                     ? 0
+                     : ld64c(src, (uint64_t)s + lane, src_len); // src[s+lane..]
     while (!irregular && s < slen) {
-        COUNT(n_win);
+        COUNT(x.n_win);
         // bytes of input left, as far as this window can see (<= 2^20)
         const uint32_t rem = slen - s < (1u << 20) ? slen - s : 1u << 20;
         // ---- 1. the element that would start at src[s + lane] ------------
@@ -999,7 +769,7 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
             break;
         }
 #ifdef SNAPMI_PROFILE
-        n_elem += __builtin_popcountll(K);
+        x.n_elem += __builtin_popcountll(K);
 #endif
         // next window's bytes: issued now, consumed after the expand
         // (plain unaligned loads while the next window lies inside the
@@ -1049,11 +819,11 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
         {
             if (M_far) {
 #ifdef SNAPMI_PROFILE
-                n_far += __builtin_popcountll(M_far);
+                x.n_far += __builtin_popcountll(M_far);
 #endif
                 if ((M_far & __ballot(qe > R.fenced)) != 0) {
                     R.fence_for(0xFFFFFFFFu);
-                    COUNT(n_fence);
+                    COUNT(x.n_fence);
                 }
             }
             // Every lane stores WHOLE 16-byte pieces with one ds_write_b128:
@@ -1079,7 +849,7 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
 #endif
                 const uint64_t M_act = c == 0 ? M_lw : M_lw & __ballot(c < olen);
                 if (M_act != 0) {
-                    COUNT(n_trip);
+                    COUNT(x.n_trip);
                     // source: 16 bytes from the literal, the ring, or HBM
                     // (a lane that loads nothing below stores nothing either:
                     // whatever v starts with - the literal bytes of trip 0 -
@@ -1135,7 +905,7 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
         dep = 0;
 #endif
         while (dep) {
-            COUNT(n_dep);
+            COUNT(x.n_dep);
             const uint32_t i = (uint32_t)__builtin_ctzll(dep);
             dep &= dep - 1;
             const uint32_t ni = rdlane(olen, i), di = rdlane(dstp, i);
@@ -1162,7 +932,7 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
                         R.flush_partial(di);
                     if (qi + nsrc > R.fenced) {
                         R.fence_for(0xFFFFFFFFu);
-                        COUNT(n_fence);
+                        COUNT(x.n_fence);
                     }
                 }
                 if (lane < ni)
@@ -1191,29 +961,462 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
         R.flush_chunks(d);
 #endif
     }
-    if (irregular) {
-        R.flush_partial(d);
-        decode_sequential(a, st, lane, src, src_len, dst, dst_len, s, d);
-        return;
-    }
-    R.flush_partial(d);
+    x.s = s;
+    x.d = d;
+    x.ring_lo = ring_lo;
+    return irregular;
+}
+
+// ---------------------------------------------------------------------
+// The third-generation window loop: kG3 x 64 compressed bytes per window,
+// one ELEMENT per lane.
+//
+// The second generation spends its instructions on lanes that hold no
+// element: every lane decodes "the element that would start at my byte" in
+// full (offset, length, checks, source classes), and one lane in four or five
+// is a real start.  Instruction issue - vector and scalar - is what bounds
+// the loop, so here the expensive part runs on real elements only:
+//
+//   1. LENGTHS.  A window is kG3 groups of 64 input bytes; lane l looks at
+//      the TAG bytes at s + 64 g + l, just far enough to know how many
+//      compressed bytes the element there would take (tag only: a literal
+//      with length bytes - 61 bytes or more - always ends a window).
+//   2. STARTS.  Per group one ds_bpermute per round, four rounds (a lane's
+//      32-bit set of its 32-byte sub-window, frontier as the highest bit:
+//      R |= R[frontier]); the 2 kG3 sub-windows are strung together by the
+//      scalar unit (two v_readlane each).
+//   3. COMPACTION.  The t-th start of the window goes to lane t: rank by
+//      population count, position through a 64 kG3-byte table in LDS.
+//   4. DECODE, PLACEMENT, CHECKS as in the second generation, but every lane
+//      below the element count holds a real element (40 of 64 lanes on the
+//      corpus instead of 14).
+//   5. COPY in in-order RUNS of lanes.  A run ends in front of the first
+//      copy whose source is not complete when the run starts, i.e. reads
+//      the run's own output; the next run starts there (2.9 runs per window
+//      on the corpus, tests/model_decoder3.py).  A run is the second
+//      generation's copy step: 16 bytes per lane and trip, whole-piece
+//      stores resolved by lane order - the excess bytes of a run's last
+//      elements land on later runs' output, which is written afterwards.  A
+//      copy that overlaps itself (offset < length; 0.2 per window) is moved
+//      by the whole wave between two runs.
+//
+// A window needs kTail3 bytes of input in front of it, so that none of its
+// loads can leave the input; the last bytes of a stream (and streams shorter
+// than that) are decode_windows2's.  True: something irregular.
+// ---------------------------------------------------------------------
+constexpr uint32_t kG3 = 2;
+// the last position (64 kG3 - 1), a tag, 60 literal bytes read as whole
+// 16-byte pieces
+constexpr uint32_t kTail3 = 64 * kG3 + 1 + 64 + 16;
+
+__device__ __forceinline__ bool decode_windows3(Wide &x, const uint32_t lane,
+                                                l_u8 *const postab)
+{
+    gcptr src = x.src;
+    gptr dst = x.dst;
+    const uint32_t slen = x.slen, dlen = x.dlen;
+    uint32_t s = x.s, d = x.d, ring_lo = x.ring_lo;
+    Ring2 &R = x.R;
+    l_u8 *const rg = R.rg;
+    bool irregular = false;
+    uint32_t tg[kG3]; // tag bytes of the window at s, one per group
+    bool have = false;
+    const int c4 = (int)((lane | 31) << 2);
+    const uint32_t self = 1u << (lane & 31);
+
+    while (slen - s >= kTail3) {
+        COUNT(x.n_win3);
+        const gcptr win_src = src + s;
+        if (!have) {
+#pragma unroll
+            for (uint32_t g = 0; g < kG3; g++)
+                tg[g] = win_src[64 * g + lane];
+        }
+        // ---- 1. lengths, 2. starts -------------------------------------
+        uint32_t nx[kG3], Rr[kG3];
+#pragma unroll
+        for (uint32_t g = 0; g < kG3; g++) {
+            const uint32_t t = tg[g], type = t & 3;
+            const uint32_t pos = 64 * g + lane;
+            // copies take 2, 3, 5 bytes; a literal its tag and n6 + 1 bytes;
+            // a literal with length bytes (n6 >= 60) ends every chain: its
+            // "next" lies behind the window
+            uint32_t enc =
+                type ? (0x05030200u >> (8 * type)) & 0xFF : (t >> 2) + 2;
+            enc = (t & 0xF3) == 0xF0 ? 255 : enc;
+            nx[g] = pos + enc;
+            // (the chain stays in this lane's 32-byte sub-window)
+            Rr[g] = self | ((nx[g] ^ pos) < 32 ? 1u << (nx[g] & 31) : 0);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+#pragma unroll
+            for (uint32_t g = 0; g < kG3; g++) {
+                const int sel = c4 - 4 * (int)__builtin_clz(Rr[g]);
+                Rr[g] |= (uint32_t)__builtin_amdgcn_ds_bpermute(sel,
+                                                                (int)Rr[g]);
+            }
+        }
+        // the sub-windows, strung together: sub-window k is entered at its
+        // byte e; its last start's element leads into a later one (or out
+        // of the window)
+        uint32_t S32[2 * kG3];
+#pragma unroll
+        for (uint32_t kk = 0; kk < 2 * kG3; kk++)
+            S32[kk] = 0;
+        {
+            uint32_t k = 0, e = 0;
+#pragma unroll
+            for (uint32_t kk = 0; kk < 2 * kG3; kk++) {
+                if (k == kk) {
+                    const uint32_t g = kk >> 1, half = 32 * (kk & 1);
+                    const uint32_t Sk = rdlane(Rr[g], half + e);
+                    S32[kk] = Sk;
+                    const uint32_t lt = 31 - (uint32_t)__builtin_clz(Sk);
+                    const uint32_t nxa = rdlane(nx[g], half + lt);
+                    k = nxa >> 5;
+                    e = nxa & 31;
+                }
+            }
+        }
+        uint64_t S[kG3];
+#pragma unroll
+        for (uint32_t g = 0; g < kG3; g++)
+            S[g] = ((uint64_t)S32[2 * g + 1] << 32) | S32[2 * g];
+        // ---- 3. compaction ---------------------------------------------
+        uint32_t base = 0;
+#pragma unroll
+        for (uint32_t g = 0; g < kG3; g++) {
+            // (a lane that is no start writes behind the table: a select is
+            // cheaper than an exec region - the scalar unit is what is short)
+            const uint32_t r = __builtin_amdgcn_inverse_ballot_w64(S[g])
+                                   ? base + popc_below(S[g])
+                                   : 64 * kG3 + lane;
+            postab[r] = (uint8_t)(64 * g + lane);
+            base += (uint32_t)__builtin_popcountll(S[g]);
+        }
+        const uint32_t n_el = base < kWave ? base : kWave;
+        const uint64_t M_act = n_el == kWave ? ~0ull : (1ull << n_el) - 1;
+        // (lanes behind the last element read what an earlier window left:
+        // any position in the window will do, they are masked by M_act)
+        const uint32_t pos = postab[lane] & (64 * kG3 - 1);
+        // ---- 4. the element, in full -----------------------------------
+        uint64_t w;
+        __builtin_memcpy(&w, win_src + pos, 8);
+        B16x lit16;
+        __builtin_memcpy(&lit16, win_src + (pos + 1), 16);
+        const uint32_t tag = (uint32_t)w & 0xFF;
+        const uint32_t b14 = (uint32_t)(w >> 8); // the 4 bytes after the tag
+        const uint32_t type = tag & 3, n6 = tag >> 2;
+        const uint64_t M_lit = __ballot(type == 0);
+        const uint64_t M_lng = M_act & M_lit & __ballot(n6 >= 60);
+        // a copy's offset: 1, 2 or 4 bytes behind the tag (TagEntry::offset /
+        // read_copy, reference src/decompress.rs:233-250,433-474)
+        const uint32_t cnb = type + (type == 3);
+        const uint32_t sh = 32 - 8 * cnb;
+        const uint32_t ext = (b14 << (sh & 31)) >> (sh & 31);
+        const uint32_t off = ext | (type == 1 ? (tag & 0xE0u) << 3 : 0);
+        // output bytes: a literal's and a long copy's n6 + 1, copy-1's 4..11
+        const uint32_t olen = type == 1 ? 4 + (n6 & 7) : 1 + n6;
+        const uint32_t enc = type == 0 ? n6 + 2 : 1 + cnb;
+        const uint64_t M_el = M_act & ~M_lng;
+        const uint32_t o =
+            __builtin_amdgcn_inverse_ballot_w64(M_el) ? olen : 0;
+        const uint32_t incl = wave_inclusive_add(o);
+        // the window ends in front of a literal with length bytes, and after
+        // kWinMax output bytes
+        const uint64_t below =
+            M_lng ? ((1ull << __builtin_ctzll(M_lng)) - 1) : ~0ull;
+        const uint64_t K = M_el & __ballot(incl <= kWinMax) & below;
+        if (K == 0) {
+            // lane 0 is a literal with length bytes (reference read_literal,
+            // src/decompress.rs:161-228): moved by the whole wave
+            const uint32_t lnb = rdlane(n6, 0) - 59; // 1..4 length bytes
+            const uint32_t b0 = rdlane(b14, 0);
+            const uint64_t Lq =
+                (uint64_t)(lnb == 4 ? b0 : b0 & ((1u << (8 * lnb)) - 1)) + 1;
+            const uint32_t h0 = 1 + lnb;
+            if (slen - (s + h0) < Lq || dlen - d < Lq) {
+                irregular = true; // the sequential decoder names the error
+                break;
+            }
+            R.flush_partial(d);
+            wave_copy<false>(dst + d, src + s + h0, Lq, lane);
+            s += h0 + (uint32_t)Lq;
+            d += (uint32_t)Lq;
+            R.gflush = d;
+            ring_lo = d; // these bytes are not in the ring
+            have = false;
+            continue;
+        }
+        // (K is a prefix of the lanes)
+        const uint32_t nK = (uint32_t)__builtin_popcountll(K);
+        const uint32_t W = rdlane(incl, nK - 1);       // output of the window
+        const uint32_t cur = rdlane(pos, nK - 1) + rdlane(enc, nK - 1);
+        const uint32_t dstp = d + (incl - o);          // element's position
+        // reference checks :209-217 (dst side), :245-250, :327-332
+        const uint64_t M_cpy = K & ~M_lit;
+        if (W > dlen - d ||
+            (M_cpy & (__ballot(off == 0) | __ballot(off > dstp))) != 0) {
+            irregular = true;
+            break;
+        }
 #ifdef SNAPMI_PROFILE
-    if (lane == 0 && a.prof) {
-        atomicAdd(&a.prof[10], (unsigned long long)n_win);
-        atomicAdd(&a.prof[11], (unsigned long long)n_trip);
-        atomicAdd(&a.prof[12], (unsigned long long)n_elem);
-        atomicAdd(&a.prof[13], (unsigned long long)n_fence);
-        atomicAdd(&a.prof[14], (unsigned long long)n_dep);
-        atomicAdd(&a.prof[9], (unsigned long long)n_far);
-        atomicAdd(&a.prof[15], 1ull);
-    }
+        x.n_elem += nK;
 #endif
-    if (d != dst_len)
-        SNAPMI_FAIL(SNAPMI_HEADER_MISMATCH, dst_len, d, 0);
-    if (lane == 0) {
-        set_error(a.errs, st, SNAPMI_OK, 0, 0, 0);
-        a.out_lens[st] = dst_len;
+        // next window's tags: issued now, consumed after the copy step
+        uint32_t tgn[kG3];
+        const bool have_next = slen - (s + cur) >= kTail3;
+        if (have_next) {
+#pragma unroll
+            for (uint32_t g = 0; g < kG3; g++)
+                tgn[g] = win_src[cur + 64 * g + lane];
+        } else {
+#pragma unroll
+            for (uint32_t g = 0; g < kG3; g++)
+                tgn[g] = 0;
+        }
+        // ---- 5. the copy step, in in-order runs ------------------------
+        const uint32_t q = dstp - off; // copy source (if cpy)
+        const uint32_t qe = q + olen;  // (its end, for a copy that does not
+                                       // overlap itself)
+        // (whole 16-byte pieces are stored: up to 15 bytes behind the window's
+        // output may be clobbered too)
+        const uint32_t dW = d + W + 16;
+        uint32_t safe_lo = dW > kRing2 ? dW - kRing2 : 0;
+        safe_lo = safe_lo > ring_lo ? safe_lo : ring_lo;
+        const uint64_t M_ring = __ballot(q >= safe_lo);
+        // a source in HBM must have been stored, and its 16-byte loads must
+        // stay inside the buffer
+        const uint64_t M_farok =
+            dlen >= 64 ? __ballot(qe <= R.gflush) & __ballot(q <= dlen - 64)
+                       : 0;
+        // moved by the whole wave: copies that overlap themselves, and (only
+        // right after a long literal) sources neither in the ring nor stored
+        const uint64_t M_swp =
+            M_cpy & (__ballot(off < olen) | ~(M_ring | M_farok));
+        // an element's own bytes wrap around the ring's end only in a
+        // window whose output does (uniform)
+        const uint32_t r0 = d & (kRing2 - 1);
+        const bool wraps = r0 + W > kRing2;
+        // the window's stores (whole pieces: up to d + W + 16) touch
+        // ring[0,16) or spill over the ring's end into the mirror
+        const bool mir = r0 < 16 || r0 + W + 16 > kRing2;
+        // sources in HBM must be completed stores: one test per window
+        {
+            const uint64_t M_far_all = M_cpy & ~M_ring & ~M_swp;
+            if (M_far_all) {
+#ifdef SNAPMI_PROFILE
+                x.n_far += __builtin_popcountll(M_far_all);
+#endif
+                if ((M_far_all & __ballot(qe > R.fenced)) != 0) {
+                    R.fence_for(0xFFFFFFFFu);
+                    COUNT(x.n_fence);
+                }
+            }
+        }
+        // elements of more than one 16-byte piece
+        const uint64_t M_o16 = K & __ballot(olen > 16);
+        const uint64_t M_crg = M_cpy & M_ring, M_cfar = M_cpy & ~M_ring;
+        // The first piece of every element whose source is not in the ring
+        // is fetched NOW, for the whole window: literal bytes are here
+        // already (lit16), far sources are old output and do not depend on
+        // the order of the runs below.  What bounds this kernel is the
+        // latency of these loads (a far source is an L2 miss: 64 bytes from
+        // HBM or the MALL, a microsecond or two) - one round trip per window,
+        // not one per run.
+        B16x v0 = lit16;
+        {
+            const uint64_t M_pre = M_cfar & ~M_swp;
+            if (M_pre != 0 && __builtin_amdgcn_inverse_ballot_w64(M_pre))
+                __builtin_memcpy(&v0, dst + q, 16);
+        }
+        uint32_t a0 = 0;
+        while (a0 < nK) {
+            const uint32_t F = rdlane(dstp, a0);
+            const uint64_t ge = ~0ull << a0;
+            // the run ends in front of the first element that must be swept
+            // or whose source reaches into the run
+            const uint64_t blocked =
+                ge & (M_swp | (M_cpy & __ballot(qe > F)));
+            const uint32_t b =
+                blocked ? (uint32_t)__builtin_ctzll(blocked) : nK;
+            if (b == a0) {
+                // element a0 by the whole wave: lane k = byte k
+                COUNT(x.n_dep);
+                const uint32_t ni = rdlane(olen, a0);
+                const uint32_t qi = rdlane(q, a0), oi = rdlane(off, a0);
+                const uint32_t nsrc = ni < oi ? ni : oi;
+                uint32_t kk = lane;
+                if (oi < ni) { // overlapping: byte k repeats byte k mod oi
+                    const uint32_t quo = (uint32_t)(
+                        ((float)lane + 0.5f) *
+                        __builtin_amdgcn_rcpf((float)oi));
+                    kk = lane - quo * oi;
+                }
+                const bool in_ring = qi >= safe_lo;
+                if (!in_ring) {
+                    // bytes the ring has lost that are not stored yet (only
+                    // right after a long literal): store them first
+                    if (qi + nsrc > R.gflush)
+                        R.flush_partial(F);
+                    if (qi + nsrc > R.fenced) {
+                        R.fence_for(0xFFFFFFFFu);
+                        COUNT(x.n_fence);
+                    }
+                }
+                if (lane < ni) {
+                    const uint32_t val =
+                        in_ring ? (uint32_t)rg[(qi + kk) & (kRing2 - 1)]
+                                : (uint32_t)dst[qi + kk];
+                    rg[(F + lane) & (kRing2 - 1)] = (uint8_t)val;
+                }
+                a0++;
+                continue;
+            }
+            COUNT(x.n_run);
+            const uint64_t M_lw = ge & ~(b == kWave ? 0ull : ~0ull << b);
+            // Sources inside this window's output are read as 16 bytes too
+            // and may run into the mirror: bring it up to date (only a
+            // window that touches the ring's ends needs it at all)
+            if (mir && a0 > 0)
+                R.mirror();
+            if (!wraps && (M_lw & M_o16) == 0) {
+                // the usual run: one piece per element, no wrap
+                COUNT(x.n_trip);
+                B16x v = v0;
+                if (__builtin_amdgcn_inverse_ballot_w64(M_lw & M_crg))
+                    __builtin_memcpy(&v, rg + (q & (kRing2 - 1)), 16);
+                if (__builtin_amdgcn_inverse_ballot_w64(M_lw))
+                    __builtin_memcpy(rg + (dstp & (kRing2 - 1)), &v, 16);
+                a0 = b;
+                continue;
+            }
+            const uint64_t M_far = M_lw & M_cfar; // source in HBM
+            const uint64_t M_rng = M_lw & M_crg;  // ... in the ring
+            // whole 16-byte pieces, last piece first (see decode_windows2)
+            const uint64_t M_g16 = M_lw & M_o16;
+            const uint32_t top =
+                M_g16 == 0 ? 0
+                           : ((M_g16 & __ballot(olen > 48))
+                                  ? 48
+                                  : ((M_g16 & __ballot(olen > 32)) ? 32 : 16));
+            for (uint32_t c = top;; c -= 16) {
+                const uint64_t M_actc =
+                    c == 0 ? M_lw : M_lw & __ballot(c < olen);
+                if (M_actc != 0) {
+                    COUNT(x.n_trip);
+                    B16x v = v0;
+                    if (c != 0) {
+                        if (__builtin_amdgcn_inverse_ballot_w64(M_actc & M_lit))
+                            __builtin_memcpy(&v, win_src + (pos + 1 + c), 16);
+                        if ((M_actc & M_far) != 0 &&
+                            __builtin_amdgcn_inverse_ballot_w64(M_actc & M_far))
+                            __builtin_memcpy(&v, dst + (q + c), 16);
+                    }
+                    if (__builtin_amdgcn_inverse_ballot_w64(M_actc & M_rng))
+                        __builtin_memcpy(&v, rg + ((q + c) & (kRing2 - 1)),
+                                         16);
+                    const uint32_t wa = (dstp + c) & (kRing2 - 1);
+                    // (rare) the element's own bytes wrap around the ring's
+                    // end: those lanes store bytewise, after the others
+                    uint64_t M_strad = 0;
+                    uint32_t m = 16;
+                    if (wraps) {
+                        m = olen - c < 16 ? olen - c : 16;
+                        M_strad = M_actc & __ballot(wa + m > kRing2);
+                    }
+                    if (__builtin_amdgcn_inverse_ballot_w64(M_actc & ~M_strad))
+                        __builtin_memcpy(rg + wa, &v, 16); // may reach the mirror
+                    if (M_strad != 0 &&
+                        __builtin_amdgcn_inverse_ballot_w64(M_strad)) {
+                        for (uint32_t j = 0; j < m; j++) {
+                            const uint64_t part = j < 8 ? v.lo : v.hi;
+                            rg[(wa + j) & (kRing2 - 1)] =
+                                (uint8_t)(part >> (8 * (j & 7)));
+                        }
+                    }
+                }
+                if (c == 0)
+                    break;
+            }
+            a0 = b;
+        }
+        // the mirror for the next window (see decode_windows2)
+        if (mir)
+            R.mirror();
+        // ---- 6. advance; whole 256-byte pieces go to HBM -----------------
+        d += W;
+        s += cur;
+#pragma unroll
+        for (uint32_t g = 0; g < kG3; g++)
+            tg[g] = tgn[g];
+        have = have_next;
+        R.flush_chunks(d);
     }
+    x.s = s;
+    x.d = d;
+    x.ring_lo = ring_lo;
+    return irregular;
+}
+} // namespace
+
+// 8 waves per SIMD (64 VGPRs, 5 KiB of LDS each): a window is a chain of
+// LDS / HBM round trips, and two more waves to switch to are worth more than
+// a few spilled dwords (36.0 -> 32.2 ms at cfg2 for the second generation).
+#ifndef SNAPMI_DEC2_WAVES
+#define SNAPMI_DEC2_WAVES 8
+#endif
+__attribute__((amdgpu_waves_per_eu(SNAPMI_DEC2_WAVES, SNAPMI_DEC2_WAVES)))
+__global__ __launch_bounds__(64) void k_decompress_streams3(DecompressArgs a)
+{
+    // the ring, its 16-byte mirror, the compaction table (+ 64 bytes that
+    // take the writes of lanes without an element)
+    __shared__ __attribute__((aligned(16)))
+    uint8_t ring_mem[kRing2 + 16 + 64 * kG3 + 64];
+    const uint32_t lane = threadIdx.x;
+    if (a.gate && uni64(*a.gate) != a.gate_value)
+        return;
+    Wide x;
+    if (!open_stream(a, lane, x, (l_u8 *)ring_mem))
+        return;
+    bool irregular = x.too_big();
+    if (!irregular)
+        irregular = decode_windows3(x, lane, (l_u8 *)ring_mem + kRing2 + 16);
+    if (!irregular)
+        irregular = decode_windows2(x, lane);
+    close_stream(a, lane, x, irregular);
+}
+
+// The second generation alone (option decode_kernel = 2): kept as the
+// cross-check every decoder parity test also runs through.
+__attribute__((amdgpu_waves_per_eu(SNAPMI_DEC2_WAVES, SNAPMI_DEC2_WAVES)))
+__global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t ring_mem[kRing2 + 16];
+    const uint32_t lane = threadIdx.x;
+    if (a.gate && uni64(*a.gate) != a.gate_value)
+        return;
+    Wide x;
+    if (!open_stream(a, lane, x, (l_u8 *)ring_mem))
+        return;
+    const bool irregular = x.too_big() || decode_windows2(x, lane);
+    close_stream(a, lane, x, irregular);
+}
+
+// The reference's loop alone, one element at a time (option decode_kernel =
+// 0): what a context falls back to when the self-check of the LDS store
+// order fails, and a third opinion for the tests.
+__global__ __launch_bounds__(64) void k_decompress_sequential(DecompressArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t ring_mem[16];
+    const uint32_t lane = threadIdx.x;
+    if (a.gate && uni64(*a.gate) != a.gate_value)
+        return;
+    Wide x;
+    if (!open_stream(a, lane, x, (l_u8 *)ring_mem))
+        return;
+    decode_sequential(a, x.st, lane, x.src, x.src_len, x.dst, x.dst_len, 0, 0);
 }
 
 // ---------------------------------------------------------------------

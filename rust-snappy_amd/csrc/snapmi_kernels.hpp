@@ -142,8 +142,9 @@ __global__ void k_stream_pieces(StreamArgs a);
 __global__ void k_stream_finish(StreamArgs a);
 
 __global__ void k_plan_decompress(DecompressArgs a);
-__global__ void k_decompress_streams(DecompressArgs a);
+__global__ void k_decompress_streams3(DecompressArgs a);
 __global__ void k_decompress_streams2(DecompressArgs a);
+__global__ void k_decompress_sequential(DecompressArgs a);
 __global__ void k_decompress_len(DecompressArgs a);
 
 } // namespace snapmi

@@ -19,17 +19,18 @@ def built():
     return True
 
 
-@pytest.fixture(scope="session", params=["dec2", "dec1"])
+@pytest.fixture(scope="session", params=["dec3", "dec2"])
 def ctx(request, built):
-    """A context per decoder kernel: the element-major k_decompress_streams2
-    (default) and the first-generation byte-per-lane kernel kept as a
-    cross-check, so every decoder parity test runs through both."""
+    """A context per decoder kernel: k_decompress_streams3 (element per lane,
+    128-byte windows; the default) and the second-generation
+    k_decompress_streams2 kept as a cross-check, so every decoder parity test
+    runs through both."""
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import rust_snappy_amd as R
     c = R.raw.Context(0)
-    c.set_option("decode_kernel", {"dec2": 2, "dec1": 1}[request.param])
+    c.set_option("decode_kernel", {"dec3": 3, "dec2": 2}[request.param])
     yield c
     c.close()
 

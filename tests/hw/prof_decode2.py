@@ -1,4 +1,4 @@
-"""Per-file decode time of both decoder kernels and the element-major kernel's
+"""Per-file decode time of the decoder kernels (second and third generation) and their
 counters (profile build: make -C rust-snappy_amd/csrc profile)."""
 import ctypes as C, os, sys
 from pathlib import Path
@@ -24,19 +24,18 @@ for k, idx in sets.items():
         comp = batch.StreamBatch.from_bytes([O.compress(rnd[idx])] * (rounds * 6))
         ub = len(rnd[idx]) * rounds * 6
     row = f"{k:18s} {ub/2**30:5.2f} GiB:"
-    for kern in (1, 2):
+    for kern in (2, 3):
         ctx = R.raw.Context(0)
         ctx.set_option("decode_kernel", kern)
         for _ in range(2):
             dst, lens, errs = batch.decompress(ctx, comp)
         t = ctx.last_timing()["codec_ms"]
         row += f"  k{kern} {t:7.2f} ms {ub/2**30/(t/1e3):7.1f} GiB/s"
-        if kern == 2:
-            out = (C.c_uint64 * 16)()
-            L.snapmi_debug_profile(ctx._h, out)
-            v = list(out)
-            nw = max(v[10], 1)
-            row += (f" | windows {v[10]} trips/win {v[11]/nw:.2f} elem/win {v[12]/nw:.1f} "
-                    f"dep/win {v[14]/nw:.2f} far/win {v[9]/nw:.2f} fences/win {v[13]/nw:.3f} out/win {ub/nw:.0f}")
+        out = (C.c_uint64 * 16)()
+        L.snapmi_debug_profile(ctx._h, out)
+        v = list(out)
+        nw = max(v[10] + v[7], 1)
+        row += (f" | windows {v[7]}+{v[10]} runs/win {v[8]/nw:.2f} trips/win {v[11]/nw:.2f} elem/win {v[12]/nw:.1f} "
+                f"swept/win {v[14]/nw:.2f} far/win {v[9]/nw:.2f} fences/win {v[13]/nw:.3f} out/win {ub/nw:.0f}\n" + " " * 28)
         ctx.close()
     print(row, flush=True)

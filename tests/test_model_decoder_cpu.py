@@ -8,8 +8,19 @@ import random
 import pytest
 
 import foreign
-import model_decoder as M
+import model_decoder as M2
+import model_decoder3 as M3
 import oracle_lib as O
+
+M = M2
+
+
+@pytest.fixture(params=[2, 3], autouse=True)
+def generation(request):
+    """every test runs over both kernels' models"""
+    global M
+    M = M2 if request.param == 2 else M3
+    return request.param
 
 
 def check(comp, data=None):
@@ -26,6 +37,12 @@ def check(comp, data=None):
         _, s, d, prefix = res
         if want is not None:
             assert prefix == want[:d], (s, d)
+            if M is M3:
+                # a valid stream leaves the third generation's wide path only
+                # for its last kTail bytes of input
+                hdr = M3.read_varint(comp)[1]
+                assert len(comp) - hdr - s < M3.TAIL, (s, len(comp))
+                return "ok", st
     if data is not None:
         assert want == data
     return res[0], st
@@ -37,11 +54,25 @@ def test_model_on_corpus():
         kind, st = check(O.compress(data), data)
         assert kind == "ok"      # a valid stream never leaves the wide path
         total.windows += st.windows
-        total.rounds += st.rounds
         total.elements += st.elements
+        if M is M2:
+            total.rounds += st.rounds
+        else:
+            total.runs += st.runs
+            total.trips += st.trips
+            total.sweeps += st.sweeps
     assert total.windows > 1000
-    # dependency rounds per window stay close to one on this corpus
-    assert total.rounds / total.windows < 2.5
+    if M is M2:
+        # dependency rounds per window stay close to one on this corpus
+        assert total.rounds / total.windows < 2.5
+    else:
+        print("windows", total.windows, "elements/window",
+              total.elements / total.windows, "runs/window",
+              total.runs / total.windows, "trips/window",
+              total.trips / total.windows, "sweeps/window",
+              total.sweeps / total.windows)
+        assert total.elements / total.windows > 30
+        assert total.runs / total.windows < 5
 
 
 def test_model_on_structured_and_random():
