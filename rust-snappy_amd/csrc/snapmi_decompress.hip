@@ -990,21 +990,22 @@ __device__ __forceinline__ bool decode_windows2(Wide &x, const uint32_t lane)
 //   4. DECODE, PLACEMENT, CHECKS as in the second generation, but every lane
 //      below the element count holds a real element (40 of 64 lanes on the
 //      corpus instead of 14).
-//   5. COPY in in-order RUNS of lanes.  A run ends in front of the first
-//      copy whose source is not complete when the run starts, i.e. reads
-//      the run's own output; the next run starts there (2.9 runs per window
-//      on the corpus, tests/model_decoder3.py).  A run is the second
-//      generation's copy step: 16 bytes per lane and trip, whole-piece
-//      stores resolved by lane order - the excess bytes of a run's last
-//      elements land on later runs' output, which is written afterwards.  A
-//      copy that overlaps itself (offset < length; 0.2 per window) is moved
-//      by the whole wave between two runs.
+//   5. COPY.  Every element whose source is complete before the window -
+//      literals, copies from in front of it - is copied by its lane, as in
+//      the second generation: 16 bytes per trip, whole-piece stores resolved
+//      by lane order, the far sources of the whole window requested at once.
+//      Then the LATE elements - copies that read the window's own output
+//      (2.3 per window on text, 8 on html) or overlap themselves - are moved
+//      one by one, in stream order, by the whole wave (lane k = byte k).
 //
 // A window needs kTail3 bytes of input in front of it, so that none of its
 // loads can leave the input; the last bytes of a stream (and streams shorter
 // than that) are decode_windows2's.  True: something irregular.
 // ---------------------------------------------------------------------
-constexpr uint32_t kG3 = 2;
+#ifndef SNAPMI_G3
+#define SNAPMI_G3 2
+#endif
+constexpr uint32_t kG3 = SNAPMI_G3;
 // the last position (64 kG3 - 1), a tag, 60 literal bytes read as whole
 // 16-byte pieces
 constexpr uint32_t kTail3 = 64 * kG3 + 1 + 64 + 16;
@@ -1186,116 +1187,65 @@ __device__ __forceinline__ bool decode_windows3(Wide &x, const uint32_t lane,
         uint32_t safe_lo = dW > kRing2 ? dW - kRing2 : 0;
         safe_lo = safe_lo > ring_lo ? safe_lo : ring_lo;
         const uint64_t M_ring = __ballot(q >= safe_lo);
-        // a source in HBM must have been stored, and its 16-byte loads must
-        // stay inside the buffer
+        // A source in HBM must have been stored, and its 16-byte loads must
+        // stay inside the buffer.  Both hold by construction while the ring
+        // is whole (a far source ends 1968 bytes or more in front of d, the
+        // stores lag d by less than 256); only behind a long literal, whose
+        // bytes are not in the ring, must the lanes be asked.
+        const bool whole = ring_lo + kRing2 <= dW;
         const uint64_t M_farok =
-            dlen >= 64 ? __ballot(qe <= R.gflush) & __ballot(q <= dlen - 64)
-                       : 0;
-        // moved by the whole wave: copies that overlap themselves, and (only
-        // right after a long literal) sources neither in the ring nor stored
-        const uint64_t M_swp =
-            M_cpy & (__ballot(off < olen) | ~(M_ring | M_farok));
+            whole ? ~0ull
+                  : (dlen >= 64 ? __ballot(qe <= R.gflush) &
+                                      __ballot(q <= dlen - 64)
+                                : 0);
+        // LATE elements are moved one by one, in stream order, by the whole
+        // wave, after everything else: copies that read this window's own
+        // output (qe > d: that includes a copy that overlaps itself) and
+        // sources neither in the ring nor stored.  (2.3 per window on text,
+        // 8 on html: a loop of in-order RUNS of lanes - whole-piece stores
+        // per run - was measured first and cost the scalar unit five times
+        // as much per dependent element.)
+        const uint64_t M_late =
+            M_cpy & (__ballot(qe > d) | ~(M_ring | M_farok));
+        const uint64_t M_lw = K & ~M_late; // copied by their own lanes, now
         // an element's own bytes wrap around the ring's end only in a
         // window whose output does (uniform)
         const uint32_t r0 = d & (kRing2 - 1);
         const bool wraps = r0 + W > kRing2;
-        // the window's stores (whole pieces: up to d + W + 16) touch
-        // ring[0,16) or spill over the ring's end into the mirror
-        const bool mir = r0 < 16 || r0 + W + 16 > kRing2;
-        // sources in HBM must be completed stores: one test per window
-        {
-            const uint64_t M_far_all = M_cpy & ~M_ring & ~M_swp;
-            if (M_far_all) {
-#ifdef SNAPMI_PROFILE
-                x.n_far += __builtin_popcountll(M_far_all);
-#endif
-                if ((M_far_all & __ballot(qe > R.fenced)) != 0) {
-                    R.fence_for(0xFFFFFFFFu);
-                    COUNT(x.n_fence);
-                }
-            }
-        }
-        // elements of more than one 16-byte piece
-        const uint64_t M_o16 = K & __ballot(olen > 16);
-        const uint64_t M_crg = M_cpy & M_ring, M_cfar = M_cpy & ~M_ring;
-        // The first piece of every element whose source is not in the ring
-        // is fetched NOW, for the whole window: literal bytes are here
-        // already (lit16), far sources are old output and do not depend on
-        // the order of the runs below.  What bounds this kernel is the
-        // latency of these loads (a far source is an L2 miss: 64 bytes from
-        // HBM or the MALL, a microsecond or two) - one round trip per window,
-        // not one per run.
+        const uint64_t M_far = M_lw & M_cpy & ~M_ring; // source in HBM
+        const uint64_t M_rng = M_lw & M_cpy & M_ring;  // ... in the ring
+        // The first piece of every element whose source is not in the ring:
+        // literal bytes are here already (lit16); far sources are an L2 miss
+        // each (64 bytes from HBM or the MALL, a microsecond or two), and
+        // that latency is what a wave waits for most - all of them at once.
         B16x v0 = lit16;
-        {
-            const uint64_t M_pre = M_cfar & ~M_swp;
-            if (M_pre != 0 && __builtin_amdgcn_inverse_ballot_w64(M_pre))
+        if (M_far) {
+#ifdef SNAPMI_PROFILE
+            x.n_far += __builtin_popcountll(M_far);
+#endif
+            // sources in HBM must be completed stores
+            if ((M_far & __ballot(qe > R.fenced)) != 0) {
+                R.fence_for(0xFFFFFFFFu);
+                COUNT(x.n_fence);
+            }
+            if (__builtin_amdgcn_inverse_ballot_w64(M_far))
                 __builtin_memcpy(&v0, dst + q, 16);
         }
-        uint32_t a0 = 0;
-        while (a0 < nK) {
-            const uint32_t F = rdlane(dstp, a0);
-            const uint64_t ge = ~0ull << a0;
-            // the run ends in front of the first element that must be swept
-            // or whose source reaches into the run
-            const uint64_t blocked =
-                ge & (M_swp | (M_cpy & __ballot(qe > F)));
-            const uint32_t b =
-                blocked ? (uint32_t)__builtin_ctzll(blocked) : nK;
-            if (b == a0) {
-                // element a0 by the whole wave: lane k = byte k
-                COUNT(x.n_dep);
-                const uint32_t ni = rdlane(olen, a0);
-                const uint32_t qi = rdlane(q, a0), oi = rdlane(off, a0);
-                const uint32_t nsrc = ni < oi ? ni : oi;
-                uint32_t kk = lane;
-                if (oi < ni) { // overlapping: byte k repeats byte k mod oi
-                    const uint32_t quo = (uint32_t)(
-                        ((float)lane + 0.5f) *
-                        __builtin_amdgcn_rcpf((float)oi));
-                    kk = lane - quo * oi;
-                }
-                const bool in_ring = qi >= safe_lo;
-                if (!in_ring) {
-                    // bytes the ring has lost that are not stored yet (only
-                    // right after a long literal): store them first
-                    if (qi + nsrc > R.gflush)
-                        R.flush_partial(F);
-                    if (qi + nsrc > R.fenced) {
-                        R.fence_for(0xFFFFFFFFu);
-                        COUNT(x.n_fence);
-                    }
-                }
-                if (lane < ni) {
-                    const uint32_t val =
-                        in_ring ? (uint32_t)rg[(qi + kk) & (kRing2 - 1)]
-                                : (uint32_t)dst[qi + kk];
-                    rg[(F + lane) & (kRing2 - 1)] = (uint8_t)val;
-                }
-                a0++;
-                continue;
-            }
-            COUNT(x.n_run);
-            const uint64_t M_lw = ge & ~(b == kWave ? 0ull : ~0ull << b);
-            // Sources inside this window's output are read as 16 bytes too
-            // and may run into the mirror: bring it up to date (only a
-            // window that touches the ring's ends needs it at all)
-            if (mir && a0 > 0)
-                R.mirror();
-            if (!wraps && (M_lw & M_o16) == 0) {
-                // the usual run: one piece per element, no wrap
-                COUNT(x.n_trip);
-                B16x v = v0;
-                if (__builtin_amdgcn_inverse_ballot_w64(M_lw & M_crg))
-                    __builtin_memcpy(&v, rg + (q & (kRing2 - 1)), 16);
-                if (__builtin_amdgcn_inverse_ballot_w64(M_lw))
-                    __builtin_memcpy(rg + (dstp & (kRing2 - 1)), &v, 16);
-                a0 = b;
-                continue;
-            }
-            const uint64_t M_far = M_lw & M_cfar; // source in HBM
-            const uint64_t M_rng = M_lw & M_crg;  // ... in the ring
-            // whole 16-byte pieces, last piece first (see decode_windows2)
-            const uint64_t M_g16 = M_lw & M_o16;
+        // Every lane stores WHOLE 16-byte pieces with one ds_write_b128 per
+        // trip, last piece first; the excess of a short element lands on
+        // the elements behind it - higher lanes of the same instruction,
+        // which win (see decode_windows2), or late elements, which are
+        // written afterwards.
+        const uint64_t M_g16 = M_lw & __ballot(olen > 16);
+        if (!wraps && M_g16 == 0) {
+            // the usual window: one piece per element, no wrap
+            COUNT(x.n_trip);
+            B16x v = v0;
+            if (__builtin_amdgcn_inverse_ballot_w64(M_rng))
+                __builtin_memcpy(&v, rg + (q & (kRing2 - 1)), 16);
+            if (__builtin_amdgcn_inverse_ballot_w64(M_lw))
+                __builtin_memcpy(rg + (dstp & (kRing2 - 1)), &v, 16);
+        } else {
             const uint32_t top =
                 M_g16 == 0 ? 0
                            : ((M_g16 & __ballot(olen > 48))
@@ -1340,10 +1290,43 @@ __device__ __forceinline__ bool decode_windows3(Wide &x, const uint32_t lane,
                 if (c == 0)
                     break;
             }
-            a0 = b;
+        }
+        // the late elements: lane k = byte k of the element (exactly its
+        // bytes, addressed bytewise: no mirror)
+        uint64_t late = M_late;
+        while (late) {
+            COUNT(x.n_dep);
+            const uint32_t i = (uint32_t)__builtin_ctzll(late);
+            late &= late - 1;
+            const uint32_t F = rdlane(dstp, i), ni = rdlane(olen, i);
+            const uint32_t qi = rdlane(q, i), oi = F - qi;
+            uint32_t kk = lane;
+            if (oi < ni) { // overlapping: byte k repeats byte k mod oi
+                const uint32_t quo = (uint32_t)(
+                    ((float)lane + 0.5f) * __builtin_amdgcn_rcpf((float)oi));
+                kk = lane - quo * oi;
+            }
+            const bool in_ring = qi >= safe_lo;
+            if (!in_ring) {
+                const uint32_t nsrc = ni < oi ? ni : oi;
+                // bytes the ring has lost that are not stored yet (only
+                // right after a long literal): store them first
+                if (qi + nsrc > R.gflush)
+                    R.flush_partial(F);
+                if (qi + nsrc > R.fenced) {
+                    R.fence_for(0xFFFFFFFFu);
+                    COUNT(x.n_fence);
+                }
+            }
+            if (lane < ni) {
+                const uint32_t val =
+                    in_ring ? (uint32_t)rg[(qi + kk) & (kRing2 - 1)]
+                            : (uint32_t)dst[qi + kk];
+                rg[(F + lane) & (kRing2 - 1)] = (uint8_t)val;
+            }
         }
         // the mirror for the next window (see decode_windows2)
-        if (mir)
+        if (r0 < 16 || r0 + W + 16 > kRing2)
             R.mirror();
         // ---- 6. advance; whole 256-byte pieces go to HBM -----------------
         d += W;

@@ -22,12 +22,11 @@ What differs from the second generation (tests/model_decoder.py):
     holds a real element;
   * literals of 61 bytes and more (a length byte behind the tag) always end a
     window and are copied by the whole wave;
-  * the copy step runs over IN-ORDER RUNS of lanes: a run ends in front of the
-    first copy whose source is not complete when the run starts (it reads the
-    run's own output).  The stores of a run are one instruction per 16-byte
-    trip, so their excess bytes land on later lanes or later runs and are
-    repaired by them.  A copy that overlaps itself (offset < length) is moved
-    by the whole wave, byte by byte, between two runs;
+  * the copy step: every element whose source is complete before the window
+    is copied by its lane (16 bytes per trip, whole-piece stores resolved by
+    lane order), then the LATE elements - copies that read the window's own
+    output or overlap themselves - are moved one by one, in stream order, by
+    the whole wave, byte by byte;
   * a window needs kTail bytes of input in front of it (all loads of the
     window then stay inside the input); the last windows of a stream are the
     sequential decoder's.
@@ -233,80 +232,73 @@ def decode(comp, stats=None):
         if (cpy & ((off == 0) | (off > dstp))).any():
             return irregular()
         assert s + cur <= src_len
-        # ---- 5. the copy step: in-order runs ------------------------------
+        # ---- 5. the copy step ---------------------------------------------
         q = dstp - off
         qe = q + olen
         safe_lo = max(ring_lo, d + W + 16 - R)
         in_ring = q >= safe_lo
-        # a far source must have been stored; one that is neither in the
-        # ring's safe part nor stored (only right after a long literal) and
-        # a copy that overlaps itself are moved by the whole wave
+        # A far source must have been stored (true by construction while the
+        # ring is whole).  LATE elements are moved one by one, in stream
+        # order, by the whole wave after everything else: copies that read
+        # this window's own output (qe > d; that includes a copy that
+        # overlaps itself) and sources neither in the ring nor stored.
+        whole = ring_lo + R <= d + W + 16
         far_ok = (qe <= gflush) & (q + 64 <= dst_len)
-        sweep = cpy & ((off < olen) | (~in_ring & ~far_ok))
-        a = 0
-        while a < E:
-            F = int(dstp[a])
-            blocked = keep & (LANE >= a) & (sweep | (cpy & (qe > F)))
-            b = int(LANE[blocked][0]) if blocked.any() else E
-            if b == a:
-                # element a by the whole wave: lane k = byte k (k mod offset)
-                st.sweeps += 1
-                assert sweep[a], "a ready element blocks its own run"
-                qi, oi, ni = int(q[a]), int(off[a]), int(olen[a])
-                inr = qi >= safe_lo
-                if not inr and qi + min(ni, oi) > gflush:
-                    flush_partial(int(dstp[a]))
-                kk = np.arange(ni)
-                srcpos = qi + (kk % oi)
-                if inr:
-                    data = ring[srcpos & (R - 1)].copy()
+        if whole:
+            assert (~(cpy & ~in_ring) | far_ok).all()
+        late = cpy & ((qe > d) | (~in_ring & ~far_ok))
+        assert (~(cpy & (off < olen)) | late).all()
+        lw = keep & ~late
+        far = lw & ~is_lit & ~in_ring
+        if far.any():
+            st.far += int(far.sum())
+            fence_for(int(qe[far].max()))
+        # whole 16-byte pieces, last piece first, one store instruction per
+        # trip (lanes applied in ascending order): the excess of a short
+        # element lands on the elements behind it - higher lanes of the same
+        # instruction, which win, or late elements, written afterwards
+        st.runs += 1
+        cmax = int(((olen[lw] + 15) // 16).max()) if lw.any() else 0
+        for c in range(cmax - 1, -1, -1):
+            st.trips += 1
+            actc = lw & (16 * c < olen)
+            reads = {}
+            for i in LANE[actc]:             # all loads of the trip first
+                if is_lit[i]:
+                    p0 = s + int(pos[i]) + 1 + 16 * c
+                    assert p0 + 16 <= src_len
+                    reads[i] = src[p0:p0 + 16].copy()
+                elif in_ring[i]:
+                    reads[i] = ring_read16(int(q[i]) + 16 * c)
                 else:
-                    fence_for(qi + min(ni, oi))
-                    data = out[srcpos].copy()
-                ring_write(int(dstp[a]), data)
-                a += 1
-                continue
-            st.runs += 1
-            run = keep & (LANE >= a) & (LANE < b)
-            far = run & ~is_lit & ~in_ring
-            if far.any():
-                st.far += int(far.sum())
-                fence_for(int(qe[far].max()))
-            # sources inside this window's output are read as 16 bytes too
-            # and may run into the mirror: refresh it when the window has
-            # written ring[0,16) or over the ring's end so far
-            a0 = d & (R - 1)
-            done = F - d
-            if a > 0 and (a0 < 16 or a0 + done + 16 > R):
-                mirror()
-            cmax = int(((olen[run] + 15) // 16).max())
-            for c in range(cmax - 1, -1, -1):
-                st.trips += 1
-                actc = run & (16 * c < olen)
-                reads = {}
-                for i in LANE[actc]:             # all loads of the trip first
-                    if is_lit[i]:
-                        p0 = s + int(pos[i]) + 1 + 16 * c
-                        assert p0 + 16 <= src_len
-                        reads[i] = src[p0:p0 + 16].copy()
-                    elif in_ring[i]:
-                        reads[i] = ring_read16(int(q[i]) + 16 * c)
-                    else:
-                        p0 = int(q[i]) + 16 * c
-                        assert p0 + 16 <= dst_len
-                        reads[i] = out[p0:p0 + 16].copy()
-                for i in LANE[actc]:             # one store instruction, lanes
-                    m = min(int(olen[i]) - 16 * c, 16)   # in ascending order
-                    wa = (int(dstp[i]) + 16 * c) & (R - 1)
-                    if wa + m > R:
-                        continue                 # the element's bytes wrap: below
-                    ring[wa:wa + 16] = reads[i]  # may spill into the mirror
-                for i in LANE[actc]:             # (rare) exact, bytewise, wrapped
-                    m = min(int(olen[i]) - 16 * c, 16)
-                    wa = (int(dstp[i]) + 16 * c) & (R - 1)
-                    if wa + m > R:
-                        ring_write(int(dstp[i]) + 16 * c, reads[i][:m])
-            a = b
+                    p0 = int(q[i]) + 16 * c
+                    assert p0 + 16 <= dst_len
+                    reads[i] = out[p0:p0 + 16].copy()
+            for i in LANE[actc]:             # one store instruction
+                m = min(int(olen[i]) - 16 * c, 16)
+                wa = (int(dstp[i]) + 16 * c) & (R - 1)
+                if wa + m > R:
+                    continue                 # the element's bytes wrap: below
+                ring[wa:wa + 16] = reads[i]  # may spill into the mirror
+            for i in LANE[actc]:             # (rare) exact, bytewise, wrapped
+                m = min(int(olen[i]) - 16 * c, 16)
+                wa = (int(dstp[i]) + 16 * c) & (R - 1)
+                if wa + m > R:
+                    ring_write(int(dstp[i]) + 16 * c, reads[i][:m])
+        for i in LANE[late]:                 # in stream order: lane k = byte k
+            st.sweeps += 1
+            qi, oi, ni = int(q[i]), int(off[i]), int(olen[i])
+            inr = qi >= safe_lo
+            if not inr and qi + min(ni, oi) > gflush:
+                flush_partial(int(dstp[i]))
+            kk = np.arange(ni)
+            srcpos = qi + (kk % oi)
+            if inr:
+                data = ring[srcpos & (R - 1)].copy()
+            else:
+                fence_for(qi + min(ni, oi))
+                data = out[srcpos].copy()
+            ring_write(int(dstp[i]), data)
         # the mirror for the next window
         a0 = d & (R - 1)
         if a0 < 16 or a0 + W + 16 > R:

@@ -72,7 +72,7 @@ def test_model_on_corpus():
               total.trips / total.windows, "sweeps/window",
               total.sweeps / total.windows)
         assert total.elements / total.windows > 30
-        assert total.runs / total.windows < 5
+        assert total.sweeps / total.windows < 8
 
 
 def test_model_on_structured_and_random():
