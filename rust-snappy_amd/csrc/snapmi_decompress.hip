@@ -395,7 +395,7 @@ __global__ __launch_bounds__(1024) void k_plan_decompress(DecompressArgs a)
 //   6. the ring goes to HBM 256 bytes at a time (one dword per lane), so
 //      global stores are whole aligned lines instead of 64 byte stores.
 //
-// decode_windows3 (third generation, the default) - 128 compressed bytes per
+// decode_windows3 (third generation, the default) - 256 compressed bytes per
 // window and one ELEMENT per lane; described at the function.
 //
 // Both loops are bound by instruction issue - VALU (a wave64 integer
@@ -1003,7 +1003,7 @@ __device__ __forceinline__ bool decode_windows2(Wide &x, const uint32_t lane)
 // than that) are decode_windows2's.  True: something irregular.
 // ---------------------------------------------------------------------
 #ifndef SNAPMI_G3
-#define SNAPMI_G3 2
+#define SNAPMI_G3 4
 #endif
 constexpr uint32_t kG3 = SNAPMI_G3;
 // the last position (64 kG3 - 1), a tag, 60 literal bytes read as whole

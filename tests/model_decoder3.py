@@ -1,6 +1,6 @@
 """Lane-level model (numpy, 64-wide arrays) of k_decompress_streams3 in
 rust-snappy_amd/csrc/snapmi_decompress.hip: the third-generation wave decoder
-(128 compressed bytes per window, one ELEMENT per lane).
+(256 compressed bytes per window, one ELEMENT per lane).
 
 TEST INFRASTRUCTURE: the kernel's algorithm restated step by step so that its
 logic can be checked on the CPU against the oracle
@@ -9,7 +9,7 @@ is not used by the product.
 
 What differs from the second generation (tests/model_decoder.py):
 
-  * a window is G groups of 64 input bytes (G = 2): lane l looks at the tag
+  * a window is G groups of 64 input bytes (G = 4): lane l looks at the tag
     bytes at s + 64 g + l only far enough to know how long the element there
     would be (no offsets, no lengths beyond the tag);
   * element starts: per group one 32-bit set per lane and half (positions of
@@ -38,7 +38,7 @@ import numpy as np
 R = 4096          # ring bytes
 WMAX = 2048       # output bytes per window at most
 WAVE = 64
-G = 2             # groups of 64 input bytes per window
+G = 4             # groups of 64 input bytes per window (kG3)
 # every load of a window stays inside the input when this much is left: the
 # last position (64 G - 1), an element header (tag + 4 offset bytes / a tag
 # and 60 literal bytes rounded up to whole 16-byte pieces)
