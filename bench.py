@@ -215,8 +215,10 @@ def run_extras(args, local_rank, dev, rank, world):
     # sharded encode + gather has never met a multi-GPU box in this repo's
     # own runs; in a child with a time limit, whatever goes wrong there is a
     # recorded error and not a lost headline line.
+    over = os.environ.get("SNAPMI_OVERSUBSCRIBE") == "1"
     res = rank_children([sys.executable, str(ROOT / "bench_configs.py"),
-                         "--plan", f"cfg4:{8 * world}"],
+                         "--plan", f"cfg4:{(1 if over else 8) * world}"]
+                        + (["--period-mib", "64"] if over else []),
                         rank, local_rank, world, 300)
     if res is not None:
         out["cfg4"] = res
@@ -287,7 +289,7 @@ def maybe_spawn(args):
     None when this process is a rank (or N == 1) and should carry on."""
     if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
         return None
-    if not args.plumbing_check:
+    if not args.plumbing_check and not args.oversubscribe:
         have = torch.cuda.device_count() if torch.cuda.is_available() else 0
         if have < args.gpus:
             sys.exit(f"bench.py: --gpus {args.gpus} but {have} GPU(s) visible "
@@ -305,6 +307,8 @@ def maybe_spawn(args):
         + " ".join(cmd[1:8]) + " ...")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get(
         "HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    if args.oversubscribe:
+        env["SNAPMI_OVERSUBSCRIBE"] = "1"
     return subprocess.call(cmd, env=env)
 
 
@@ -355,6 +359,10 @@ def main():
     ap.add_argument("--extras-gib", type=float, default=None,
                     help="size of the cfg3 / cfg5 extras (default: BASELINE's "
                          "64 and 32 GiB)")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="proof run of the N > 1 code on ONE GPU: all ranks "
+                         "drive cuda:0, collectives over gloo; the JSON line "
+                         "is marked INVALID (it is no scaling number)")
     ap.add_argument("--plumbing-check", action="store_true",
                     help="no GPU work: only the --gpus N launch plumbing over "
                          "gloo (what tests/test_bench_spawn_cpu.py runs)")
@@ -372,15 +380,26 @@ def main():
     if args.plumbing_check:
         return plumbing_check(rank, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    # --oversubscribe: the real rank code, N ranks on cuda:0, gloo instead of
+    # RCCL (which refuses two ranks on one device) - proves the N > 1 path
+    # before a multi-GPU box runs it; never a measurement
+    over = args.oversubscribe or os.environ.get("SNAPMI_OVERSUBSCRIBE") == "1"
+    if over:
+        os.environ["SNAPMI_OVERSUBSCRIBE"] = "1"
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         sys.exit(f"bench.py: rank {rank} wants cuda:{local_rank} but only "
                  f"{torch.cuda.device_count()} devices are visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if over else dev  # where collectives run
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if over:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import __graft_entry__ as g
     g.build()
@@ -501,13 +520,17 @@ def main():
                  float(np.mean(k_dec_ms)), elapsed / args.steps * 1e3]]
     if world > 1:
         t = torch.tensor([elapsed, t_comp, t_dec], dtype=torch.float64,
-                         device=dev)
+                         device=cdev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed, t_comp, t_dec = t.tolist()
-        mine = torch.tensor(per_rank[0], dtype=torch.float64, device=dev)
+        mine = torch.tensor(per_rank[0], dtype=torch.float64, device=cdev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         torch.distributed.all_gather(allr, mine)
         per_rank = [x.tolist() for x in allr]
+        ranks_seen = [None] * world
+        torch.distributed.all_gather_object(ranks_seen, rank)
+    else:
+        ranks_seen = [0]
 
     # ---- extra configs (never part of `value`) ---------------------------
     extras = None
@@ -543,8 +566,8 @@ def main():
         ach_d = alg / kd / 1e9
         dom_name = ("k_match_blocks" if abs(kdom - kc) > 1e-9
                     else "k_compress_blocks")
-        dec_name = ("k_decompress_streams" if os.environ.get(
-            "SNAPMI_DECODE_KERNEL") == "1" else "k_decompress_streams2")
+        dec_name = ("k_decompress_streams2" if os.environ.get(
+            "SNAPMI_DECODE_KERNEL") == "2" else "k_decompress_streams3")
         traffic = traffic_d = None
         pmc_name = None
         for cand in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
@@ -609,10 +632,15 @@ def main():
         # per rank: [dominant compress kernel, all compress kernels,
         # decompress kernel, wall per step] in ms (HIP events / host clock)
         line["per_rank_ms"] = [[round(v, 3) for v in r] for r in per_rank]
+        line["ranks_seen"] = sorted(ranks_seen)
         if extras is not None:
             line["extras"] = extras
         if args.no_verify:
             line["INVALID"] = "experiment build, parity gate skipped"
+        if over:
+            line["INVALID"] = (f"oversubscribed: {world} ranks on one GPU over "
+                               "gloo - a proof of the N > 1 code, not a "
+                               "measurement")
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(rnd)
         print(json.dumps(line), flush=True)

@@ -355,7 +355,10 @@ def cfg4(args, ctx, dev):
     rank = int(os.environ.get("RANK", "0"))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if os.environ.get("SNAPMI_OVERSUBSCRIBE") == "1":
+            dist.init_process_group("gloo")  # N ranks on one GPU: proof run
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     period = synth_text(dev, int(args.period_mib * (1 << 20)))
     assert period.numel() % 65536 == 0
     periods = max(world, int(args.gib * GIB / period.numel()))
@@ -386,6 +389,10 @@ def cfg4(args, ctx, dev):
     whole = shard.gatherv(part, dst=0) if world > 1 else part
     sync()
     t_gather = time.perf_counter() - t0
+    seen = [rank]
+    if world > 1:
+        seen = [None] * world
+        dist.all_gather_object(seen, rank)
     res = None
     if rank == 0:
         # the head of the gathered stream against the oracle, chunk for chunk
@@ -407,7 +414,7 @@ def cfg4(args, ctx, dev):
                "gather_gbs": (round((whole.numel() - part.numel()) / t_gather
                                     / 1e9, 1) if world > 1 else None),
                "gather_bound_gbs": 1071.0,
-               "ranks_seen": world}
+               "ranks_seen": sorted(seen)}
     if world > 1:
         dist.barrier()
     if rank == 0:
@@ -432,6 +439,8 @@ def main():
     from rust_snappy_amd import raw
     import os
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("SNAPMI_OVERSUBSCRIBE") == "1":
+        local = 0  # bench.py --oversubscribe: every rank drives cuda:0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     ctx = raw.Context(local)

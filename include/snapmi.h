@@ -21,6 +21,7 @@
  *     host buffers one batch of chunks per call - what a host-language
  *     FrameEncoder / FrameDecoder (shim/, rust-snappy_amd/frame.py,
  *     tools/szip.cpp) makes per batch.
+ *  5. The gather of framed parts across the GPUs of a node (RCCL).
  *
  * Plain pointers and sizes only; no C++ or torch types.  All functions are
  * blocking unless stated otherwise.  Every compute entry point runs HIP
@@ -446,6 +447,45 @@ int snapmi_frame_index_host(const void *h_in, uint64_t in_len,
 int snapmi_crc32c_masked_batch(snapmi_ctx *ctx, const void *const *d_ptrs,
                                const uint64_t *d_lens, uint32_t *d_out,
                                size_t n);
+
+/* ------------------------------------------------------------------ */
+/* 5. Multi-GPU: the one exchange step of the path.         */
+/*                                                                      */
+/* Raw streams and frame chunks are independent, so N GPUs shard a job  */
+/* with no exchange during compute: rank r frames a contiguous range of */
+/* chunks with snapmi_frame_compress[_chunks] (ranks behind the first   */
+/* pass SNAPMI_FRAME_NO_IDENT, or drop the 10-byte identifier), and the */
+/* concatenation of the parts in rank order is the single-stream        */
+/* framing the reference's writer produces (src/write.rs:165-192).      */
+/* snapmi_gatherv assembles it on one rank over RCCL (xGMI inside a     */
+/* node): sizes first, then ONE group of point-to-point transfers       */
+/* straight into the root's buffer at every rank's prefix offset, so    */
+/* the root's links receive in parallel.  librccl is opened at run time */
+/* (dlopen); a process that already holds one (PyTorch) shares it.      */
+/* ------------------------------------------------------------------ */
+#define SNAPMI_COMM_ID_BYTES 128
+typedef struct snapmi_comm snapmi_comm;
+
+/* A fresh rendezvous id (ncclGetUniqueId): call on ONE rank, hand the 128
+ * bytes to the others by any means (file, socket, MPI, torch store). */
+int snapmi_comm_unique_id(uint8_t id_out[SNAPMI_COMM_ID_BYTES]);
+/* Collective: every rank calls it with the same id and world, its own rank,
+ * and a context on the GPU it drives (one process per GPU). */
+int snapmi_comm_init(snapmi_ctx *ctx, const uint8_t id[SNAPMI_COMM_ID_BYTES],
+                     int rank, int world, snapmi_comm **out);
+/* Or use a communicator the host already has (an ncclComm_t, as void *);
+ * it is not destroyed by snapmi_comm_destroy. */
+int snapmi_comm_wrap(snapmi_ctx *ctx, void *nccl_comm, int rank, int world,
+                     snapmi_comm **out);
+void snapmi_comm_destroy(snapmi_comm *comm);
+/* Collective, blocking.  Every rank contributes d_send[0, send_bytes) (device
+ * memory, may be empty); on `root`, d_recv[0, *total) receives the parts in
+ * rank order.  h_sizes (host, [world], may be NULL) and *total are filled on
+ * EVERY rank.  recv_cap matters on the root only; if the parts do not fit,
+ * every rank returns SNAPMI_E_ARGUMENT and nothing is exchanged. */
+int snapmi_gatherv(snapmi_ctx *ctx, snapmi_comm *comm, int root,
+                   const void *d_send, uint64_t send_bytes, void *d_recv,
+                   uint64_t recv_cap, uint64_t *h_sizes, uint64_t *total);
 
 #ifdef __cplusplus
 }

@@ -82,6 +82,13 @@ SYMBOLS = [
     ("snapmi_frame_index_host", C.c_int,
      [_P, C.c_uint64, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("snapmi_crc32c_masked_batch", C.c_int, [_P, _P, _P, _P, _SZ]),
+    ("snapmi_comm_unique_id", C.c_int, [_P]),
+    ("snapmi_comm_init", C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
+    ("snapmi_comm_wrap", C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
+    ("snapmi_comm_destroy", None, [_P]),
+    ("snapmi_gatherv", C.c_int,
+     [_P, _P, C.c_int, _P, C.c_uint64, _P, C.c_uint64, _P,
+      C.POINTER(C.c_uint64)]),
 ]
 
 _lib = None

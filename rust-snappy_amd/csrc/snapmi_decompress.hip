@@ -40,7 +40,6 @@ namespace snapmi {
 
 namespace {
 
-constexpr uint32_t kRing = 4096;
 
 // reference bytes::read_varu64, src/bytes.rs:73-90 (returns header length,
 // 0 = invalid).  Executed redundantly by every lane on uniform data.

@@ -8,6 +8,8 @@ of the (variable-length) results, used to assemble one framed stream.
 Works with any torch.distributed backend: `nccl` (= RCCL over xGMI) on GPUs,
 `gloo` on CPU (tests).
 """
+import ctypes as C
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -57,6 +59,11 @@ def gatherv(local, dst=0, group=None):
     concatenation on `dst`, None elsewhere."""
     rank = dist.get_rank(group)
     world = dist.get_world_size(group)
+    if dist.get_backend(group) == "gloo" and local.is_cuda:
+        # gloo moves host memory: stage (CPU tests, and bench.py's
+        # --oversubscribe proof run of N ranks on one GPU)
+        whole = gatherv(local.cpu(), dst, group)
+        return None if whole is None else whole.to(local.device)
     sizes, offs = exchange_sizes(local.numel(), local.device, group)
     ops, out = [], None
     if rank == dst:
@@ -73,3 +80,57 @@ def gatherv(local, dst=0, group=None):
         for q in dist.batch_isend_irecv(ops):
             q.wait()
     return out
+
+
+class Comm:
+    """snapmi_comm: an RCCL communicator behind the C ABI (include/snapmi.h
+    section 5) - what a host without torch.distributed uses.  `ident` is the
+    128-byte rendezvous id of snapmi_comm_unique_id(), made on one rank and
+    handed to the others by any means."""
+
+    def __init__(self, ctx, ident, rank, world):
+        from . import _lib, raw
+        self._L, self._raw, self.ctx = _lib.load(), raw, ctx
+        self.rank, self.world = rank, world
+        h = C.c_void_p()
+        rc = self._L.snapmi_comm_init(ctx._h, bytes(ident), rank, world,
+                                      C.byref(h))
+        if rc:
+            raw._raise(ctx, rc)
+        self._h = h
+
+    @staticmethod
+    def unique_id():
+        from . import _lib
+        buf = C.create_string_buffer(128)
+        rc = _lib.load().snapmi_comm_unique_id(buf)
+        if rc:
+            raise RuntimeError(f"snapmi_comm_unique_id failed ({rc}): "
+                               "is librccl reachable?")
+        return buf.raw
+
+    def gatherv(self, local, dst=0, cap=None):
+        """snapmi_gatherv of a 1-D uint8 CUDA tensor; returns (the
+        concatenation on `dst` / None elsewhere, sizes per rank)."""
+        sizes = (C.c_uint64 * self.world)()
+        total = C.c_uint64(0)
+        n = local.numel()
+        if cap is None:
+            # sizes are not known before the call: the root passes a bound
+            raise ValueError("gatherv needs the root's capacity (bytes)")
+        out = (torch.empty(max(cap, 16), dtype=torch.uint8,
+                           device=local.device)
+               if self.rank == dst else None)
+        rc = self._L.snapmi_gatherv(
+            self.ctx._h, self._h, dst,
+            C.c_void_p(local.data_ptr()) if n else None, n,
+            C.c_void_p(out.data_ptr()) if out is not None else None,
+            cap if out is not None else 0, sizes, C.byref(total))
+        if rc:
+            self._raw._raise(self.ctx, rc)
+        return (out[:total.value] if out is not None else None), list(sizes)
+
+    def close(self):
+        if self._h:
+            self._L.snapmi_comm_destroy(self._h)
+            self._h = None
