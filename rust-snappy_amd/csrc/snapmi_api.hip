@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
 #include <new>
 #include <string>
@@ -1178,24 +1179,75 @@ int snapmi_raw_decompress(snapmi_ctx *ctx, const uint8_t *input,
 
 // ----------------------------------------------------------------------
 // libsnappy C API (snappy-c.h), as bound by the reference's snappy-cpp
-// crate.  A process-wide context on device SNAPMI_DEVICE (default 0),
-// serialised by a mutex: the C API is stateless and re-entrant.
+// crate.  The reference's wrappers are stateless and may be called from any
+// number of threads at once (snappy-cpp/src/lib.rs:13-64), so these calls
+// check a context out of a small process-wide pool on device SNAPMI_DEVICE
+// (default 0): contexts are created on demand, up to SNAPMI_SEAM_CONTEXTS
+// (default 8); T callers run on T HIP streams, further callers wait for a
+// context to come back.
 // ----------------------------------------------------------------------
 namespace {
-std::mutex g_mu;
-snapmi_ctx *g_ctx = nullptr;
+struct SeamPool {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<snapmi_ctx *> idle;
+    size_t created = 0, cap = 0;
+    bool broken = false; // a context could not be created: do not retry
 
-snapmi_ctx *global_ctx()
-{
-    if (!g_ctx) {
-        int dev = 0;
-        if (const char *e = getenv("SNAPMI_DEVICE"))
-            dev = atoi(e);
-        if (snapmi_ctx_create(dev, nullptr, &g_ctx) != SNAPMI_OK)
-            g_ctx = nullptr;
+    snapmi_ctx *checkout()
+    {
+        std::unique_lock<std::mutex> lock(mu);
+        if (cap == 0) {
+            cap = 8;
+            if (const char *e = getenv("SNAPMI_SEAM_CONTEXTS"))
+                cap = (size_t)(atoi(e) < 1 ? 1 : atoi(e));
+        }
+        for (;;) {
+            if (!idle.empty()) {
+                snapmi_ctx *c = idle.back();
+                idle.pop_back();
+                return c;
+            }
+            if (created < cap && !broken) {
+                created++; // reserved: created outside the lock
+                lock.unlock();
+                int dev = 0;
+                if (const char *e = getenv("SNAPMI_DEVICE"))
+                    dev = atoi(e);
+                snapmi_ctx *c = nullptr;
+                if (snapmi_ctx_create(dev, nullptr, &c) == SNAPMI_OK)
+                    return c;
+                lock.lock();
+                created--;
+                broken = true; // (snapmi_ctx_create has printed why)
+                cv.notify_all();
+                return nullptr;
+            }
+            if (created == 0)
+                return nullptr; // no context and none can be made
+            cv.wait(lock);
+        }
     }
-    return g_ctx;
-}
+    void give_back(snapmi_ctx *c)
+    {
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            idle.push_back(c);
+        }
+        cv.notify_one();
+    }
+};
+SeamPool g_pool;
+
+struct SeamLease {
+    snapmi_ctx *ctx;
+    SeamLease() : ctx(g_pool.checkout()) {}
+    ~SeamLease()
+    {
+        if (ctx)
+            g_pool.give_back(ctx);
+    }
+};
 } // namespace
 
 size_t snappy_max_compressed_length(size_t source_length)
@@ -1224,8 +1276,8 @@ snappy_status snappy_compress(const char *input, size_t input_length,
         return SNAPPY_INVALID_INPUT;
     if (*compressed_length < snappy_max_compressed_length(input_length))
         return SNAPPY_BUFFER_TOO_SMALL;
-    std::lock_guard<std::mutex> lock(g_mu);
-    snapmi_ctx *ctx = global_ctx();
+    SeamLease lease;
+    snapmi_ctx *ctx = lease.ctx;
     if (!ctx) // (snapmi_ctx_create has printed why)
         return SNAPPY_INVALID_INPUT;
     size_t written = 0;
@@ -1260,8 +1312,8 @@ snappy_status snappy_uncompress(const char *compressed,
         return SNAPPY_INVALID_INPUT;
     if (*uncompressed_length < need)
         return SNAPPY_BUFFER_TOO_SMALL;
-    std::lock_guard<std::mutex> lock(g_mu);
-    snapmi_ctx *ctx = global_ctx();
+    SeamLease lease;
+    snapmi_ctx *ctx = lease.ctx;
     if (!ctx)
         return SNAPPY_INVALID_INPUT;
     size_t written = 0;

@@ -160,6 +160,36 @@ def test_frame_scan_host_batches_and_stale_bytes(built):
     assert bytes(stale) == b"\x80\x81\x82\x00" + bytes(range(104, 110))
 
 
+_RUST_SCALARS = {"c_int": "int", "i32": "int", "u32": "uint32_t",
+                 "u64": "uint64_t", "usize": "size_t", "u8": "uint8_t",
+                 "c_char": "char", "c_void": "void",
+                 "SnapmiCtx": "snapmi_ctx", "SnapmiError": "snapmi_error"}
+
+
+def _rust_c_type(t):
+    """`*mut *mut SnapmiCtx` -> 'snapmi_ctx**' (constness dropped: C allows
+    passing either, the ABI is the same)."""
+    t = t.strip()
+    stars = 0
+    while t.startswith("*"):
+        t = t[1:].strip()
+        assert t.startswith(("mut ", "const ")), t
+        t = t.split(" ", 1)[1].strip()
+        stars += 1
+    return _RUST_SCALARS[t] + "*" * stars
+
+
+def _c_type(param):
+    """`const uint8_t *h_in` -> 'uint8_t*'; `uint8_t id[128]` -> 'uint8_t*'"""
+    import re
+    p = re.sub(r"\bconst\b", "", param).strip()
+    stars = p.count("*") + (1 if "[" in p else 0)
+    p = re.sub(r"\[.*?\]", "", p).replace("*", " ")
+    words = p.split()
+    base = " ".join(words[:-1]) if len(words) > 1 else words[0]
+    return base + "*" * stars
+
+
 def test_rust_shim_binds_only_exported_symbols(built):
     """shim/ cannot be compiled here (no rustc); what can be checked is that
     every `extern "C"` function it declares is exported by libsnapmi.so with
@@ -184,6 +214,16 @@ def test_rust_shim_binds_only_exported_symbols(built):
         c_params = m.group(1).strip()
         n_c = 0 if c_params in ("", "void") else len(c_params.split(","))
         assert n_rust == n_c, (name, n_rust, n_c)
+        # ... and the same TYPES, parameter by parameter and for the result
+        rust_types = [_rust_c_type(p.split(":", 1)[1])
+                      for p in params.split(",") if p.strip()]
+        c_types = [] if n_c == 0 else [_c_type(p) for p in c_params.split(",")]
+        assert rust_types == c_types, (name, rust_types, c_types)
+        rm = re.search(r"pub fn %s\s*\([^;]*?\)\s*(?:->\s*([\w:*<> ]+))?;"
+                       % name, block, re.S)
+        r_ret = _rust_c_type(rm.group(1)) if rm.group(1) else "void"
+        cm = re.search(r"([\w \*]+?)\b%s\s*\(" % name, header)
+        assert r_ret == _c_type(cm.group(1) + " x"), (name, r_ret, cm.group(1))
     for variant in ("TooBig", "BufferTooSmall", "Empty", "Header",
                     "HeaderMismatch", "Literal", "CopyRead", "CopyWrite",
                     "Offset", "StreamHeader", "StreamHeaderMismatch",

@@ -575,3 +575,134 @@ def test_compress_without_lds_atomic_order(built):
     for d, g in zip(ins, got):
         assert g == O.compress(d), len(d)
     c.close()
+
+
+def test_compress_too_big_by_descriptor(cctx):
+    """Error::TooBig on compress (reference src/compress.rs:104-110) without a
+    4 GiB buffer: a batch descriptor CLAIMS 2^32 bytes.  The stream is
+    rejected with the reference's fields and never touched; its neighbours
+    compress to the oracle's bytes."""
+    import torch
+    from rust_snappy_amd import batch, raw
+    ins = [b"neighbour " * 500, b"x" * 64, bytes(range(256)) * 40]
+    src = batch.StreamBatch.from_bytes(ins)
+    fake = src.lens.copy()
+    fake[1] = 1 << 32
+    d_lens = torch.from_numpy(fake).to(src.data.device)
+    caps = [raw.max_compress_len(len(s)) for s in ins]
+    dst = batch.StreamBatch.empty(caps, src.data.device)
+    out_lens = torch.zeros(3, dtype=torch.int64, device=src.data.device)
+    errs = torch.zeros(32 * 3, dtype=torch.uint8, device=src.data.device)
+    # (the capacity check comes second in the reference: pass no capacities)
+    raw.compress_batch(cctx, src.d_ptrs, d_lens, dst.d_ptrs, None, out_lens,
+                       errs, host_in_lens=torch.from_numpy(fake.copy()))
+    cctx.synchronize()
+    e = batch.read_errors(errs)
+    assert e[1] == (O.KIND_NAMES.index("TooBig"), 1 << 32, 0xFFFFFFFF, 0)
+    assert int(out_lens[1]) == 0
+    for i in (0, 2):
+        assert e[i][0] == 0
+        assert dst.stream_bytes(i, int(out_lens[i])) == O.compress(ins[i])
+
+
+def test_decode_descriptor_of_4_gib_goes_to_the_sequential_decoder(ctx):
+    """A compressed stream of 4 GiB or more is legal (every element tiny) and
+    is left to the sequential decoder as a whole (positions in the window
+    loops are 32-bit).  Exercised with a descriptor that CLAIMS 2^32 + 100
+    bytes over a tiny buffer whose first element already fails: the error
+    carries the claimed length, like the reference's would
+    (src/decompress.rs:209-217)."""
+    import torch
+    from rust_snappy_amd import batch, raw
+    # header: 5 bytes of output; a literal of 10 bytes -> Literal{len 10,
+    # src_len (what is left behind the tag), dst_len 5}
+    body = bytes([5, (10 - 1) << 2]) + b"0123456789" + bytes(64)
+    src = batch.StreamBatch.from_bytes([body, O.compress(b"fine" * 100)])
+    claimed = (1 << 32) + 100
+    fake = src.lens.copy()
+    fake[0] = claimed
+    d_lens = torch.from_numpy(fake).to(src.data.device)
+    dst = batch.StreamBatch.empty([5, 400], src.data.device)
+    out_lens = torch.zeros(2, dtype=torch.int64, device=src.data.device)
+    errs = torch.zeros(64, dtype=torch.uint8, device=src.data.device)
+    raw.decompress_batch(ctx, src.d_ptrs, d_lens, dst.d_ptrs, dst.d_lens,
+                         out_lens, errs)
+    ctx.synchronize()
+    e = batch.read_errors(errs)
+    assert e[0] == (O.KIND_NAMES.index("Literal"), 10, claimed - 2, 5), e[0]
+    assert e[1][0] == 0 and dst.stream_bytes(1, 400) == b"fine" * 100
+
+
+def test_snappy_uncompress_into_a_short_buffer(ctx):
+    """snappy_uncompress with *uncompressed_length too small: the status of
+    libsnappy 1.1.8 (the library the reference's seam binds), and the length
+    is left alone."""
+    import ctypes as C
+    from rust_snappy_amd import _lib
+    L = _lib.load()
+    data = b"status parity " * 300
+    comp = O.compress(data)
+    buf = C.create_string_buffer(len(data))
+    for cap in (0, 1, len(data) - 1):
+        n = C.c_size_t(cap)
+        got = L.snappy_uncompress(comp, len(comp), buf, C.byref(n))
+        assert got == 2 and n.value == cap          # SNAPPY_BUFFER_TOO_SMALL
+        ref = O.libsnappy()
+        if ref is not None:
+            m = C.c_size_t(cap)
+            ref.snappy_uncompress.restype = C.c_int
+            want = ref.snappy_uncompress(comp, C.c_size_t(len(comp)), buf,
+                                         C.byref(m))
+            assert got == want, (cap, got, want)
+    n = C.c_size_t(len(data))
+    assert L.snappy_uncompress(comp, len(comp), buf, C.byref(n)) == 0
+    assert buf.raw[:n.value] == data
+
+
+def test_snappy_c_api_from_many_threads(ctx):
+    """The reference's native wrappers are stateless and callable from any
+    thread at once (snappy-cpp/src/lib.rs:13-64): 8 threads x 200 calls of
+    snappy_compress + snappy_uncompress, bytes equal to the oracle's, and the
+    calls really overlap (a pool of contexts, not one behind a mutex)."""
+    import ctypes as C
+    import threading
+    import time
+    from rust_snappy_amd import _lib
+    L = _lib.load()
+    rng = random.Random(77)
+    inputs = [bytes(rng.choices(range(rng.choice([2, 4, 16, 256])),
+                                k=rng.randrange(1, 40000))) for _ in range(25)]
+    want = [O.compress(x) for x in inputs]
+    bad = []
+
+    def worker(tid, calls):
+        cap = max(L.snappy_max_compressed_length(len(x)) for x in inputs)
+        out = C.create_string_buffer(cap)
+        back = C.create_string_buffer(40000)
+        for k in range(calls):
+            i = (tid * 7 + k) % len(inputs)
+            n = C.c_size_t(cap)
+            if L.snappy_compress(inputs[i], len(inputs[i]), out, C.byref(n)) \
+                    or out.raw[:n.value] != want[i]:
+                bad.append(("compress", tid, k))
+            m = C.c_size_t(40000)
+            if L.snappy_uncompress(want[i], len(want[i]), back, C.byref(m)) \
+                    or back.raw[:m.value] != inputs[i]:
+                bad.append(("uncompress", tid, k))
+
+    worker(0, 20)                                  # warm: first context
+    t0 = time.perf_counter()
+    worker(0, 200)
+    t1 = time.perf_counter() - t0
+    ths = [threading.Thread(target=worker, args=(t, 200)) for t in range(8)]
+    t0 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    t8 = time.perf_counter() - t0
+    assert not bad, bad[:5]
+    rate1, rate8 = 400 / t1, 8 * 400 / t8
+    print(f"\nsnappy C API calls/s: 1 thread {rate1:.0f}, 8 threads {rate8:.0f}"
+          f" ({rate8 / rate1:.2f}x)")
+    assert rate8 > 2.0 * rate1, (rate1, rate8)
