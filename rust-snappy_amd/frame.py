@@ -376,10 +376,11 @@ class FrameDecoder:
         self.r = rdr
         self.ctx = ctx or raw.default_context()
         self.batch_bytes = max(int(batch_bytes), 1 << 17)
-        self._carry = b""        # bytes read but not decoded (a cut chunk)
+        self._carry = bytearray()  # bytes read but not decoded (a cut chunk)
         self._out = b""
         self._pos = 0
         self._err = None
+        self._io_err = None      # the inner reader's error (retryable)
         self._eof = False
         self._seen_ident = False
         self._stale = bytearray(10)  # reference src[0..10): include/snapmi.h
@@ -393,16 +394,24 @@ class FrameDecoder:
         return self.r
 
     def _pull(self, want):
-        parts, got = [self._carry], len(self._carry)
-        while got < want and not self._eof:
-            b = self.r.read(want - got)
+        """Bytes for one batch: the carry plus what the reader has NOW.  The
+        reference reads one chunk per call (src/read.rs:105-172); batching
+        must not turn into waiting: one inner read at least, more only while
+        the reader keeps filling what it is offered (a short read means it
+        has no more at the moment - a pipe, a socket, a request/response
+        peer that waits for our answer before it sends on)."""
+        rd = getattr(self.r, "read1", None) or self.r.read
+        while len(self._carry) < want and not self._eof:
+            ask = want - len(self._carry)
+            b = rd(ask)   # (if it raises, what was read so far stays in _carry)
             if not b:
                 self._eof = True
                 break
-            parts.append(bytes(b))
-            got += len(b)
-        self._carry = b""
-        return b"".join(parts)
+            self._carry += b
+            if len(b) < ask:
+                break
+        data, self._carry = bytes(self._carry), bytearray()
+        return data
 
     def _fill(self):
         want = self.batch_bytes
@@ -419,14 +428,14 @@ class FrameDecoder:
             n, used, err = decode_host(self.ctx, data, out, self._seen_ident,
                                        self._eof, self._stale)
             if err is None and used == 0:   # not one whole chunk yet
-                self._carry = data
+                self._carry = bytearray(data)
                 want = len(data) + self.batch_bytes
                 if self._eof:
                     raise Error(101, message="frame_decode_host made no "
                                              "progress at end of input")
                 continue
             break
-        self._carry = data[used:] if err is None else b""
+        self._carry = bytearray(data[used:] if err is None else b"")
         self._seen_ident = self._seen_ident or used > 0
         self._out, self._pos, self._err = bytes(out[:n]), 0, err
 
@@ -447,9 +456,20 @@ class FrameDecoder:
                 if parts:
                     break          # hand out the good bytes first
                 raise self._err
+            if self._io_err is not None:
+                if parts:
+                    break
+                e, self._io_err = self._io_err, None
+                raise e            # a caller may retry: nothing was lost
             if self._eof and not self._carry:
                 break
-            self._fill()
+            try:
+                self._fill()
+            except Error:
+                raise
+            except Exception as e:  # noqa: BLE001 - the reader's error
+                self._io_err = e    # behind the bytes gathered so far
+                continue
             if not self._out and self._err is None and self._eof \
                     and not self._carry:
                 break
@@ -480,6 +500,8 @@ class ReadFrameEncoder:
         self._pos = 0
         self._eof = False
         self._wrote_ident = False
+        self._chunks = []        # read, not yet compressed
+        self._pending = None     # a reader's error, raised behind _buf
 
     def get_ref(self):
         return self.r
@@ -487,17 +509,32 @@ class ReadFrameEncoder:
     get_mut = get_ref
 
     def _fill(self):
-        chunks, total = [], 0
-        while total < self.batch_bytes:
-            b = self.r.read(MAX_BLOCK_SIZE)
+        """Up to batch_bytes of inner reads -> one device call.  A read that
+        fails does not lose the chunks gathered before it: they are
+        compressed and handed out, the error is raised by the read that
+        follows them (the reference does one inner read per outer read,
+        src/read.rs:378, so an error there loses nothing either).  A short
+        read ends the batch: the reader has no more right now."""
+        total = sum(len(c) for c in self._chunks)
+        while total < self.batch_bytes and self._pending is None:
+            try:
+                b = self.r.read(MAX_BLOCK_SIZE)
+            except InterruptedError:
+                continue                     # ErrorKind::Interrupted: retry
+            except Exception as e:           # noqa: BLE001 - re-raised later
+                self._pending = e
+                break
             if not b:
                 self._eof = True
                 break
-            chunks.append(bytes(b))
+            self._chunks.append(bytes(b))
             total += len(b)
+            if len(b) < MAX_BLOCK_SIZE:
+                break
         self._buf, self._pos = b"", 0
-        if not chunks:
+        if not self._chunks:
             return
+        chunks, self._chunks = self._chunks, []
         lens = np.fromiter((len(c) for c in chunks), dtype=np.uint32,
                            count=len(chunks))
         self._buf = encode_host(self.ctx, bytearray().join(chunks), lens,
@@ -515,6 +552,11 @@ class ReadFrameEncoder:
                     need -= end - self._pos
                 self._pos = end
                 continue
+            if self._pending is not None:
+                if parts:
+                    break                    # the good bytes first
+                e, self._pending = self._pending, None
+                raise e
             if self._eof:
                 break
             self._fill()

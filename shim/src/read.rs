@@ -1,11 +1,12 @@
 //! `snap::read::FrameDecoder` and `snap::read::FrameEncoder` (reference
 //! src/read.rs).
 //!
-//! `FrameDecoder` pulls up to `BATCH` bytes from the reader, lets
-//! `snapmi_frame_decode_host` decode every complete chunk in them in one
-//! device call (header checks, raw decode, CRC, all in the reference's order)
-//! and keeps the cut-off tail for the next round.  Bytes of the chunks in
-//! front of a bad chunk are returned before the error (reference :111-118).
+//! `FrameDecoder` takes what the reader has - up to `BATCH` bytes, but never
+//! waiting for more once a read came back short - lets
+//! `snapmi_frame_decode_host` decode every complete chunk in it in one device
+//! call (header checks, raw decode, CRC, all in the reference's order) and
+//! keeps the cut-off tail for the next round.  Bytes of the chunks in front of
+//! a bad chunk are returned before the error (reference :111-118).
 use std::cmp;
 use std::fmt;
 use std::io::{self, Read};
@@ -13,7 +14,10 @@ use std::io::{self, Read};
 use crate::gpu::{self, Context, Failure, SnapmiError};
 use crate::MAX_BLOCK_SIZE;
 
+/// Most that one device call is handed.  Buffers start small and grow towards
+/// it only while the reader keeps them full.
 const BATCH: usize = 64 << 20;
+const FIRST: usize = 1 << 20;
 
 /// Decompresses a Snappy frame stream while it is read (reference :37-101).
 pub struct FrameDecoder<R: io::Read> {
@@ -41,9 +45,9 @@ impl<R: io::Read> FrameDecoder<R> {
         FrameDecoder {
             r: rdr,
             ctx: Context::new(),
-            src: vec![0; BATCH],
+            src: vec![0; FIRST],
             srce: 0,
-            dst: vec![0; 2 * BATCH],
+            dst: vec![0; 2 * FIRST],
             dsts: 0,
             dste: 0,
             pending: None,
@@ -69,14 +73,37 @@ impl<R: io::Read> FrameDecoder<R> {
     }
 
     /// One batch: read, decode the whole chunks, keep the tail.
+    ///
+    /// The reference reads one chunk per call (:105-172).  Batching must not
+    /// turn into waiting: one inner read at least, more only while the reader
+    /// fills what it is offered - a short read means it has no more right now
+    /// (a pipe, a socket, a peer that waits for our answer before it sends
+    /// on).  A read error leaves `src[..srce]` as it is: nothing is lost, the
+    /// next call carries on.
     fn fill(&mut self) -> io::Result<()> {
         loop {
+            let mut full = true;
             while self.srce < self.src.len() && !self.eof {
-                let n = self.r.read(&mut self.src[self.srce..])?;
+                let ask = self.src.len() - self.srce;
+                let n = match self.r.read(&mut self.src[self.srce..]) {
+                    Ok(n) => n,
+                    Err(ref e) if e.kind() == io::ErrorKind::Interrupted => continue,
+                    Err(e) => return Err(e),
+                };
                 if n == 0 {
                     self.eof = true;
                 }
                 self.srce += n;
+                if n < ask {
+                    full = false;
+                    break;
+                }
+            }
+            if full && !self.eof && self.src.len() < BATCH {
+                // the reader keeps up: a larger batch next time
+                let len = cmp::min(2 * self.src.len(), BATCH);
+                self.src.resize(len, 0);
+                self.dst.resize(2 * len, 0);
             }
             if self.srce == 0 {
                 return Ok(()); // clean end of the stream
@@ -178,6 +205,8 @@ pub struct FrameEncoder<R: io::Read> {
     dste: usize,
     eof: bool,
     wrote_stream_ident: bool,
+    /// A reader's error that follows the bytes in `dst`.
+    pending: Option<io::Error>,
 }
 
 impl<R: io::Read> FrameEncoder<R> {
@@ -193,6 +222,7 @@ impl<R: io::Read> FrameEncoder<R> {
             dste: 0,
             eof: false,
             wrote_stream_ident: false,
+            pending: None,
         }
     }
 
@@ -206,19 +236,41 @@ impl<R: io::Read> FrameEncoder<R> {
         &mut self.r
     }
 
+    /// Up to `BATCH` bytes of inner reads -> one device call.  A read that
+    /// fails does not lose the chunks gathered before it: they are compressed
+    /// and handed out, the error is returned by the read that follows them
+    /// (the reference does one inner read per outer read, :378, so an error
+    /// there loses nothing either).  A short read ends the batch.
     fn fill(&mut self) -> io::Result<()> {
         self.src.clear();
         self.lens.clear();
         while self.src.len() < BATCH {
             let at = self.src.len();
             self.src.resize(at + MAX_BLOCK_SIZE, 0);
-            let n = self.r.read(&mut self.src[at..])?;
+            let n = match self.r.read(&mut self.src[at..]) {
+                Ok(n) => n,
+                Err(ref e) if e.kind() == io::ErrorKind::Interrupted => {
+                    self.src.truncate(at);
+                    continue;
+                }
+                Err(e) => {
+                    self.src.truncate(at);
+                    if self.lens.is_empty() {
+                        return Err(e);
+                    }
+                    self.pending = Some(e);
+                    break;
+                }
+            };
             self.src.truncate(at + n);
             if n == 0 {
                 self.eof = true;
                 break;
             }
             self.lens.push(n as u32);
+            if n < MAX_BLOCK_SIZE {
+                break;
+            }
         }
         self.dsts = 0;
         self.dste = 0;
@@ -257,6 +309,9 @@ impl<R: io::Read> io::Read for FrameEncoder<R> {
                 buf[..len].copy_from_slice(&self.dst[self.dsts..self.dsts + len]);
                 self.dsts += len;
                 return Ok(len);
+            }
+            if let Some(err) = self.pending.take() {
+                return Err(err);
             }
             if self.eof {
                 return Ok(0);

@@ -459,6 +459,101 @@ def test_read_frame_encoder_chunks_follow_the_reads(ctx):
             assert bytes(out) == want, (step, batch)
 
 
+class Flaky(io.RawIOBase):
+    """A reader whose k-th read call fails (once) with `exc`; short reads of
+    `step` bytes otherwise."""
+
+    def __init__(self, data, step, fail_at, exc):
+        self.b, self.step, self.calls = io.BytesIO(data), step, 0
+        self.fail_at, self.exc = fail_at, exc
+
+    def read(self, n=-1):
+        self.calls += 1
+        if self.calls == self.fail_at:
+            raise self.exc
+        n = self.step if n is None or n < 0 else min(n, self.step)
+        return self.b.read(n)
+
+
+def test_adapters_lose_nothing_when_the_reader_fails(ctx):
+    """A read error in the middle of a batch (the reference makes one inner
+    read per outer read, src/read.rs:378, so an error there costs nothing):
+    what was read before it is compressed / decoded and handed out, the error
+    comes behind it, and a caller that retries gets the rest - no gap."""
+    from rust_snappy_amd import frame
+    data = (O.CORPUS / "lcet10.txt").read_bytes()
+    step = 65536
+    want = frame_of_chunks([data[o:o + step]
+                            for o in range(0, len(data), step)])
+    for fail_at, exc in ((3, OSError("wire trouble")),
+                         (2, InterruptedError())):
+        enc = frame.ReadFrameEncoder(Flaky(data, step, fail_at, exc), ctx)
+        out, errors = bytearray(), 0
+        while True:
+            try:
+                b = enc.read(50000)
+            except OSError:
+                errors += 1
+                continue                      # retry, like io::copy would
+            if not b:
+                break
+            out += b
+        assert bytes(out) == want
+        assert errors == (0 if isinstance(exc, InterruptedError) else 1)
+    # the decoder keeps what it has read when a later read fails
+    f = O.frame_compress(data)
+    dec = frame.FrameDecoder(Flaky(f, 30000, 4, OSError("again")), ctx)
+    out, errors = bytearray(), 0
+    while True:
+        try:
+            b = dec.read(100000)
+        except OSError:
+            errors += 1
+            continue
+        if not b:
+            break
+        out += b
+    assert bytes(out) == data and errors == 1
+
+
+class Turnstile(io.RawIOBase):
+    """A request/response peer: it hands out one piece per read and refuses
+    (the test fails) to be asked for the next piece before the consumer has
+    acknowledged the bytes of the previous one."""
+
+    def __init__(self, pieces):
+        self.pieces, self.i, self.allowed = pieces, 0, 1
+
+    def read(self, n=-1):
+        if self.i >= len(self.pieces):
+            return b""
+        assert self.i < self.allowed, "decoder waits for input it has no use for"
+        p = self.pieces[self.i]
+        assert len(p) <= n
+        self.i += 1
+        return p
+
+
+def test_frame_decoder_does_not_wait_for_a_full_batch(ctx):
+    """The reference returns after each chunk (src/read.rs:105-172).  A
+    batching decoder must decode as soon as a read came back short and the
+    buffer holds a whole chunk - on a pipe or a socket the peer may be waiting
+    for our answer before it sends the next chunk."""
+    from rust_snappy_amd import frame
+    msgs = [bytes([65 + i]) * (1000 + 37 * i) for i in range(5)]
+    pieces = []
+    for i, m in enumerate(msgs):
+        f = O.frame_compress(m)
+        pieces.append(f if i == 0 else f[10:])   # one stream, 5 chunks
+    peer = Turnstile(pieces)
+    dec = frame.FrameDecoder(peer, ctx)           # default 64 MiB batches
+    for i, m in enumerate(msgs):
+        got = dec.read(len(m))
+        assert got == m, i
+        peer.allowed = i + 2                      # "answer" received: send on
+    assert dec.read(10) == b""
+
+
 # ---------------------------------------------------------------------
 # src/read.rs:216: decompress_len over the reader's whole scratch buffer
 # ---------------------------------------------------------------------
