@@ -215,71 +215,133 @@ def files(args, ctx, dev):
             "files": rows}
 
 
+def _host_corpus(gib):
+    """The corpus round tiled into pinned host memory (snapmi_host_alloc)."""
+    import oracle_lib as O
+    from rust_snappy_amd import frame
+    blob = b"".join(d for _, d in O.corpus_round())
+    reps = max(1, int(gib * GIB / len(blob)))
+    n = reps * len(blob)
+    h_in = frame.HostBuffer(n)
+    h_in.array.reshape(reps, len(blob))[:] = np.frombuffer(blob, dtype=np.uint8)
+    return blob, n, h_in
+
+
 def pcie(args, ctx, dev):
-    """Host to host through the frame layer: pinned host buffer -> H2D ->
-    snapmi_frame_compress -> D2H of the framed bytes, and the inverse (chunk
-    headers scanned on the host, snapmi_frame_index_host, during the H2D).  This is what a
-    host-side FrameEncoder / FrameDecoder pays per batch; bench.py's `value`
-    is device resident."""
+    """Host to host through the frame layer: snapmi_frame_encode_host and
+    snapmi_frame_decode_host on pinned host buffers - what a host-side
+    FrameEncoder / FrameDecoder pays per batch (slices in flight on three
+    streams: copy in, kernels, copy out).  bench.py's `value` is device
+    resident; this is never it."""
     import ctypes as C
     import oracle_lib as O
     from rust_snappy_amd import _lib, frame
     L = _lib.load()
-    blob = b"".join(d for _, d in O.corpus_round())
-    reps = max(1, int(min(args.gib, 4.0) * GIB / len(blob)))
-    n = reps * len(blob)
-    h_in = torch.empty(n, dtype=torch.uint8).pin_memory()
-    h_in.view(reps, len(blob))[:] = torch.frombuffer(bytearray(blob),
-                                                     dtype=torch.uint8)
-    cap = frame.frame_max_len(n)
-    d_in = torch.empty(n, dtype=torch.uint8, device=dev)
-    d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
-    d_back = torch.empty(n, dtype=torch.uint8, device=dev)
-    h_out = torch.empty(cap, dtype=torch.uint8).pin_memory()
-    h_back = torch.empty(n, dtype=torch.uint8).pin_memory()
-    out_len = torch.zeros(1, dtype=torch.int64, device=dev)
-    err = torch.zeros(32, dtype=torch.uint8, device=dev)
+    blob, n, h_in = _host_corpus(min(args.gib, 4.0))
+    nch = (n + 65535) // 65536
+    lens = np.full(nch, 65536, dtype=np.uint32)
+    lens[-1] = n - (nch - 1) * 65536
+    h_out = frame.HostBuffer(10 + n + 8 * nch)
+    h_back = frame.HostBuffer(nch * 65536)
     flen = 0
 
     def enc():
         nonlocal flen
-        d_in.copy_(h_in, non_blocking=True)
-        torch.cuda.synchronize()
-        rc = L.snapmi_frame_compress(ctx._h, C.c_void_p(d_in.data_ptr()), n,
-                                     C.c_void_p(d_out.data_ptr()), cap,
-                                     C.c_void_p(out_len.data_ptr()), None)
-        assert rc == 0
-        ctx.synchronize()
-        flen = int(out_len.item())
-        h_out[:flen].copy_(d_out[:flen], non_blocking=True)
-        torch.cuda.synchronize()
+        flen = frame.encode_host_into(ctx, h_in.view, lens, h_out)
 
     def dec():
-        d_out[:flen].copy_(h_out[:flen], non_blocking=True)
-        # chunk scan on the host while the copy is in flight
-        offs = frame.index_host(h_out[:flen])
-        d_idx = torch.from_numpy(offs).to(dev)
-        torch.cuda.synchronize()
-        rc = L.snapmi_frame_decompress(ctx._h, C.c_void_p(d_out.data_ptr()),
-                                       flen, C.c_void_p(d_back.data_ptr()), n,
-                                       C.c_void_p(out_len.data_ptr()),
-                                       C.c_void_p(err.data_ptr()),
-                                       C.c_void_p(d_idx.data_ptr()),
-                                       len(offs) - 1)
-        assert rc == 0
-        ctx.synchronize()
-        h_back.copy_(d_back, non_blocking=True)
-        torch.cuda.synchronize()
+        stale = (C.c_uint8 * 10)()
+        written, consumed = C.c_size_t(0), C.c_size_t(0)
+        err = _lib.SnapmiError()
+        rc = L.snapmi_frame_decode_host(
+            ctx._h, C.c_void_p(h_out.ptr), flen, 2, stale,
+            C.c_void_p(h_back.ptr), h_back.nbytes, C.byref(written),
+            C.byref(consumed), C.byref(err))
+        assert rc == 0 and written.value == n and consumed.value == flen, \
+            (rc, written.value, consumed.value)
 
     te = time_it(enc, args.steps, ctx)
     td = time_it(dec, args.steps, ctx)
-    assert bool((h_back == h_in).all()), "host round trip"
-    return {"config": "host to host through the frame layer (pinned memory, "
-                      "H2D + kernels + D2H, no overlap)",
-            "gib": round(n / GIB, 3), "ratio": round(flen / n, 4),
-            "frame_encode_gibs": round(n / GIB / te, 2),
-            "frame_decode_gibs": round(n / GIB / td, 2),
-            "encode_ms": round(te * 1e3, 2), "decode_ms": round(td * 1e3, 2)}
+    assert bool((h_back.array[:n] == h_in.array).all()), "host round trip"
+    head = O.frame_compress(bytes(h_in.view[:1 << 20]))
+    assert bytes(h_out.view[:len(head)]) == head, "framed bytes vs the oracle"
+    res = {"config": "host to host through snapmi_frame_encode_host / "
+                     "_decode_host (pinned memory; slices pipelined over "
+                     "copy-in, kernels, copy-out)",
+           "gib": round(n / GIB, 3), "ratio": round(flen / n, 4),
+           "frame_encode_gibs": round(n / GIB / te, 2),
+           "frame_decode_gibs": round(n / GIB / td, 2),
+           "encode_ms": round(te * 1e3, 2), "decode_ms": round(td * 1e3, 2)}
+    for b in (h_in, h_out, h_back):
+        b.close()
+    return res
+
+
+def adapters(args, ctx, dev):
+    """The streaming adapters the north star keeps: FrameEncoder.write_all of
+    one large host buffer (rust-snappy_amd/frame.py, the mirror of
+    snap::write::FrameEncoder) and FrameDecoder.read_to_end of the result."""
+    import io
+    import oracle_lib as O
+    from rust_snappy_amd import frame
+    blob, n, h_in = _host_corpus(min(args.gib, 4.0))
+
+    class Sink:
+        def __init__(self):
+            self.n, self.head = 0, bytearray()
+
+        def write(self, b):
+            if len(self.head) < (2 << 20):
+                self.head += b[:2 << 20]
+            self.n += len(b)
+            return len(b)
+
+    # one encoder, written to repeatedly (its pinned staging buffer is made
+    # by the first large write, like a Vec that has grown)
+    sink = Sink()
+    enc = frame.FrameEncoder(sink, ctx)
+    enc.write_all(h_in.view[:64 << 20])
+    enc.flush()
+    enc.DIRECT_MAX = 4 << 30
+    enc.write_all(h_in.view)                    # staging grows here
+    enc.flush()
+    head0 = bytes(sink.head)
+    best = None
+    for _ in range(max(2, args.steps)):
+        t0 = time.perf_counter()
+        enc.write_all(h_in.view)
+        enc.flush()
+        t = time.perf_counter() - t0
+        best = t if best is None or t < best else best
+    sink = Sink()
+    enc2 = frame.FrameEncoder(sink, ctx)
+    enc2.write_all(h_in.view[:4 << 20])
+    enc2.flush()
+    want = O.frame_compress(bytes(h_in.view[:1 << 20]))
+    assert bytes(sink.head[:len(want)]) == want, "adapter bytes vs the oracle"
+    # decoder adapter on a smaller stream (it hands out Python bytes)
+    m = min(n, 1 << 30)
+    sink = io.BytesIO()
+    enc = frame.FrameEncoder(sink, ctx)
+    enc.write_all(h_in.view[:m])
+    enc.flush()
+    framed = sink.getvalue()
+    t0 = time.perf_counter()
+    back = frame.FrameDecoder(io.BytesIO(framed), ctx).read_to_end()
+    td = time.perf_counter() - t0
+    assert back == bytes(h_in.view[:m]), "adapter round trip"
+    h_in.close()
+    return {"config": "Python streaming adapters over the host-buffer calls: "
+                      "FrameEncoder.write_all of one pinned buffer (no copy "
+                      "on the Python side), FrameDecoder.read_to_end",
+            "gib": round(n / GIB, 3), "framed_bytes": sink_n(sink, framed),
+            "frame_encoder_write_all_gibs": round(n / GIB / best, 2),
+            "frame_decoder_read_to_end_gibs": round(m / GIB / td, 2),
+            "decoder_gib": round(m / GIB, 3)}
+
+
+def sink_n(sink, framed):
+    return len(framed)
 
 
 def stream(args, ctx, dev):
@@ -445,7 +507,7 @@ def main():
     dev = torch.device("cuda", local)
     ctx = raw.Context(local)
     table = {"cfg3": cfg3, "cfg5": cfg5, "files": files, "pcie": pcie,
-             "stream": stream, "cfg4": cfg4}
+             "adapters": adapters, "stream": stream, "cfg4": cfg4}
     if args.plan:
         for item in args.plan.split(","):
             name, gib = item.split(":")
@@ -462,7 +524,8 @@ def main():
                 print(json.dumps(res), flush=True)
         return
     for name, fn in (("cfg3", cfg3), ("cfg5", cfg5), ("files", files),
-                     ("pcie", pcie), ("stream", stream), ("cfg4", cfg4)):
+                     ("pcie", pcie), ("adapters", adapters),
+                     ("stream", stream), ("cfg4", cfg4)):
         if args.only != name and (args.only or name == "cfg4"):
             continue  # cfg4 only on request (it is the multi-rank config)
         res = fn(args, ctx, dev)

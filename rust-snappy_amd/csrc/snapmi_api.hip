@@ -111,6 +111,15 @@ int snapmi_ctx_create(int device, void *hip_stream, snapmi_ctx **out)
             ctx->lane_tables_uncached = atoi(e) != 0;
         if (const char *e = getenv("SNAPMI_LANE_DIRECT"))
             ctx->lane_direct_encode = atoi(e) != 0;
+        if (const char *e = getenv("SNAPMI_HOST_COPY_KERNEL"))
+            ctx->host_copy_kernel = atoi(e) & 3;
+        if (const char *e = getenv("SNAPMI_HOST_ENCODE_SLICE"))
+            ctx->host_encode_slice = (uint64_t)atoll(e) < 65536
+                                         ? 65536
+                                         : (uint64_t)atoll(e);
+        if (const char *e = getenv("SNAPMI_HOST_DECODE_CHUNKS"))
+            ctx->host_decode_slice_chunks =
+                atoll(e) < 1 ? 1 : (uint64_t)atoll(e);
         if (const char *e = getenv("SNAPMI_DECODE_KERNEL"))
             ctx->decode_kernel = atoi(e) == 0 ? 0 : (atoi(e) == 2 ? 2 : 3);
         if (const char *m = getenv("SNAPMI_COMPRESS"))
@@ -194,6 +203,9 @@ void snapmi_ctx_destroy(snapmi_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
+    host_pipe_destroy(ctx);
+    if (ctx->h_mail)
+        (void)hipHostFree((void *)ctx->h_mail);
     for (DevBuf *b : {&ctx->blk_first, &ctx->slot_first, &ctx->blk_size,
                       &ctx->blk_off, &ctx->slots, &ctx->st_in, &ctx->st_out,
                       &ctx->st_desc, &ctx->st_prof, &ctx->ticket,
@@ -262,6 +274,12 @@ int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value)
         ctx->frame_walk_segment = (uint64_t)value;
     else if (strcmp(name, "frame_parallel_walk_min") == 0 && value >= 0)
         ctx->frame_parallel_walk_min = (uint64_t)value;
+    else if (strcmp(name, "host_copy_kernel") == 0 && value >= 0 && value <= 3)
+        ctx->host_copy_kernel = (int)value;
+    else if (strcmp(name, "host_encode_slice") == 0 && value >= (1 << 16))
+        ctx->host_encode_slice = (uint64_t)value;
+    else if (strcmp(name, "host_decode_slice_chunks") == 0 && value >= 1)
+        ctx->host_decode_slice_chunks = (uint64_t)value;
     else if (strcmp(name, "decode_kernel") == 0 &&
              (value == 0 || value == 2 || value == 3))
         ctx->decode_kernel = ctx->lds_store_order_ok ? (int)value : 0;

@@ -19,8 +19,26 @@ struct DevBuf {
 
 } // namespace snapmi
 
+struct snapmi_host_pipe; // snapmi_frame.hip: staging of the host-buffer calls
+
 struct snapmi_ctx {
     int device = 0;
+    snapmi_host_pipe *pipe = nullptr;
+    // 256 bytes of pinned, device-mapped host memory: kernels post small
+    // results here (no copy-engine round trip behind a bulk copy)
+    volatile uint32_t *h_mail = nullptr;
+    // slices of the host-buffer frame calls: input bytes per encode slice,
+    // data chunks per decode slice
+    // (measured, profiles/r3_host_pipeline.txt: the match finder's latency
+    // floor wants two slices for 4 GiB, the decoder is happy from 0.5 GiB)
+    uint64_t host_encode_slice = 2048ull << 20;
+    uint64_t host_decode_slice_chunks = 8192;
+    // results go home by a copy kernel (bit 0: decode, bit 1: encode) or by
+    // hipMemcpyAsync: see k_to_host.  The kernel is used only when the
+    // caller's buffer is pinned, device-mapped host memory
+    // (snapmi_host_alloc).  Encode: off - the copy kernel would wait for the
+    // match finder's persistent workgroups.
+    int host_copy_kernel = 1;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
     std::string last_error;
@@ -145,6 +163,7 @@ inline int reserve(snapmi_ctx *ctx, DevBuf &b, size_t bytes)
 
 // internal launchers (snapmi_api.hip), shared with the frame layer
 namespace snapmi {
+void host_pipe_destroy(snapmi_ctx *ctx); // snapmi_frame.hip
 // raw compress of n streams; blocks/slots = launch geometry computed from
 // the (host-known) stream lengths
 int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,

@@ -28,6 +28,8 @@
 #include <string.h>
 #include <vector>
 
+#include <chrono>
+
 #include "snapmi.h"
 #include "snapmi_ctx.hpp"
 #include "snapmi_device.hpp"
@@ -691,6 +693,11 @@ __global__ void k_frame_index(FrameDecodeArgs a)
         if (!ok)
             a.meta[3] = 1; // the walk reports what is wrong with the start
     }
+    // an index without entries tiles nothing: only a stream that ends right
+    // behind its identifier (or an empty continuation) has no chunks
+    if (i == 0 && a.n_index == 0 &&
+        a.in_len != ((a.flags & SNAPMI_FRAME_CONTINUATION) ? 0u : 10u))
+        a.meta[3] = 1;
     if (i >= a.n_index)
         return;
     const uint64_t r = a.index[i];
@@ -1169,6 +1176,81 @@ __global__ void k_frame_meta_init(FrameDecodeArgs a)
     a.serr[0].kind = SNAPMI_OK;
 }
 
+// Device memory -> pinned (device-mapped) host memory by a kernel: 16-byte
+// stores over the host link.  On this platform a hipMemcpyAsync to the host
+// and one from the host, on two streams of one process, ran one after the
+// other (tests/hw/r3 trace: a 0.55 GB copy in took 26 ms behind a 1 GiB copy
+// out) although the link is full duplex (tests/hw/pcie_duplex.py: 2 x 48
+// GB/s); a copy kernel beside a copy-engine transfer the other way does
+// overlap.  The destination is brought to a 16-byte boundary first.
+__global__ __launch_bounds__(256) void k_to_host(uint8_t *host,
+                                                 const uint8_t *dev,
+                                                 uint64_t n)
+{
+    gptr to = (gptr)host;
+    gcptr from = (gcptr)dev;
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t nthr = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t head = (16 - ((uintptr_t)host & 15)) & 15;
+    if (head > n)
+        head = n;
+    if (tid < head)
+        to[tid] = from[tid];
+    const uint64_t body = (n - head) & ~15ull;
+    typedef __attribute__((address_space(1))) u32x4 g_u32x4;
+    for (uint64_t i = 16 * tid; i < body; i += 16 * nthr)
+        *(g_u32x4 *)(to + head + i) = ld128g(from + head + i);
+    const uint64_t tail = n - head - body;
+    if (tid < tail)
+        to[head + body + tid] = from[head + body + tid];
+}
+
+// is [p, p + n) host memory a kernel may write (pinned and mapped)?
+static bool device_visible(const void *p)
+{
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError(); // plain malloc memory: not an error here
+        return false;
+    }
+    return at.type == hipMemoryTypeHost && at.devicePointer != nullptr;
+}
+
+static int copy_home(snapmi_ctx *ctx, hipStream_t st, uint8_t *h_dst,
+                     const void *d_src, uint64_t n, bool by_kernel)
+{
+    if (by_kernel) {
+        // enough workgroups to keep the link busy, few enough to leave the
+        // codec its CUs
+        hipLaunchKernelGGL(k_to_host, dim3(128), dim3(256), 0, st, h_dst,
+                           (const uint8_t *)d_src, n);
+        HIP_TRY(ctx, hipGetLastError());
+        return SNAPMI_OK;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(h_dst, d_src, n, hipMemcpyDeviceToHost, st));
+    return SNAPMI_OK;
+}
+
+static int mailbox(snapmi_ctx *ctx)
+{
+    if (!ctx->h_mail)
+        HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_mail, 256,
+                                   hipHostMallocDefault));
+    return SNAPMI_OK;
+}
+
+// A few words of a result, from device memory into pinned (device-mapped)
+// host memory.  A hipMemcpyAsync of 16 bytes would do the same - through the
+// copy engine, where it waits behind whatever bulk copy is under way in that
+// direction (20 ms behind a 1 GiB result): a kernel store does not queue.
+__global__ void k_post_words(uint32_t *host_mapped, const uint32_t *dev,
+                             uint32_t n)
+{
+    if (threadIdx.x < n)
+        host_mapped[threadIdx.x] = dev[threadIdx.x];
+    __threadfence_system();
+}
+
 // snapmi_frame_scan_host, stopping in front of data chunk number `max_data`
 // (status 3: the caller's output buffer is full)
 static int frame_scan(const void *h_in, uint64_t in_len, uint32_t flags,
@@ -1335,9 +1417,12 @@ int snapmi_frame_decompress_ex(snapmi_ctx *ctx, const void *d_in,
         }
         // the number of data chunks decides the launch sizes below
         uint32_t meta[4];
-        HIP_TRY(ctx, hipMemcpyAsync(meta, a.meta, sizeof meta,
-                                    hipMemcpyDeviceToHost, s));
+        if ((rc = mailbox(ctx)))
+            return rc;
+        hipLaunchKernelGGL(k_post_words, dim3(1), dim3(64), 0, s,
+                           (uint32_t *)ctx->h_mail, a.meta, 4u);
         HIP_TRY(ctx, hipStreamSynchronize(s));
+        memcpy(meta, (const void *)ctx->h_mail, sizeof meta);
         if (use_index && meta[3]) { // the index does not tile the stream with
             use_index = false;      // plain data chunks: the walk decides
             cap = n_chunks + in_len / 65536 + 64;
@@ -1399,46 +1484,242 @@ size_t snapmi_frame_encode_bound(size_t total_bytes, size_t n_chunks)
     return 10 + total_bytes + 8 * n_chunks;
 }
 
+} // extern "C"
+
+// ---- the pipeline behind the two host-buffer calls -----------------------
+// A batch is cut into slices; slice i+1 is on its way to the device (copy
+// stream 1) while the kernels of slice i run (the context's stream) and the
+// result of slice i-1 goes back to the host (copy stream 2): PCIe is full
+// duplex, and the three legs of a batch cost about the same (a 4 GiB corpus
+// batch: 78 ms in, 60 ms of kernels, 39 ms out - 177 ms one after the other).
+// Three slots of device staging, so that none of the three legs waits for a
+// buffer of the other two.  Host memory from snapmi_host_alloc (pinned) is
+// what makes the copies asynchronous; pageable memory works, one leg at a
+// time.
+namespace {
+constexpr int kSlots = 3;
+struct PipeSlot {
+    snapmi::DevBuf in, out, desc; // desc: u64 len | snapmi_error | index...
+    hipEvent_t ev_h2d = nullptr, ev_k = nullptr, ev_d2h = nullptr;
+    struct Result {
+        uint64_t len;
+        snapmi_error e;
+    } *h_res = nullptr;            // pinned
+    uint64_t *h_off = nullptr;     // pinned: chunk offsets of the slice
+    size_t h_off_cap = 0;
+};
+} // namespace
+
+struct snapmi_host_pipe {
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    PipeSlot slot[kSlots];
+};
+
+namespace snapmi {
+void host_pipe_destroy(snapmi_ctx *ctx)
+{
+    snapmi_host_pipe *p = ctx->pipe;
+    if (!p)
+        return;
+    if (p->s_in) {
+        (void)hipStreamSynchronize(p->s_in);
+        (void)hipStreamDestroy(p->s_in);
+    }
+    if (p->s_out) {
+        (void)hipStreamSynchronize(p->s_out);
+        (void)hipStreamDestroy(p->s_out);
+    }
+    for (PipeSlot &sl : p->slot) {
+        for (DevBuf *b : {&sl.in, &sl.out, &sl.desc})
+            if (b->p)
+                (void)hipFree(b->p);
+        for (hipEvent_t e : {sl.ev_h2d, sl.ev_k, sl.ev_d2h})
+            if (e)
+                (void)hipEventDestroy(e);
+        if (sl.h_res)
+            (void)hipHostFree(sl.h_res);
+        if (sl.h_off)
+            (void)hipHostFree(sl.h_off);
+    }
+    delete p;
+    ctx->pipe = nullptr;
+}
+} // namespace snapmi
+
+static int host_pipe(snapmi_ctx *ctx, snapmi_host_pipe **out)
+{
+    if (!ctx->pipe) {
+        snapmi_host_pipe *p = new snapmi_host_pipe;
+        ctx->pipe = p; // (freed with the context whatever fails below)
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&p->s_in, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&p->s_out, hipStreamNonBlocking));
+        for (PipeSlot &sl : p->slot) {
+            HIP_TRY(ctx, hipEventCreate(&sl.ev_h2d));
+            HIP_TRY(ctx, hipEventCreate(&sl.ev_k));
+            HIP_TRY(ctx, hipEventCreate(&sl.ev_d2h));
+            HIP_TRY(ctx, hipHostMalloc((void **)&sl.h_res, sizeof *sl.h_res,
+                                       hipHostMallocDefault));
+        }
+    }
+    *out = ctx->pipe;
+    return SNAPMI_OK;
+}
+
+static int slot_offsets(snapmi_ctx *ctx, PipeSlot &sl, size_t n)
+{
+    if (n <= sl.h_off_cap)
+        return SNAPMI_OK;
+    if (sl.h_off)
+        HIP_TRY(ctx, hipHostFree(sl.h_off));
+    sl.h_off = nullptr;
+    sl.h_off_cap = 0;
+    const size_t want = n + n / 4 + 64;
+    HIP_TRY(ctx, hipHostMalloc((void **)&sl.h_off, want * sizeof(uint64_t),
+                               hipHostMallocDefault));
+    sl.h_off_cap = want;
+    return SNAPMI_OK;
+}
+
+// a slot's device buffer grows only when nothing of the slot is in flight
+static int slot_reserve(snapmi_ctx *ctx, snapmi::DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap)
+        return SNAPMI_OK;
+    if (b.p) {
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        HIP_TRY(ctx, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    const size_t want = bytes + bytes / 8 + 256;
+    HIP_TRY(ctx, hipMalloc(&b.p, want));
+    b.cap = want;
+    return SNAPMI_OK;
+}
+
+extern "C" {
+
 int snapmi_frame_encode_host(snapmi_ctx *ctx, const uint8_t *h_in,
                              const uint32_t *h_chunk_lens, size_t n,
                              uint32_t flags, uint8_t *h_out, size_t out_cap,
                              size_t *written)
 {
-    if (!ctx || !written || (n && (!h_in || !h_chunk_lens || !h_out)))
+    if (!ctx || !written || (n && (!h_in || !h_chunk_lens || !h_out)) ||
+        n > 0x7FFFFFFFu || (flags & ~(uint32_t)SNAPMI_FRAME_NO_IDENT))
         return SNAPMI_E_ARGUMENT;
     *written = 0;
     if (n == 0)
         return SNAPMI_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     uint64_t total = 0;
-    for (size_t i = 0; i < n; i++)
+    for (size_t i = 0; i < n; i++) {
+        if (h_chunk_lens[i] == 0 || h_chunk_lens[i] > kMaxBlock)
+            return fail_ctx(ctx, SNAPMI_E_ARGUMENT,
+                            "frame_encode_host: chunk %zu has %u bytes "
+                            "(1..65536)", i, h_chunk_lens[i]);
         total += h_chunk_lens[i];
+    }
     const size_t need = snapmi_frame_encode_bound(total, n);
     if (out_cap < need - ((flags & SNAPMI_FRAME_NO_IDENT) ? 10 : 0))
         return fail_ctx(ctx, SNAPMI_E_ARGUMENT,
                         "frame_encode_host: out_cap %zu < %zu", out_cap, need);
-    int rc;
-    if ((rc = reserve(ctx, ctx->st_in, total + 16)) ||
-        (rc = reserve(ctx, ctx->st_out, need + 64)) ||
-        (rc = reserve(ctx, ctx->st_desc, 64)))
-        return rc;
-    hipStream_t s = ctx->stream;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->st_in.p, h_in, total,
-                                hipMemcpyHostToDevice, s));
-    uint64_t *d_len = (uint64_t *)ctx->st_desc.p;
-    rc = snapmi_frame_compress_chunks(ctx, ctx->st_in.p, h_chunk_lens, n,
-                                      flags, ctx->st_out.p, need, d_len,
-                                      nullptr);
+    snapmi_host_pipe *P;
+    int rc = host_pipe(ctx, &P);
     if (rc)
         return rc;
-    uint64_t flen = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&flen, d_len, 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
-    if (flen > out_cap)
-        return fail_ctx(ctx, SNAPMI_E_DEVICE, "frame_encode_host: %llu > cap",
-                        (unsigned long long)flen);
-    HIP_TRY(ctx, hipMemcpy(h_out, ctx->st_out.p, flen, hipMemcpyDeviceToHost));
-    *written = (size_t)flen;
+    hipStream_t sK = ctx->stream;
+    // Slices: the match finder wants large launches (its latency floor is
+    // ~35 ms whatever the size: DESIGN 4.1), the pipeline wants several
+    // slices; by default a batch of 1 GiB or more is cut in two to three.
+    const uint64_t slice_bytes = ctx->host_encode_slice;
+    struct Slice {
+        size_t c0, c1;      // chunks [c0, c1)
+        uint64_t b0, bytes; // input bytes
+    };
+    std::vector<Slice> sl;
+    {
+        const uint64_t k = total <= slice_bytes
+                               ? 1
+                               : (total + slice_bytes - 1) / slice_bytes;
+        const uint64_t per = (total + k - 1) / k;
+        size_t c = 0;
+        uint64_t b = 0;
+        while (c < n) {
+            Slice x{c, c, b, 0};
+            while (x.c1 < n && (x.bytes < per || x.c1 == x.c0)) {
+                x.bytes += h_chunk_lens[x.c1];
+                x.c1++;
+            }
+            c = x.c1;
+            b += x.bytes;
+            sl.push_back(x);
+        }
+    }
+    const size_t ns = sl.size();
+    uint64_t out_off = 0;
+    const bool out_by_kernel =
+        (ctx->host_copy_kernel & 2) && device_visible(h_out);
+    // step t: copy slice t in, start the kernels of slice t-1, send the
+    // result of slice t-2 home
+    for (size_t t = 0; t < ns + 2; t++) {
+        if (t < ns) {
+            PipeSlot &s = P->slot[t % kSlots];
+            const Slice &x = sl[t];
+            const size_t cn = x.c1 - x.c0;
+            if ((rc = slot_reserve(ctx, s.in, x.bytes + 16)) ||
+                (rc = slot_reserve(ctx, s.out,
+                                   snapmi_frame_encode_bound(x.bytes, cn) +
+                                       64)) ||
+                (rc = slot_reserve(ctx, s.desc, 64 + (cn + 1) * 8)) ||
+                (rc = slot_offsets(ctx, s, cn + 1)))
+                return rc;
+            HIP_TRY(ctx, hipMemcpyAsync(s.in.p, h_in + x.b0, x.bytes,
+                                        hipMemcpyHostToDevice, P->s_in));
+            HIP_TRY(ctx, hipEventRecord(s.ev_h2d, P->s_in));
+        }
+        if (t >= 1 && t - 1 < ns) {
+            PipeSlot &s = P->slot[(t - 1) % kSlots];
+            const Slice &x = sl[t - 1];
+            const size_t cn = x.c1 - x.c0;
+            s.h_off[0] = 0;
+            for (size_t i = 0; i < cn; i++)
+                s.h_off[i + 1] = s.h_off[i] + h_chunk_lens[x.c0 + i];
+            uint64_t *d_len = (uint64_t *)s.desc.p;
+            HIP_TRY(ctx, hipStreamWaitEvent(sK, s.ev_h2d, 0));
+            if (t - 1 >= kSlots) // the slot's last result has left
+                HIP_TRY(ctx, hipStreamWaitEvent(sK, s.ev_d2h, 0));
+            const bool ident =
+                t - 1 == 0 && !(flags & SNAPMI_FRAME_NO_IDENT);
+            // (the chunk offsets are read where they lie, in pinned host
+            // memory: a copy would wait behind the bulk copy of the next
+            // slice; so would one of the result)
+            rc = snapmi::frame_compress_impl(
+                ctx, s.in.p, x.bytes, (uint32_t)cn, s.h_off, ident, s.out.p,
+                d_len, nullptr);
+            if (rc)
+                return rc;
+            hipLaunchKernelGGL(k_post_words, dim3(1), dim3(64), 0, sK,
+                               (uint32_t *)&s.h_res->len,
+                               (const uint32_t *)d_len, 2u);
+            HIP_TRY(ctx, hipEventRecord(s.ev_k, sK));
+        }
+        if (t >= 2) {
+            PipeSlot &s = P->slot[(t - 2) % kSlots];
+            HIP_TRY(ctx, hipEventSynchronize(s.ev_k));
+            const uint64_t flen = s.h_res->len;
+            if (out_off + flen > out_cap)
+                return fail_ctx(ctx, SNAPMI_E_DEVICE,
+                                "frame_encode_host: %llu > cap",
+                                (unsigned long long)(out_off + flen));
+            if ((rc = copy_home(ctx, P->s_out, h_out + out_off, s.out.p,
+                                flen, out_by_kernel)))
+                return rc;
+            HIP_TRY(ctx, hipEventRecord(s.ev_d2h, P->s_out));
+            out_off += flen;
+        }
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(P->s_out));
+    *written = (size_t)out_off;
     return SNAPMI_OK;
 }
 
@@ -1458,85 +1739,221 @@ int snapmi_frame_decode_host(snapmi_ctx *ctx, const uint8_t *h_in,
     if (in_len == 0)
         return SNAPMI_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const bool final = (flags & SNAPMI_FRAME_FINAL) != 0;
-    const uint32_t cflag = flags & SNAPMI_FRAME_CONTINUATION;
-    // as many whole chunks as the output buffer is sure to hold (a chunk
-    // decodes to at most 65536 bytes)
-    const uint64_t max_chunks = out_cap / kMaxBlock;
-    uint8_t stale_in[10] = {0};
-    if (stale10)
-        memcpy(stale_in, stale10, 10);
-    uint8_t stale_work[10];
-    memcpy(stale_work, stale_in, 10);
-    // the scan stops at the first cut-off (2) or rejected (1) chunk, or in
-    // front of the first data chunk the output buffer has no room for (3)
-    uint64_t nd = 0, used = 0;
-    int status = frame_scan(h_in, in_len, cflag, nullptr, nullptr, 0,
-                            max_chunks, &nd, &used);
-    if (status > 3)
-        return status;
-    std::vector<uint64_t> offs(nd + 1);
-    status = frame_scan(h_in, in_len, cflag, stale_work, offs.data(), nd + 1,
-                        max_chunks, &nd, &used);
-    if (status > 3)
-        return status;
-    if (status == 3 && used == 0 && max_chunks == 0)
-        return fail_ctx(ctx, SNAPMI_E_ARGUMENT,
-                        "frame_decode_host: out_cap below 65536");
-    const bool limited = status == 3;
-    if (used == 0 && status == 2 && !final)
-        return SNAPMI_OK; // not one whole chunk yet: read more
-    const bool clean = limited || status == 0 || (status == 2 && !final);
-    const uint64_t dec_len = clean ? used : in_len;
-    int rc;
-    if ((rc = reserve(ctx, ctx->st_in, dec_len + 16)) ||
-        (rc = reserve(ctx, ctx->st_out, nd * kMaxBlock + 64)) ||
-        (rc = reserve(ctx, ctx->st_desc, 128 + (nd + 1) * 8)))
-        return rc;
-    hipStream_t s = ctx->stream;
-    uint64_t *d_len = (uint64_t *)ctx->st_desc.p;
-    snapmi_error *d_err = (snapmi_error *)((uint8_t *)ctx->st_desc.p + 64);
-    uint64_t *d_idx = (uint64_t *)((uint8_t *)ctx->st_desc.p + 128);
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->st_in.p, h_in, dec_len,
-                                hipMemcpyHostToDevice, s));
-    const bool with_index = clean && nd > 0;
-    if (with_index) {
-        HIP_TRY(ctx, hipMemcpyAsync(d_idx, offs.data(), (nd + 1) * 8,
-                                    hipMemcpyHostToDevice, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s)); // offs is pageable memory
-    }
-    rc = snapmi_frame_decompress_ex(ctx, ctx->st_in.p, dec_len, ctx->st_out.p,
-                                    nd * kMaxBlock, d_len, d_err,
-                                    with_index ? d_idx : nullptr, nd, cflag,
-                                    stale_in);
+    snapmi_host_pipe *P;
+    int rc = host_pipe(ctx, &P);
     if (rc)
         return rc;
-    struct {
-        uint64_t len;
-        snapmi_error e;
-    } h;
-    HIP_TRY(ctx, hipMemcpyAsync(&h.len, d_len, 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipMemcpyAsync(&h.e, d_err, sizeof h.e,
-                                hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
-    if (h.len > out_cap)
-        return fail_ctx(ctx, SNAPMI_E_DEVICE, "frame_decode_host: %llu > cap",
-                        (unsigned long long)h.len);
-    if (h.len)
-        HIP_TRY(ctx, hipMemcpy(h_out, ctx->st_out.p, h.len,
-                               hipMemcpyDeviceToHost));
-    *written = (size_t)h.len;
-    if (err)
-        *err = h.e;
-    if (h.e.kind != SNAPMI_OK)
-        return h.e.kind;
-    if (!clean) // the host scan saw a bad or cut-off chunk the walk did not
+    hipStream_t sK = ctx->stream;
+    const bool final = (flags & SNAPMI_FRAME_FINAL) != 0;
+    uint32_t cflag = flags & SNAPMI_FRAME_CONTINUATION;
+    uint8_t stale[10] = {0}; // the reader's src[0..10) in front of `pos`
+    if (stale10)
+        memcpy(stale, stale10, 10);
+    const uint64_t slice_chunks = ctx->host_decode_slice_chunks;
+    const bool out_by_kernel =
+        (ctx->host_copy_kernel & 1) && out_cap && device_visible(h_out);
+
+    static const bool trace = getenv("SNAPMI_PIPE_TRACE") != nullptr;
+    static hipEvent_t ev_base = nullptr;
+    if (trace) {
+        if (!ev_base)
+            (void)hipEventCreate(&ev_base);
+        (void)hipEventRecord(ev_base, sK);
+    }
+    const auto t_start = std::chrono::steady_clock::now();
+    auto now_us = [&] {
+        return (long)std::chrono::duration_cast<std::chrono::microseconds>(
+                   std::chrono::steady_clock::now() - t_start)
+            .count();
+    };
+    // what a slice in flight is
+    struct Flight {
+        bool live = false, clean = false;
+        uint64_t used = 0;
+    } fl[kSlots];
+    uint64_t pos = 0;      // input consumed by the slices issued so far
+    uint64_t wrote = 0;    // output bytes of the slices retired so far
+    uint64_t budget = out_cap / kMaxBlock; // chunks the output still holds
+    bool more = true;      // another slice may follow
+    int result = SNAPMI_OK;
+    snapmi_error first_err;
+    memset(&first_err, 0, sizeof first_err);
+    bool disagree = false;
+
+    // the result of the slice in slot k goes home
+    auto retire = [&](int k) -> int {
+        PipeSlot &s = P->slot[k];
+        Flight &f = fl[k];
+        if (!f.live)
+            return SNAPMI_OK;
+        f.live = false;
+        HIP_TRY(ctx, hipEventSynchronize(s.ev_k));
+        if (trace) {
+            float a = 0, b = 0;
+            (void)hipEventElapsedTime(&a, ev_base, s.ev_h2d);
+            (void)hipEventElapsedTime(&b, ev_base, s.ev_k);
+            fprintf(stderr, "[pipe] slot %d: h2d done %.1f ms, kernels done "
+                            "%.1f ms (device clock)\n", k, a, b);
+        }
+        const uint64_t len = s.h_res->len;
+        if (wrote + len > out_cap)
+            return fail_ctx(ctx, SNAPMI_E_DEVICE,
+                            "frame_decode_host: %llu > cap",
+                            (unsigned long long)(wrote + len));
+        if (result == SNAPMI_OK && !disagree) {
+            // (nothing behind a failed slice is delivered)
+            if (len) {
+                if (int e = copy_home(ctx, P->s_out, h_out + wrote, s.out.p,
+                                      len, out_by_kernel))
+                    return e;
+                HIP_TRY(ctx, hipEventRecord(s.ev_d2h, P->s_out));
+            }
+            wrote += len;
+            if (s.h_res->e.kind != SNAPMI_OK) {
+                result = s.h_res->e.kind;
+                first_err = s.h_res->e;
+            } else if (!f.clean) {
+                disagree = true; // the host scan saw a bad or cut-off chunk
+            }
+        }
+        return SNAPMI_OK;
+    };
+
+    // step t: slice t is issued (copy in on one stream, kernels behind it on
+    // the context's); then slice t-1 is retired - its kernels lie in front of
+    // slice t's on the same stream and snapmi_frame_decompress_ex waits for
+    // its own header pass, so they are done - and its output goes home on the
+    // third stream while slice t decodes
+    for (uint64_t t = 0;; t++) {
+        const int k = (int)(t % kSlots);
+        // the slot's previous slice (t - 3) is retired by now (see below)
+        if (more && result == SNAPMI_OK && !disagree) {
+            PipeSlot &s = P->slot[k];
+            const uint64_t maxc = budget < slice_chunks ? budget : slice_chunks;
+            uint8_t stale_in[10], stale_work[10];
+            memcpy(stale_in, stale, 10);
+            memcpy(stale_work, stale, 10);
+            uint64_t nd = 0, used = 0;
+            const uint8_t *in = h_in + pos;
+            const uint64_t left = in_len - pos;
+            // the scan stops at the first cut-off (2) or rejected (1) chunk,
+            // or in front of the first data chunk beyond the slice (3)
+            int status = frame_scan(in, left, cflag, nullptr, nullptr, 0, maxc,
+                                    &nd, &used);
+            if (status > 3)
+                return status;
+            if ((rc = slot_offsets(ctx, s, nd + 1)))
+                return rc;
+            status = frame_scan(in, left, cflag, stale_work, s.h_off, nd + 1,
+                                maxc, &nd, &used);
+            if (status > 3)
+                return status;
+            if (status == 3 && used == 0 && budget == 0) {
+                if (pos == 0 && out_cap < kMaxBlock)
+                    return fail_ctx(ctx, SNAPMI_E_ARGUMENT,
+                                    "frame_decode_host: out_cap below 65536");
+                more = false; // the output buffer is full: call again
+            } else if (used == 0 && status == 2 && !final) {
+                more = false; // not one whole chunk here: supply more input
+            } else if (left == 0) {
+                more = false;
+            } else {
+                const bool clean =
+                    status == 3 || status == 0 || (status == 2 && !final);
+                const uint64_t dec_len = clean ? used : left;
+                if ((rc = slot_reserve(ctx, s.in, dec_len + 16)) ||
+                    (rc = slot_reserve(ctx, s.out, nd * kMaxBlock + 64)) ||
+                    (rc = slot_reserve(ctx, s.desc, 128 + (nd + 1) * 8)))
+                    return rc;
+                if (trace)
+                    fprintf(stderr, "[pipe] t=%lu scanned %ld us\n",
+                            (unsigned long)t, now_us());
+                HIP_TRY(ctx, hipMemcpyAsync(s.in.p, in, dec_len,
+                                            hipMemcpyHostToDevice, P->s_in));
+                HIP_TRY(ctx, hipEventRecord(s.ev_h2d, P->s_in));
+                if (trace)
+                    fprintf(stderr, "[pipe] t=%lu h2d issued %ld us (%llu B)\n",
+                            (unsigned long)t, now_us(),
+                            (unsigned long long)dec_len);
+                uint64_t *d_len = (uint64_t *)s.desc.p;
+                snapmi_error *d_err =
+                    (snapmi_error *)((uint8_t *)s.desc.p + 64);
+                HIP_TRY(ctx, hipStreamWaitEvent(sK, s.ev_h2d, 0));
+                if (t >= kSlots) // the slot's last result has left
+                    HIP_TRY(ctx, hipStreamWaitEvent(sK, s.ev_d2h, 0));
+                const bool with_index = clean && nd > 0;
+                // (the side index is read where it lies, in pinned host
+                // memory, and the result is posted by a kernel: copies on
+                // this stream would wait behind the bulk copies)
+                rc = snapmi_frame_decompress_ex(
+                    ctx, s.in.p, dec_len, s.out.p, nd * kMaxBlock, d_len,
+                    d_err, with_index ? s.h_off : nullptr, nd, cflag,
+                    stale_in);
+                if (rc)
+                    return rc;
+                static_assert(sizeof(PipeSlot::Result) == 40, "len + error");
+                hipLaunchKernelGGL(k_post_words, dim3(1), dim3(64), 0, sK,
+                                   (uint32_t *)&s.h_res->len,
+                                   (const uint32_t *)d_len, 2u);
+                hipLaunchKernelGGL(k_post_words, dim3(1), dim3(64), 0, sK,
+                                   (uint32_t *)&s.h_res->e,
+                                   (const uint32_t *)d_err, 8u);
+                HIP_TRY(ctx, hipEventRecord(s.ev_k, sK));
+                if (trace)
+                    fprintf(stderr, "[pipe] t=%lu kernels issued %ld us\n",
+                            (unsigned long)t, now_us());
+                fl[k].live = true;
+                fl[k].clean = clean;
+                fl[k].used = used;
+                if (clean) {
+                    pos += used;
+                    budget -= nd;
+                    cflag = SNAPMI_FRAME_CONTINUATION;
+                    memcpy(stale, stale_work, 10);
+                }
+                // 3: the slice was full, the next one follows; anything else
+                // ends the batch (all consumed / a cut-off tail / an error
+                // the device is about to name)
+                more = status == 3;
+            }
+        } else {
+            more = false;
+        }
+        if (t >= 1 && (rc = retire((int)((t - 1) % kSlots))))
+            return rc;
+        if (trace)
+            fprintf(stderr, "[pipe] t=%lu retired %ld us\n", (unsigned long)t,
+                    now_us());
+        if (!more)
+            break;
+    }
+    for (int k = 0; k < kSlots; k++)
+        if ((rc = retire(k)))
+            return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(P->s_out));
+    if (trace) {
+        for (int k = 0; k < kSlots; k++) {
+            float a = 0;
+            if (hipEventElapsedTime(&a, ev_base, P->slot[k].ev_d2h) ==
+                hipSuccess)
+                fprintf(stderr, "[pipe] slot %d: last d2h done %.1f ms\n", k,
+                        a);
+        }
+        fprintf(stderr, "[pipe] done %ld us\n", now_us());
+    }
+    *written = (size_t)wrote;
+    if (result != SNAPMI_OK) {
+        if (err)
+            *err = first_err;
+        return result;
+    }
+    if (disagree)
         return fail_ctx(ctx, SNAPMI_E_DEVICE,
                         "frame_decode_host: host scan and device walk "
                         "disagree");
-    *consumed = (size_t)used;
+    *consumed = (size_t)pos;
     if (stale10)
-        memcpy(stale10, stale_work, 10);
+        memcpy(stale10, stale, 10);
     return SNAPMI_OK;
 }
 

@@ -187,6 +187,59 @@ def encode_host(ctx, data, chunk_lens, ident=True):
     return bytes(out[:written.value])
 
 
+class HostBuffer:
+    """Pinned host memory (snapmi_host_alloc): what makes the copies of the
+    host-buffer calls asynchronous, so that the three legs of a batch (in,
+    kernels, out) overlap.  `.view` is a writable memoryview, `.array` a
+    uint8 numpy array over the same bytes."""
+
+    def __init__(self, nbytes):
+        L = _lib.load()
+        self.nbytes = int(nbytes)
+        self.ptr = L.snapmi_host_alloc(max(self.nbytes, 1))
+        if not self.ptr:
+            raise MemoryError(f"snapmi_host_alloc({nbytes})")
+        self._c = (C.c_uint8 * max(self.nbytes, 1)).from_address(self.ptr)
+        self.view = memoryview(self._c).cast("B")[:self.nbytes]
+        self.array = np.frombuffer(self._c, dtype=np.uint8,
+                                   count=self.nbytes)
+
+    def close(self):
+        if self.ptr:
+            self.view = self.array = self._c = None
+            _lib.load().snapmi_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+
+def _address(buf):
+    """(address, length) of a buffer-protocol object, without a copy."""
+    a = np.frombuffer(buf, dtype=np.uint8)
+    return a.ctypes.data, a.size, a
+
+
+def encode_host_into(ctx, buf, chunk_lens, out, ident=True):
+    """snapmi_frame_encode_host from any buffer into the HostBuffer `out`
+    (no copies on the Python side); returns the bytes written."""
+    L = _lib.load()
+    lens = np.ascontiguousarray(chunk_lens, dtype=np.uint32)
+    addr, n, keep = _address(buf)
+    written = C.c_size_t(0)
+    rc = L.snapmi_frame_encode_host(
+        ctx._h, C.c_void_p(addr), lens.ctypes.data_as(C.c_void_p),
+        int(lens.size), 0 if ident else 1, C.c_void_p(out.ptr), out.nbytes,
+        C.byref(written))
+    del keep
+    if rc:
+        raw._raise(ctx, rc)
+    return written.value
+
+
 def decode_host(ctx, data, out, continuation, final, stale):
     """snapmi_frame_decode_host: decode the whole chunks at the start of
     `data` (bytes) into the bytearray `out`; returns (written, consumed,
@@ -274,6 +327,12 @@ class FrameEncoder:
     its partial tail (src/write.rs:123-152,171-190).  Chunks are queued and
     compressed `batch_bytes` at a time; flush() compresses what is queued."""
 
+    # a write of at least this many bytes that arrives with an empty block
+    # buffer is compressed where it lies (no queue, no copy), at most
+    # DIRECT_MAX bytes per device call
+    DIRECT_MIN = 4 << 20
+    DIRECT_MAX = 4 << 30
+
     def __init__(self, wtr, ctx=None, batch_bytes=BATCH_BYTES):
         self.w = wtr
         self.ctx = ctx or raw.default_context()
@@ -282,14 +341,39 @@ class FrameEncoder:
         self._queue = []             # chunks cut but not yet compressed
         self._queued = 0
         self._wrote_ident = False
+        self._stage = None           # pinned staging of the framed output
 
     def get_ref(self):
         return self.w
 
     get_mut = get_ref
 
+    def _emit_direct(self, buf):
+        """The chunks of `buf` (cut like _inner_write cuts them) straight from
+        the caller's memory through the pipelined host call; the framed bytes
+        reach the writer as a view of pinned staging memory."""
+        for lo in range(0, len(buf), self.DIRECT_MAX):
+            part = buf[lo:lo + self.DIRECT_MAX]
+            n = len(part)
+            nch = (n + MAX_BLOCK_SIZE - 1) // MAX_BLOCK_SIZE
+            lens = np.full(nch, MAX_BLOCK_SIZE, dtype=np.uint32)
+            lens[-1] = n - (nch - 1) * MAX_BLOCK_SIZE
+            cap = 10 + n + 8 * nch
+            if self._stage is None or self._stage.nbytes < cap:
+                if self._stage is not None:
+                    self._stage.close()
+                self._stage = HostBuffer(cap + cap // 8)
+            k = encode_host_into(self.ctx, part, lens, self._stage,
+                                 ident=not self._wrote_ident)
+            self._wrote_ident = True
+            self.w.write(self._stage.view[:k])
+
     # reference Inner::write (src/write.rs:171-190): cut `buf` into chunks
     def _inner_write(self, buf):
+        if len(buf) >= self.DIRECT_MIN and isinstance(buf, memoryview):
+            self._emit()             # what is queued goes first
+            self._emit_direct(buf)
+            return len(buf)
         for o in range(0, len(buf), MAX_BLOCK_SIZE):
             self._queue.append(bytes(buf[o:o + MAX_BLOCK_SIZE]))
         self._queued += len(buf)
@@ -310,7 +394,10 @@ class FrameEncoder:
         self.w.write(framed)
 
     def write(self, buf):
-        buf = memoryview(bytes(buf))
+        try:
+            buf = memoryview(buf).cast("B")      # no copy
+        except TypeError:
+            buf = memoryview(bytes(buf))
         total = 0
         while True:  # src/write.rs:123-152
             free = MAX_BLOCK_SIZE - len(self._src)

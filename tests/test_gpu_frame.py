@@ -647,6 +647,7 @@ def test_frame_side_index_is_only_a_hint(ctx):
         else:
             o[0] = 0
         bad.append(o)
+    bad.append(offs[-1:].copy())                # an index with no chunks
     for o in bad:
         good, err = frame.decompress_batch_device(
             ctx, d_in, len(f), n, torch.from_numpy(o.astype(np.int64)).cuda())
