@@ -29,35 +29,117 @@ import torch  # noqa: E402
 GIB = float(1 << 30)
 
 
-def synth_text(dev, period_bytes, seed=0x5EED5A4D):
+SYNTH_SEED = 0x5EED5A4D53505931
+_GAMMA = 0x9E3779B97F4A7C15
+_M1, _M2 = 0xBF58476D1CE4E5B9, 0x94D049BB133111EB
+
+
+def _s64(x):
+    """a 64-bit pattern as the int64 torch computes with (wrapping)"""
+    x &= (1 << 64) - 1
+    return x - (1 << 64) if x >> 63 else x
+
+
+def _vocabulary():
+    """Whitespace-delimited tokens of the four text files of the corpus, in
+    byte order, with their counts (the empirical unigram distribution)."""
     import oracle_lib as O
     words = []
     for name in ("alice29.txt", "asyoulik.txt", "lcet10.txt", "plrabn12.txt"):
         words += (O.CORPUS / name).read_bytes().split()
-    vocab, counts = np.unique(np.array(words, dtype=object), return_counts=True)
+    vocab, counts = np.unique(np.array(words, dtype=object),
+                              return_counts=True)
+    return [bytes(w) for w in vocab], counts.astype(np.int64)
+
+
+def synth_text_reference(period_bytes, seed=SYNTH_SEED):
+    """The generator of SURVEY 8d, one token at a time on the CPU (small
+    periods only: it pins synth_text below).  Token i is drawn with the i-th
+    output of splitmix64(seed): r = (z >> 1) mod total count, looked up in
+    the cumulative counts of the vocabulary; tokens are joined by single
+    spaces; the separator behind the first token that passes column 72 is a
+    newline."""
+    vocab, counts = _vocabulary()
+    cum = np.cumsum(counts)
+    total = int(cum[-1])
+    out = bytearray()
+    state, col = seed, 0
+    mask = (1 << 64) - 1
+    while len(out) < period_bytes:
+        state = (state + _GAMMA) & mask
+        z = state
+        z = ((z ^ (z >> 30)) * _M1) & mask
+        z = ((z ^ (z >> 27)) * _M2) & mask
+        z ^= z >> 31
+        w = vocab[int(np.searchsorted(cum, (z >> 1) % total, side="right"))]
+        out += w
+        col += len(w)
+        if col > 72:
+            out += b"\n"
+            col = 0
+        else:
+            out += b" "
+            col += 1
+    return bytes(out[:period_bytes])
+
+
+def synth_text(dev, period_bytes, seed=SYNTH_SEED):
+    """synth_text_reference on the device (a period is 10^7..10^8 tokens):
+    counter-based splitmix64 in wrapping int64 arithmetic, a search in the
+    cumulative counts, byte positions by a prefix sum - and the greedy line
+    breaks, which are a chain (line k starts where line k-1 broke): "the line
+    that starts at token i ends behind token next(i)" for every i, then the
+    orbit of token 0 by pointer doubling."""
+    vocab, counts = _vocabulary()
     maxlen = max(len(w) for w in vocab)
     table = np.zeros((len(vocab), maxlen), dtype=np.uint8)
-    lens = np.zeros(len(vocab), dtype=np.int64)
+    lens = np.array([len(w) for w in vocab], dtype=np.int64)
     for i, w in enumerate(vocab):
         table[i, :len(w)] = np.frombuffer(w, dtype=np.uint8)
-        lens[i] = len(w)
-    g = torch.Generator(device=dev)
-    g.manual_seed(seed)
-    p = torch.from_numpy(counts.astype(np.float64)).to(dev)
+    cum = torch.from_numpy(np.cumsum(counts)).to(dev)
+    total = int(cum[-1].item())
     mean_len = float((lens * counts).sum() / counts.sum()) + 1.0
-    ntok = int(period_bytes / mean_len * 1.02) + 16
-    ids = torch.multinomial(p, ntok, replacement=True, generator=g)
-    d_lens = torch.from_numpy(lens).to(dev)[ids] + 1        # token + separator
-    ends = torch.cumsum(d_lens, 0)
-    starts = ends - d_lens
-    total = int(ends[-1].item())
-    out = torch.full((total,), 32, dtype=torch.uint8, device=dev)  # spaces
+    ntok = int(period_bytes / mean_len * 1.02) + 64
+    i = torch.arange(1, ntok + 1, dtype=torch.int64, device=dev)
+    z = i * _s64(_GAMMA) + _s64(seed)                   # wraps mod 2^64
+
+    def lsr(x, k):                                      # logical shift right
+        return (x >> k) & ((1 << (64 - k)) - 1)
+    z = (z ^ lsr(z, 30)) * _s64(_M1)
+    z = (z ^ lsr(z, 27)) * _s64(_M2)
+    z = z ^ lsr(z, 31)
+    ids = torch.searchsorted(cum, lsr(z, 1) % total, right=True)
+    del z, i
+    d_len = torch.from_numpy(lens).to(dev)[ids]          # token lengths
+    ends = torch.cumsum(d_len + 1, 0)                    # behind separator
+    starts = ends - d_len - 1
+    total_bytes = int(ends[-1].item())
+    assert total_bytes >= period_bytes
+    # a line that starts at token i (byte starts[i]) breaks behind the first
+    # token j whose last byte passes column 72: ends[j] - 1 - starts[i] > 72
+    brk = torch.searchsorted(ends, starts + 73, right=True)   # that token j
+    nxt = torch.clamp(brk + 1, max=ntok - 1)             # next line's first
+    is_start = torch.zeros(ntok, dtype=torch.bool, device=dev)
+    is_start[0] = True
+    jump = nxt
+    while True:                                          # pointer doubling
+        idx = is_start.nonzero().squeeze(1)
+        before = idx.numel()
+        is_start[jump[idx]] = True
+        if int(is_start.sum().item()) == before:
+            break
+        jump = jump[jump]
+    del jump
+    is_start[-1] = True   # (the clamp's fixed point; behind the period)
+    line_first = is_start.nonzero().squeeze(1)
+    last_tok = brk[line_first]                           # gets the newline
+    last_tok = last_tok[last_tok < ntok]
+    out = torch.full((total_bytes,), 32, dtype=torch.uint8, device=dev)
     d_table = torch.from_numpy(table).to(dev)
-    for k in range(maxlen):                                   # k-th char
-        m = (d_lens - 1) > k
+    for k in range(maxlen):                              # k-th character
+        m = d_len > k
         out[starts[m] + k] = d_table[ids[m], k]
-    nl = (starts // 73) != ((ends - 1) // 73)
-    out[ends[nl] - 1] = 10
+    out[ends[last_tok] - 1] = 10
     return out[:period_bytes].contiguous()
 
 
@@ -76,7 +158,9 @@ def time_it(fn, steps, ctx):
 def cfg3(args, ctx, dev):
     from rust_snappy_amd import frame
     import oracle_lib as O
-    period = synth_text(dev, int(args.period_mib * (1 << 20)))
+    pbytes = min(int(args.period_mib * (1 << 20)),
+                 max(1 << 20, int(args.gib * GIB) // 65536 * 65536))
+    period = synth_text(dev, pbytes)
     reps = max(1, int(args.gib * GIB / period.numel()))
     data = period.repeat(reps)
     n = data.numel()
@@ -134,8 +218,16 @@ def cfg3(args, ctx, dev):
     per = back[:reps * period.numel()].view(reps, period.numel())
     for r in range(reps):
         assert torch.equal(per[r], period), "frame round trip (timed)"
-    return {"config": "cfg3 framed synthetic text", "gib": round(n / GIB, 3),
-            "chunks": index.numel() - 1, "ratio": round(flen / n, 4),
+    types = out[index[:-1]]                  # chunk type bytes
+    n_stored = int((types == 1).sum().item())
+    return {"config": "cfg3 framed synthetic text (SURVEY 8d generator: "
+                      "splitmix64 seed 0x5EED5A4D53505931, unigram tokens of "
+                      "the four corpus texts, newline behind the first token "
+                      "past column 72; period "
+                      f"{period.numel() >> 20} MiB)",
+            "gib": round(n / GIB, 3),
+            "chunks": index.numel() - 1, "uncompressed_chunks": n_stored,
+            "ratio": round(flen / n, 4),
             "frame_encode_gibs": round(n / GIB / te, 2),
             "frame_decode_gibs": round(n / GIB / td, 2),
             "encode_ms": round(te * 1e3, 2), "decode_ms": round(td * 1e3, 2),
@@ -421,7 +513,9 @@ def cfg4(args, ctx, dev):
             dist.init_process_group("gloo")  # N ranks on one GPU: proof run
         else:
             dist.init_process_group("nccl", device_id=dev)
-    period = synth_text(dev, int(args.period_mib * (1 << 20)))
+    pbytes = min(int(args.period_mib * (1 << 20)),
+                 max(1 << 20, int(args.gib * GIB / world) // 65536 * 65536))
+    period = synth_text(dev, pbytes)
     assert period.numel() % 65536 == 0
     periods = max(world, int(args.gib * GIB / period.numel()))
     lo, hi = periods * rank // world, periods * (rank + 1) // world
@@ -487,7 +581,8 @@ def cfg4(args, ctx, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gib", type=float, default=8.0)
-    ap.add_argument("--period-mib", type=float, default=256.0)
+    ap.add_argument("--period-mib", type=float, default=1024.0,
+                    help="period of the synthetic text (SURVEY 8d: 1 GiB)")
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--only", default="")
     ap.add_argument("--plan", default="",
