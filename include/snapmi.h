@@ -115,15 +115,16 @@ const char *snapmi_last_error(const snapmi_ctx *ctx);
  * pageable memory).  NULL when it cannot be had. */
 void *snapmi_host_alloc(size_t bytes);
 void snapmi_host_free(void *p);
-/* "ms ms ..." of the placement probe for every candidate region of the last
- * lane-table allocation ("" when lane_table_tries is 1). */
+/* "ms ms ... | held at most B of budget B": the placement probe's time for
+ * every candidate region of the last lane-table allocation (none when
+ * lane_table_tries is 1) and the most device memory it held at once. */
 const char *snapmi_table_probe_log(const snapmi_ctx *ctx);
 /* hipStream_t the context launches on (for event timing by the caller). */
 void *snapmi_ctx_stream(const snapmi_ctx *ctx);
 /* "snapmi <version> gfx950" */
 const char *snapmi_version(void);
 /*
- * Tuning knobs (results never depend on them, only speed):
+ * Options (results never depend on them, only speed and memory):
  *   "compress_mode"        0 wavefront-per-block kernel only, 1 lane-per-block
  *                          kernel on large batches (default), 2 both at once
  *   "small_batch_kernel"   1 (default): batches of at most two blocks per
@@ -132,40 +133,37 @@ const char *snapmi_version(void);
  *                          would run
  *   "lane_min_blocks"      batches with at least this many 64 KiB blocks use
  *                          the lane-per-block kernel (default 8192)
- *   "lane_waves_per_cu"    lanes in flight = 64 x this x CUs (default 6)
  *   "lane_segment_blocks"  blocks per lane-kernel launch (default 262144 =
  *                          16 GiB of input; bounds the token scratch)
- *   "lane_tables_uncached" 1: the lane tables come from an uncached
- *                          allocation (measured: no gain; default 0)
- *   "lane_direct_encode"   1 (default): the lane kernel's encoder writes every
- *                          block at its final position (the match finder adds
- *                          up the encoded sizes); 0: scratch slot per block +
- *                          a compaction pass, as the wavefront kernel needs
- *   "lane_overlap_encode"  0 (default) never; 1: a lane-kernel segment with
- *                          at least 1.4 blocks per lane is matched in two
- *                          halves, the first half's tokens encoded on a side
- *                          stream meanwhile (measured slower); 2: whenever it
- *                          has two blocks (tests)
  *   "lane_table_spread"    1 (default): the lane kernel's hash tables are
- *                          spread over up to 4x their size, within a third of
- *                          the free device memory (HBM sustains more random
- *                          accesses that way); 0: packed (25 GB at most)
+ *                          spread over up to 4x their size (HBM sustains more
+ *                          random accesses that way); 0: packed (25 GB)
+ *   "lane_table_budget_pct"  percent of the device memory that is free when
+ *                          a context first needs its lane tables that the
+ *                          tables - and, while a placement is being chosen,
+ *                          its candidates together - may hold (default 33,
+ *                          1..90).  A host that owns the GPU raises it: the
+ *                          tables then spread further (bench.py: 75)
  *   "lane_table_tries"     placements of the lane tables that are timed
- *                          (k_probe_tables) before the fastest is kept, when
- *                          a context first allocates them
+ *                          (k_probe_tables, 3 ms each) before the fastest is
+ *                          kept (default 10; DESIGN 4.1: where the tables lie
+ *                          decides 10-25 % of the match finder's speed).  1:
+ *                          no probing, one region of the whole budget
+ *   "decode_kernel"        3 (default) k_decompress_streams3; 2 the second
+ *                          generation (cross-check); 0 one element at a time
  *   "frame_parallel_walk_min"  framed streams of at least this many bytes
  *                          decoded without a side index get their chunk
  *                          headers found in parallel (default 4 MiB)
- * Test knobs (results still never depend on them):
- *   "lane_tables_renew"    1: free the lane tables now; the next large batch
- *                          allocates (and places) new ones
- *   "lane_max_waves"       cap on the lane kernel's wavefronts (0 = none), so
- *                          a small batch puts several blocks on one lane
- *   "lane_epoch_preset"    0..65535: every lane's hash-table epoch is set to
- *                          this before the next lane-kernel launch (reaches
- *                          the 16-bit epoch wrap without 65 535 blocks/lane)
- *   "lds_order_ok"         0: behave as if the LDS atomic order self-check of
- *                          snapmi_ctx_create had failed (lane kernel only)
+ *   "host_encode_slice"    input bytes per slice of snapmi_frame_encode_host
+ *                          (default 2 GiB: the match finder wants few, large
+ *                          launches)
+ *   "host_decode_slice_chunks"  data chunks per slice of
+ *                          snapmi_frame_decode_host (default 8192)
+ *   "host_copy_kernel"     bit 0 / bit 1: decoded / encoded results go home
+ *                          by a copy kernel instead of hipMemcpyAsync when
+ *                          the caller's buffer is pinned (default 1)
+ * The knobs of the test suite and of the experiment drivers are declared in
+ * snapmi_test.h (snapmi_ctx_set_test_option).
  * Returns SNAPMI_E_ARGUMENT for an unknown name.
  */
 int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value);

@@ -47,6 +47,7 @@ SYMBOLS = [
     ("snapmi_ctx_stream", _P, [_P]),
     ("snapmi_version", C.c_char_p, []),
     ("snapmi_ctx_set_option", C.c_int, [_P, C.c_char_p, C.c_int64]),
+    ("snapmi_ctx_set_test_option", C.c_int, [_P, C.c_char_p, C.c_int64]),
     ("snapmi_max_compress_len", _SZ, [_SZ]),
     ("snapmi_decompress_len", C.c_int, [C.c_char_p, _SZ, _SZP, _ERRP]),
     ("snapmi_raw_compress", C.c_int,

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "snapmi.h"
+#include "snapmi_test.h"
 #include "snapmi_ctx.hpp"
 #include "snapmi_device.hpp"
 #include "snapmi_kernels.hpp"
@@ -91,6 +92,11 @@ int snapmi_ctx_create(int device, void *hip_stream, snapmi_ctx **out)
             return SNAPMI_E_DEVICE;
         }
         ctx->num_cus = prop.multiProcessorCount;
+    }
+    // experiment knobs from the environment (tests/hw drivers): only for a
+    // process that says SNAPMI_TESTING=1 - a production host sets what it
+    // needs through snapmi_ctx_set_option
+    if (getenv("SNAPMI_TESTING")) {
         if (const char *e = getenv("SNAPMI_LANE_WAVES")) {
             const int v = atoi(e);
             ctx->lane_waves_per_cu = (uint32_t)(v < 1 ? 1 : (v > 32 ? 32 : v));
@@ -249,8 +255,38 @@ int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value)
     else if (strcmp(name, "lane_table_spread") == 0 && value >= 0 &&
              value <= 1)
         ctx->lane_table_spread = value != 0;
-    else if (strcmp(name, "lane_waves_per_cu") == 0 && value >= 1 &&
-             value <= 32)
+    else if (strcmp(name, "lane_table_tries") == 0 && value >= 1 &&
+             value <= 16)
+        ctx->lane_table_tries = (uint32_t)value;
+    else if (strcmp(name, "lane_table_budget_pct") == 0 && value >= 1 &&
+             value <= 90)
+        ctx->lane_table_budget_pct = (uint32_t)value;
+    else if (strcmp(name, "small_batch_kernel") == 0 && value >= 0 &&
+             value <= 2)
+        ctx->small_batch_kernel = (int)value;
+    else if (strcmp(name, "frame_parallel_walk_min") == 0 && value >= 0)
+        ctx->frame_parallel_walk_min = (uint64_t)value;
+    else if (strcmp(name, "host_copy_kernel") == 0 && value >= 0 && value <= 3)
+        ctx->host_copy_kernel = (int)value;
+    else if (strcmp(name, "host_encode_slice") == 0 && value >= (1 << 16))
+        ctx->host_encode_slice = (uint64_t)value;
+    else if (strcmp(name, "host_decode_slice_chunks") == 0 && value >= 1)
+        ctx->host_decode_slice_chunks = (uint64_t)value;
+    else if (strcmp(name, "decode_kernel") == 0 &&
+             (value == 0 || value == 2 || value == 3))
+        ctx->decode_kernel = ctx->lds_store_order_ok ? (int)value : 0;
+    else
+        return fail_ctx(ctx, SNAPMI_E_ARGUMENT, "unknown option %s", name);
+    return SNAPMI_OK;
+}
+
+// include/snapmi_test.h: knobs of the test suite and the experiment drivers
+int snapmi_ctx_set_test_option(snapmi_ctx *ctx, const char *name,
+                               int64_t value)
+{
+    if (!ctx || !name)
+        return SNAPMI_E_ARGUMENT;
+    if (strcmp(name, "lane_waves_per_cu") == 0 && value >= 1 && value <= 32)
         ctx->lane_waves_per_cu = (uint32_t)value;
     else if (strcmp(name, "lane_max_waves") == 0 && value >= 0 &&
              value <= 0x7FFFFFFF)
@@ -267,30 +303,13 @@ int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value)
     else if (strcmp(name, "lane_overlap_encode") == 0 && value >= 0 &&
              value <= 2)
         ctx->lane_overlap_encode = (int)value;
-    else if (strcmp(name, "small_batch_kernel") == 0 && value >= 0 &&
-             value <= 2)
-        ctx->small_batch_kernel = (int)value;
     else if (strcmp(name, "frame_walk_segment") == 0 && value >= (128 << 10))
         ctx->frame_walk_segment = (uint64_t)value;
-    else if (strcmp(name, "frame_parallel_walk_min") == 0 && value >= 0)
-        ctx->frame_parallel_walk_min = (uint64_t)value;
-    else if (strcmp(name, "host_copy_kernel") == 0 && value >= 0 && value <= 3)
-        ctx->host_copy_kernel = (int)value;
-    else if (strcmp(name, "host_encode_slice") == 0 && value >= (1 << 16))
-        ctx->host_encode_slice = (uint64_t)value;
-    else if (strcmp(name, "host_decode_slice_chunks") == 0 && value >= 1)
-        ctx->host_decode_slice_chunks = (uint64_t)value;
-    else if (strcmp(name, "decode_kernel") == 0 &&
-             (value == 0 || value == 2 || value == 3))
-        ctx->decode_kernel = ctx->lds_store_order_ok ? (int)value : 0;
-    else if (strcmp(name, "lane_table_tries") == 0 && value >= 1 &&
-             value <= 16)
-        ctx->lane_table_tries = (uint32_t)value;
     else if (strcmp(name, "lane_table_probe") == 0 && value >= 0 &&
              value <= 1)
         ctx->lane_table_probe = value != 0; // time the placement even if 1 try
     else if (strcmp(name, "lane_tables_renew") == 0 && value == 1) {
-        // experiment knob: drop the tables so the next launch places new ones
+        // drop the tables so the next launch places new ones
         if (ctx->lane_tables.p) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             HIP_TRY(ctx, hipFree(ctx->lane_tables.p));
@@ -304,7 +323,8 @@ int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value)
     else if (strcmp(name, "lds_order_ok") == 0 && value >= 0 && value <= 1)
         ctx->lds_order_ok = ctx->lds_order_hw && value != 0; // can only lower
     else
-        return fail_ctx(ctx, SNAPMI_E_ARGUMENT, "unknown option %s", name);
+        return fail_ctx(ctx, SNAPMI_E_ARGUMENT, "unknown test option %s",
+                        name);
     return SNAPMI_OK;
 }
 
@@ -511,15 +531,23 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
             // within a third of the memory that is free right now.
             const size_t tbytes = (size_t)kMaxTable * 16;
             size_t stride = tbytes;
+            // (only worth it for a launch that fills the chip: a small
+            // batch gets a handful of tables and no measurable placement)
+            const uint32_t tries =
+                lanes >= 16384 && ctx->lane_table_tries
+                    ? ctx->lane_table_tries : 1;
+            size_t budget = 0; // bytes this context may hold while it chooses
             if (ctx->lane_table_spread) {
                 size_t free_b = 0, total_b = 0;
                 HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
                 free_b += ctx->lane_tables.cap; // about to be released
-                // (a third; a quarter when several placements are tried,
-                // so that three regions fit while one is being chosen)
-                stride = free_b /
-                         (ctx->lane_table_tries > 1 && lanes >= 16384 ? 4 : 3) /
-                         lanes / 4096 * 4096;
+                // The GPU may be shared: at no moment does the placement
+                // hold more than lane_table_budget_pct of what is free now
+                // (a third by default).  While a placement is being chosen
+                // three regions are alive (best so far, last loser, new
+                // candidate), so each gets a third of the budget.
+                budget = free_b / 100 * ctx->lane_table_budget_pct;
+                stride = budget / (tries > 1 ? 3 : 1) / lanes / 4096 * 4096;
                 if (stride > 4 * tbytes)
                     stride = 4 * tbytes;
                 if (stride < tbytes)
@@ -557,11 +585,7 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
             } rg;
             float best_ms = 0;
             ctx->probe_log.clear();
-            // (only worth it for a launch that fills the chip: a small
-            // batch gets a handful of tables and no measurable placement)
-            const uint32_t tries =
-                lanes >= 16384 && ctx->lane_table_tries
-                    ? ctx->lane_table_tries : 1;
+            size_t held_peak = 0;
             for (uint32_t t = 0; t < tries; t++) {
                 void *&cand = rg.cand;
                 void *&best = rg.best, *&loser = rg.loser;
@@ -574,6 +598,11 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                          : hipMalloc(&cand, bytes)) != hipSuccess) {
                     (void)hipGetLastError();
                     break; // no room for another candidate: keep the best
+                }
+                {
+                    const size_t held =
+                        bytes * (1 + (rg.best ? 1 : 0) + (rg.loser ? 1 : 0));
+                    held_peak = held > held_peak ? held : held_peak;
                 }
                 if (loser) {
                     void *gone = loser;
@@ -610,6 +639,12 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                     loser = cand;
                 }
                 cand = nullptr;
+            }
+            {
+                char buf[96];
+                snprintf(buf, sizeof buf, " | held at most %zu of budget %zu",
+                         held_peak, budget);
+                ctx->probe_log += buf;
             }
             void *&best = rg.best, *&loser = rg.loser;
             if (loser) {

@@ -101,6 +101,9 @@ struct snapmi_ctx {
     // (default 10 for a full-size launch: profiles/r2_placement_probe2.txt;
     // a candidate costs one hipMalloc and a 3 ms probe)
     uint32_t lane_table_tries = 10;
+    // percent of the free device memory the lane tables (and, while a
+    // placement is chosen, their candidates) may hold: the GPU may be shared
+    uint32_t lane_table_budget_pct = 33;
     bool lane_table_probe = false; // experiment knob: probe even with 1 try
     std::string probe_log;          // k_probe_tables ms of every candidate
     // test knob: every lane's table epoch is set to this value before the

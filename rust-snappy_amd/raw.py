@@ -69,6 +69,14 @@ class Context:
         if rc:
             _raise(self, rc)
 
+    def set_test_option(self, name, value):
+        """snapmi_ctx_set_test_option (include/snapmi_test.h): knobs of the
+        test suite and the experiment drivers."""
+        rc = _lib.load().snapmi_ctx_set_test_option(self._h, name.encode(),
+                                                    int(value))
+        if rc:
+            _raise(self, rc)
+
     @property
     def stream(self):
         return _lib.load().snapmi_ctx_stream(self._h)

@@ -63,7 +63,7 @@ def cctx(request, built):
     if request.param == "lanes_segmented":
         c.set_option("lane_segment_blocks", 64)
     # matched in two halves, the first half encoded on the side stream
-    c.set_option("lane_overlap_encode",
+    c.set_test_option("lane_overlap_encode",
                  2 if request.param == "lanes_overlap" else 0)
     yield c
     c.close()

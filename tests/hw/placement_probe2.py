@@ -38,14 +38,14 @@ def run(ctx, k=2):
 hold = []   # dummy allocations that push the next placement elsewhere
 for tries, reps in ((1, 6), (4, 3), (8, 2)):
     ctx = raw.Context(0)
-    ctx.set_option("lane_table_probe", 1)
+    ctx.set_test_option("lane_table_probe", 1)
     ctx.set_option("lane_table_tries", tries)
     for i in range(reps):
         ms = run(ctx)
         log = L.snapmi_table_probe_log(ctx._h).decode()
         free, _ = torch.cuda.mem_get_info()
         print(f"tries {tries} placement {i}: probe ms [{log}]  lane kernel ms {ms[0]:.1f} {ms[1]:.1f}  free {free/2**30:.0f} GiB", flush=True)
-        ctx.set_option("lane_tables_renew", 1)
+        ctx.set_test_option("lane_tables_renew", 1)
         if tries == 1 and i % 2 == 1:   # shift what the allocator hands out next
             hold.append(torch.empty((3 + i) << 30, dtype=torch.uint8, device=dev))
     ctx.close()

@@ -4,7 +4,7 @@
 v=$1; w=$2; tag=$3; shift 3
 R=$PWD
 [ "$v" != "-" ] && export SNAPMI_LIB=$R/rust-snappy_amd/variants/$v.so
-[ "$w" != "-" ] && export SNAPMI_LANE_WAVES=$w
+[ "$w" != "-" ] && export SNAPMI_TESTING=1 SNAPMI_LANE_WAVES=$w
 cd /tmp && export TMPDIR=/tmp
 i=0
 for grp in "$@"; do

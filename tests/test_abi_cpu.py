@@ -10,7 +10,8 @@ from conftest import ROOT
 
 
 def declared_symbols():
-    text = (ROOT / "include" / "snapmi.h").read_text()
+    text = (ROOT / "include" / "snapmi.h").read_text() + \
+        (ROOT / "include" / "snapmi_test.h").read_text()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     names = re.findall(r"\b(snap(?:py|mi)_[a-z_0-9]+)\s*\(", text)
     return sorted(set(names))

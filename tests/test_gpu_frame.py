@@ -721,7 +721,7 @@ def test_frame_parallel_header_walk(built):
     from rust_snappy_amd import frame
     par = R.raw.Context(0)
     par.set_option("frame_parallel_walk_min", 0)
-    par.set_option("frame_walk_segment", 128 << 10)
+    par.set_test_option("frame_walk_segment", 128 << 10)
     seq = R.raw.Context(0)
     seq.set_option("frame_parallel_walk_min", 1 << 60)
     rnd = O.corpus_round()
