@@ -307,6 +307,23 @@ def files(args, ctx, dev):
             "files": rows}
 
 
+def tiny(args, ctx, dev):
+    """The tiny-stream regime on its own: zflat03 (the first 200 bytes of
+    fireworks.jpeg, bench/src/bench.rs:91) tiled to --gib = 10.7 M streams
+    at 2 GiB."""
+    import oracle_lib as O
+    for bench_id, blob in O.corpus_round():
+        if len(blob) == 200:
+            n, c, reps, te, td = raw_tiles(ctx, dev, blob, args.gib,
+                                           args.steps, O.compress(blob))
+            return {"config": f"{bench_id} tiled to {args.gib} GiB",
+                    "streams": reps, "ratio": round(c / n, 4),
+                    "compress_gibs": round(n / GIB / te, 2),
+                    "decompress_gibs": round(n / GIB / td, 2),
+                    "compress_ms": round(te * 1e3, 2),
+                    "decompress_ms": round(td * 1e3, 2)}
+
+
 def _host_corpus(gib):
     """The corpus round tiled into pinned host memory (snapmi_host_alloc)."""
     import oracle_lib as O
@@ -603,7 +620,8 @@ def main():
     ctx = raw.Context(local)
     ctx.set_option("lane_table_budget_pct", 75)   # the benchmark owns its GPU
     table = {"cfg3": cfg3, "cfg5": cfg5, "files": files, "pcie": pcie,
-             "adapters": adapters, "stream": stream, "cfg4": cfg4}
+             "adapters": adapters, "stream": stream, "cfg4": cfg4,
+             "tiny": tiny}
     if args.plan:
         for item in args.plan.split(","):
             name, gib = item.split(":")

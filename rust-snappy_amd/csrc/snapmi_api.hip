@@ -213,7 +213,8 @@ void snapmi_ctx_destroy(snapmi_ctx *ctx)
     if (ctx->h_mail)
         (void)hipHostFree((void *)ctx->h_mail);
     for (DevBuf *b : {&ctx->blk_first, &ctx->slot_first, &ctx->blk_size,
-                      &ctx->blk_off, &ctx->slots, &ctx->st_in, &ctx->st_out,
+                      &ctx->blk_off, &ctx->slots, &ctx->plan_part,
+                      &ctx->st_in, &ctx->st_out,
                       &ctx->st_desc, &ctx->st_prof, &ctx->ticket,
                       &ctx->order, &ctx->fr_tables, &ctx->fr_desc,
                       &ctx->fr_meta, &ctx->fr_scan, &ctx->fr_slots,
@@ -439,6 +440,27 @@ int snapmi_compress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
 
 namespace snapmi {
 
+// batches of up to this many streams / blocks are planned and scanned by one
+// workgroup (one launch instead of three)
+constexpr size_t kPlanOneWg = 16384;
+
+// k_scan_sizes over the blocks [a.blk_lo, min(a.blk_hi, host_blocks))
+static void launch_scan_sizes(const CompressArgs &a, hipStream_t s)
+{
+    const uint32_t hi = a.blk_hi < a.host_blocks ? a.blk_hi : a.host_blocks;
+    const uint32_t cnt = hi > a.blk_lo ? hi - a.blk_lo : 0;
+    if (cnt > kPlanOneWg) {
+        const uint32_t parts = (cnt + 1023) / 1024;
+        hipLaunchKernelGGL(k_scan_sizes_a, dim3(parts), dim3(1024), 0, s, a,
+                           parts);
+        hipLaunchKernelGGL(k_scan_sizes_b, dim3(1), dim3(1024), 0, s, a,
+                           parts);
+        hipLaunchKernelGGL(k_scan_sizes_c, dim3(parts), dim3(1024), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(k_scan_sizes, dim3(1), dim3(1024), 0, s, a);
+    }
+}
+
 int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                     const uint64_t *d_in_lens, void *const *d_out_ptrs,
                     const uint64_t *d_out_caps, uint64_t *d_out_lens,
@@ -456,6 +478,8 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
         (rc = reserve(ctx, ctx->slot_first, (n + 1) * sizeof(uint32_t))) ||
         (rc = reserve(ctx, ctx->blk_size, (blocks + 1) * sizeof(uint32_t))) ||
         (rc = reserve(ctx, ctx->blk_off, (blocks + 2) * sizeof(uint64_t))) ||
+        (rc = reserve(ctx, ctx->plan_part,
+                      ((n > blocks ? n : blocks) / 1024 + 4) * 16)) ||
         (rc = reserve(ctx, ctx->ticket, 64)))
         return rc;
 
@@ -470,6 +494,9 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     a.slot_first = (uint32_t *)ctx->slot_first.p;
     a.blk_size = (uint32_t *)ctx->blk_size.p;
     a.blk_off = (uint64_t *)ctx->blk_off.p;
+    // (the two scans never run at the same time: one buffer for both)
+    a.plan_part = (uint2 *)ctx->plan_part.p;
+    a.scan_part = (unsigned long long *)ctx->plan_part.p;
     a.n_streams = (uint32_t)n;
     a.host_blocks = (uint32_t)blocks;
     a.host_slots = (uint32_t)slots;
@@ -697,7 +724,15 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     hipStream_t s = ctx->stream;
     ctx->timing_valid = false;
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], s));
-    hipLaunchKernelGGL(k_plan_compress, dim3(1), dim3(1024), 0, s, a);
+    if (n > kPlanOneWg) {
+        const uint32_t parts = (uint32_t)((n + 1023) / 1024);
+        hipLaunchKernelGGL(k_plan_compress_a, dim3(parts), dim3(1024), 0, s, a);
+        hipLaunchKernelGGL(k_plan_compress_b, dim3(1), dim3(1024), 0, s, a,
+                           parts);
+        hipLaunchKernelGGL(k_plan_compress_c, dim3(parts), dim3(1024), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(k_plan_compress, dim3(1), dim3(1024), 0, s, a);
+    }
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], s));
     if (blocks) {
         hipStream_t ws = s; // stream of the wavefront kernel
@@ -780,8 +815,7 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                     HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
                 }
                 if (direct)
-                    hipLaunchKernelGGL(k_scan_sizes, dim3(1), dim3(1024), 0,
-                                       s, a);
+                    launch_scan_sizes(a, s);
                 hipLaunchKernelGGL(k_encode_tokens,
                                    dim3((uint32_t)(hi - a.blk_lo)), dim3(64),
                                    0, s, a);
@@ -798,7 +832,7 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
         hipLaunchKernelGGL(k_stream_lens, dim3((uint32_t)((n + 255) / 256)),
                            dim3(256), 0, s, a);
     } else if (blocks) {
-        hipLaunchKernelGGL(k_scan_sizes, dim3(1), dim3(1024), 0, s, a);
+        launch_scan_sizes(a, s);
         hipLaunchKernelGGL(k_compact, dim3((uint32_t)blocks), dim3(256), 0,
                            s, a);
     }
@@ -831,12 +865,13 @@ int launch_decompress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     a.modes = d_modes;
     a.n_streams = (uint32_t)n;
     {
-        int rc = reserve(ctx, ctx->order, n * sizeof(uint32_t));
+        // (+ 64 bucket counters of the many-workgroup sort behind the order)
+        int rc = reserve(ctx, ctx->order, (n + 64) * sizeof(uint32_t));
         if (rc)
             return rc;
     }
     a.order = (uint32_t *)ctx->order.p;
-    a.bucket_pos = nullptr;
+    a.bucket_pos = a.order + n;
     a.prof = nullptr;
 #ifdef SNAPMI_PROFILE
     {
@@ -851,7 +886,17 @@ int launch_decompress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     hipStream_t s = ctx->stream;
     ctx->timing_valid = false;
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], s));
-    hipLaunchKernelGGL(k_plan_decompress, dim3(1), dim3(1024), 0, s, a);
+    if (n > kPlanOneWg) {
+        const uint32_t parts = (uint32_t)((n + 1023) / 1024);
+        HIP_TRY(ctx, hipMemsetAsync(a.bucket_pos, 0, 64 * sizeof(uint32_t), s));
+        hipLaunchKernelGGL(k_plan_decompress_a, dim3(parts), dim3(1024), 0, s,
+                           a);
+        hipLaunchKernelGGL(k_plan_decompress_b, dim3(1), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(k_plan_decompress_c, dim3(parts), dim3(1024), 0, s,
+                           a);
+    } else {
+        hipLaunchKernelGGL(k_plan_decompress, dim3(1), dim3(1024), 0, s, a);
+    }
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], s));
     if (ctx->decode_kernel == 0)
         hipLaunchKernelGGL(k_decompress_sequential, dim3((uint32_t)n),

@@ -1431,6 +1431,185 @@ __global__ __launch_bounds__(1024) void k_scan_sizes(CompressArgs a)
         blk_off[nblocks] = carry;
 }
 
+// ---------------------------------------------------------------------
+// The same two scans on many workgroups, for batches of many streams /
+// blocks (10.7 M streams of 200 bytes: the one-workgroup kernels above took
+// 27.8 ms and 41 x 0.46 ms of a 104 ms pass).  Three launches each: (a) every
+// workgroup scans its 1024 items and leaves its total, (b) one workgroup
+// scans the totals, (c) every workgroup adds its offset.
+// ---------------------------------------------------------------------
+namespace {
+// blocks of stream i, or 0 for a stream that is rejected or empty
+// (reference src/compress.rs:104-125)
+__device__ __forceinline__ uint32_t plan_blocks(const CompressArgs &a,
+                                                uint32_t i, bool report)
+{
+    const uint64_t len = a.in_lens[i];
+    const uint64_t need = max_compress_len_u64(len);
+    if (report)
+        a.out_lens[i] = 0;
+    if (need == 0) {
+        if (report)
+            set_error(a.errs, i, SNAPMI_TOO_BIG, len, kMaxInput, 0);
+        return 0;
+    }
+    if (a.out_caps && a.out_caps[i] < need) {
+        if (report)
+            set_error(a.errs, i, SNAPMI_BUFFER_TOO_SMALL, a.out_caps[i], need,
+                      0);
+        return 0;
+    }
+    if (len == 0) { // src/compress.rs:120-125
+        if (report) {
+            ((gptr)a.out_ptrs[i])[0] = 0;
+            a.out_lens[i] = 1;
+            set_error(a.errs, i, SNAPMI_OK, 0, 0, 0);
+        }
+        return 0;
+    }
+    if (report)
+        set_error(a.errs, i, SNAPMI_OK, 0, 0, 0);
+    return (uint32_t)((len + kMaxBlock - 1) / kMaxBlock);
+}
+} // namespace
+
+__global__ __launch_bounds__(1024) void k_plan_compress_a(CompressArgs a)
+{
+    __shared__ uint2 wave_tot[16];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nb = i < a.n_streams ? plan_blocks(a, i, true) : 0;
+    uint2 tot;
+    const uint2 ex = wg_scan2(nb, nb ? nb - 1 : 0, wave_tot, &tot);
+    if (i < a.n_streams) {
+        a.blk_first[i] = ex.x;  // within this workgroup, for now
+        a.slot_first[i] = ex.y;
+    }
+    if (threadIdx.x == 0)
+        a.plan_part[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(1024) void k_plan_compress_b(CompressArgs a,
+                                                          uint32_t nparts)
+{
+    __shared__ uint2 wave_tot[16];
+    uint32_t carry_b = 0, carry_s = 0;
+    for (uint32_t base = 0; base < nparts; base += blockDim.x) {
+        const uint32_t j = base + threadIdx.x;
+        const uint2 v = j < nparts ? a.plan_part[j] : make_uint2(0, 0);
+        uint2 tot;
+        const uint2 ex = wg_scan2(v.x, v.y, wave_tot, &tot);
+        if (j < nparts)
+            a.plan_part[j] = make_uint2(carry_b + ex.x, carry_s + ex.y);
+        carry_b += tot.x;
+        carry_s += tot.y;
+    }
+    if (threadIdx.x == 0) {
+        a.blk_first[a.n_streams] = carry_b;
+        a.slot_first[a.n_streams] = carry_s;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_plan_compress_c(CompressArgs a)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_streams)
+        return;
+    const uint2 off = a.plan_part[blockIdx.x];
+    const uint32_t fb = a.blk_first[i] + off.x, fs = a.slot_first[i] + off.y;
+    const uint32_t nb = plan_blocks(a, i, false);
+    // The launch was sized from the host's copy of the lengths; a stream
+    // that does not fit in it is rejected, never overrun.
+    if (nb && ((uint64_t)fb + nb > a.host_blocks ||
+               (uint64_t)fs + (nb - 1) > a.host_slots))
+        set_error(a.errs, i, SNAPMI_E_ARGUMENT, a.in_lens[i], 0, 0);
+    a.blk_first[i] = fb;
+    a.slot_first[i] = fs;
+}
+
+namespace {
+__device__ __forceinline__ uint32_t scan_nblocks(const CompressArgs &a)
+{
+    uint32_t nblocks = a.blk_first[a.n_streams];
+    if (nblocks > a.host_blocks)
+        nblocks = a.host_blocks;
+    if (nblocks > a.blk_hi)
+        nblocks = a.blk_hi;
+    return nblocks;
+}
+// exclusive scan of x over the workgroup (u64), total in *all
+__device__ __forceinline__ uint64_t wg_scan64(uint64_t x, uint64_t *wave_tot,
+                                              uint64_t *all)
+{
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint64_t sx = x;
+    for (uint32_t o = 1; o < 64; o <<= 1) {
+        const uint64_t t = __shfl_up(sx, o);
+        if (lane >= o)
+            sx += t;
+    }
+    if (lane == 63)
+        wave_tot[w] = sx;
+    __syncthreads();
+    uint64_t before = 0, tot = 0;
+    for (uint32_t j = 0; j < (blockDim.x >> 6); j++) {
+        const uint64_t t = wave_tot[j];
+        if (j < w)
+            before += t;
+        tot += t;
+    }
+    __syncthreads();
+    *all = tot;
+    return before + sx - x;
+}
+} // namespace
+
+// part64[0, nparts): workgroup totals, then offsets; part64[nparts]: the carry
+// from the segment in front (blk_off[blk_lo] before it is rewritten)
+__global__ __launch_bounds__(1024) void k_scan_sizes_a(CompressArgs a,
+                                                       uint32_t nparts)
+{
+    __shared__ uint64_t wave_tot[16];
+    const uint32_t nblocks = scan_nblocks(a);
+    const uint32_t i = a.blk_lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        a.scan_part[nparts] = a.blk_lo ? a.blk_off[a.blk_lo] : 0;
+    __syncthreads();
+    const uint64_t x = i < nblocks ? a.blk_size[i] : 0;
+    uint64_t all;
+    const uint64_t ex = wg_scan64(x, wave_tot, &all);
+    if (i < nblocks)
+        a.blk_off[i] = ex;
+    if (threadIdx.x == 0)
+        a.scan_part[blockIdx.x] = all;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_sizes_b(CompressArgs a,
+                                                       uint32_t nparts)
+{
+    __shared__ uint64_t wave_tot[16];
+    const uint32_t nblocks = scan_nblocks(a);
+    uint64_t carry = a.scan_part[nparts];
+    for (uint32_t base = 0; base < nparts; base += blockDim.x) {
+        const uint32_t j = base + threadIdx.x;
+        const uint64_t v = j < nparts ? a.scan_part[j] : 0;
+        uint64_t all;
+        const uint64_t ex = wg_scan64(v, wave_tot, &all);
+        if (j < nparts)
+            a.scan_part[j] = carry + ex;
+        carry += all;
+    }
+    if (threadIdx.x == 0 && nblocks >= a.blk_lo)
+        a.blk_off[nblocks] = carry;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_sizes_c(CompressArgs a)
+{
+    const uint32_t nblocks = scan_nblocks(a);
+    const uint32_t i = a.blk_lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nblocks)
+        a.blk_off[i] += a.scan_part[blockIdx.x];
+}
+
 // Direct encoding (k_encode_tokens wrote every block at its final position):
 // what is left of k_compact is the compressed length of every stream.
 __global__ __launch_bounds__(256) void k_stream_lens(CompressArgs a)

@@ -43,7 +43,7 @@ struct snapmi_ctx {
     bool owns_stream = false;
     std::string last_error;
     // grow-only device scratch of the raw codec
-    snapmi::DevBuf blk_first, slot_first, blk_size, blk_off, slots;
+    snapmi::DevBuf blk_first, slot_first, blk_size, blk_off, slots, plan_part;
     // lane-per-block match finder: tokens, token counts, HBM hash tables
     snapmi::DevBuf tokens, ntok, lane_tables, lane_epochs;
     uint32_t n_lanes = 0;

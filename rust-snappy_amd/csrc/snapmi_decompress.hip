@@ -362,6 +362,67 @@ __global__ __launch_bounds__(1024) void k_plan_decompress(DecompressArgs a)
     }
 }
 
+// The same sort on many workgroups (10.7 M streams: 19 ms of a 33 ms pass in
+// the one-workgroup kernel): histogram, offsets, scatter.  bucket_pos[0, 64)
+// = counts, then cursors.
+__global__ __launch_bounds__(1024) void k_plan_decompress_a(DecompressArgs a)
+{
+    __shared__ uint32_t hist[64];
+    if (a.gate && *a.gate != a.gate_value)
+        return;
+    if (threadIdx.x < 64)
+        hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.n_streams) {
+        const uint64_t len = a.in_lens[i];
+        const uint32_t bk = len ? 63 - (uint32_t)__builtin_clzll(len) : 0;
+        atomicAdd(&hist[63 - bk], 1u); // reversed: big buckets first
+    }
+    __syncthreads();
+    if (threadIdx.x < 64 && hist[threadIdx.x])
+        atomicAdd(&a.bucket_pos[threadIdx.x], hist[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(64) void k_plan_decompress_b(DecompressArgs a)
+{
+    if (a.gate && *a.gate != a.gate_value)
+        return;
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t k = 0; k < 64; k++) {
+            const uint32_t c = a.bucket_pos[k];
+            a.bucket_pos[k] = run;
+            run += c;
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_plan_decompress_c(DecompressArgs a)
+{
+    __shared__ uint32_t hist[64], base[64];
+    if (a.gate && *a.gate != a.gate_value)
+        return;
+    if (threadIdx.x < 64)
+        hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t bk = 0, mine = 0;
+    if (i < a.n_streams) {
+        const uint64_t len = a.in_lens[i];
+        bk = 63 - (len ? 63 - (uint32_t)__builtin_clzll(len) : 0);
+        mine = atomicAdd(&hist[bk], 1u); // my place among this workgroup's
+    }
+    __syncthreads();
+    // one range per bucket and workgroup
+    if (threadIdx.x < 64 && hist[threadIdx.x])
+        base[threadIdx.x] = atomicAdd(&a.bucket_pos[threadIdx.x],
+                                      hist[threadIdx.x]);
+    __syncthreads();
+    if (i < a.n_streams)
+        a.order[base[bk] + mine] = i;
+}
+
 // ---------------------------------------------------------------------
 // One wavefront per raw stream: the wide path.
 //

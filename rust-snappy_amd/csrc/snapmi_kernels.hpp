@@ -39,6 +39,10 @@ struct CompressArgs {
     uint32_t n_lanes;
     // experiment builds (-DSNAPMI_PROFILE) only: 16 u64 cycle counters
     unsigned long long *prof;
+    // partial sums of the many-workgroup scans (k_plan_compress_*,
+    // k_scan_sizes_*): one per 1024 streams / blocks, + 1
+    uint2 *plan_part;
+    unsigned long long *scan_part;
 };
 
 // wavefronts (= hash tables) per persistent compress workgroup: 5 x 32 KiB
@@ -76,6 +80,12 @@ __global__ void k_probe_lds_order(uint32_t *bad);
 __global__ void k_probe_tables(unsigned long long *tables,
                                unsigned long long stride, uint32_t steps);
 __global__ void k_plan_compress(CompressArgs a);
+__global__ void k_plan_compress_a(CompressArgs a);
+__global__ void k_plan_compress_b(CompressArgs a, uint32_t nparts);
+__global__ void k_plan_compress_c(CompressArgs a);
+__global__ void k_scan_sizes_a(CompressArgs a, uint32_t nparts);
+__global__ void k_scan_sizes_b(CompressArgs a, uint32_t nparts);
+__global__ void k_scan_sizes_c(CompressArgs a);
 __global__ void k_compress_blocks(CompressArgs a);
 __global__ void k_compress_block_lds(CompressArgs a);
 __global__ void k_match_blocks(CompressArgs a);
@@ -142,6 +152,9 @@ __global__ void k_stream_pieces(StreamArgs a);
 __global__ void k_stream_finish(StreamArgs a);
 
 __global__ void k_plan_decompress(DecompressArgs a);
+__global__ void k_plan_decompress_a(DecompressArgs a);
+__global__ void k_plan_decompress_b(DecompressArgs a);
+__global__ void k_plan_decompress_c(DecompressArgs a);
 __global__ void k_decompress_streams3(DecompressArgs a);
 __global__ void k_decompress_streams2(DecompressArgs a);
 __global__ void k_decompress_sequential(DecompressArgs a);
