@@ -951,9 +951,30 @@ __global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
     g_u64 *tok = nullptr;
 
     for (;;) {
-        if (!have && !out_of_work) {
+        // Tickets are taken for the whole wavefront at once: the lanes that
+        // need a block count themselves (ballot) and ONE of them adds the
+        // count to the device-wide counter.  (One atomic per lane on one
+        // address is 3.7 ns each, one after the other in the L2: 0.97 ms for
+        // a launch of 262 144 tiny blocks, all of its duration.)
+        const bool need = !have && !out_of_work;
+        const uint64_t M_need = __ballot(need);
+        unsigned long long tbase = 0;
+        if (M_need) {
+            const uint32_t leader = (uint32_t)__builtin_ctzll(M_need);
+            if (threadIdx.x == leader)
+                tbase = atomicAdd((unsigned long long *)a.ticket,
+                                  (unsigned long long)__builtin_popcountll(
+                                      M_need));
+            tbase = ((unsigned long long)rdlane((uint32_t)(tbase >> 32),
+                                                leader)
+                     << 32) |
+                    rdlane((uint32_t)tbase, leader);
+        }
+        if (need) {
             const unsigned long long old =
-                atomicAdd((unsigned long long *)a.ticket, 1ull);
+                tbase + __builtin_amdgcn_mbcnt_hi(
+                            (uint32_t)(M_need >> 32),
+                            __builtin_amdgcn_mbcnt_lo((uint32_t)M_need, 0));
             b = a.blk_lo + (uint32_t)old;
             if ((uint64_t)b + (uint32_t)(old >> 32) >= nblocks) {
                 out_of_work = true;
