@@ -11,7 +11,7 @@ for grp in "$@"; do
   i=$((i+1))
   out=$R/gpurun_out/pmc_${tag}_$i
   rm -rf $out
-  timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out -o p -- python $R/bench.py --steps 1 --warmup 0 --no-cpu --no-extras --no-verify > $out.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out -o p -- python $R/bench.py --steps 1 --warmup 0 --no-cpu --no-extras --no-verify --no-pmc > $out.log 2>&1
   f=$(find $out -name "*counter_collection.csv" | head -1)
   python - "$f" "$tag" <<'PY'
 import csv, sys, collections
