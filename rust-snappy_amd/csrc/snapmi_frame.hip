@@ -1179,7 +1179,7 @@ __global__ void k_frame_meta_init(FrameDecodeArgs a)
 // Device memory -> pinned (device-mapped) host memory by a kernel: 16-byte
 // stores over the host link.  On this platform a hipMemcpyAsync to the host
 // and one from the host, on two streams of one process, ran one after the
-// other (tests/hw/r3 trace: a 0.55 GB copy in took 26 ms behind a 1 GiB copy
+// other (SNAPMI_PIPE_TRACE: a 0.55 GB copy in took 26 ms behind a 1 GiB copy
 // out) although the link is full duplex (tests/hw/pcie_duplex.py: 2 x 48
 // GB/s); a copy kernel beside a copy-engine transfer the other way does
 // overlap.  The destination is brought to a 16-byte boundary first.
