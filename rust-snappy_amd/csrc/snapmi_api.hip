@@ -173,8 +173,13 @@ int snapmi_ctx_create(int device, void *hip_stream, snapmi_ctx **out)
             snapmi_ctx_destroy(ctx);
             return SNAPMI_E_DEVICE;
         }
-        hipLaunchKernelGGL(k_probe_lds_order, dim3(1), dim3(64), 0,
-                           ctx->stream, (uint32_t *)ctx->ticket.p);
+        // (a launch that fills the chip: the properties are checked under
+        // the LDS contention of the real kernels)
+        hipLaunchKernelGGL(k_probe_lds_order,
+                           dim3((uint32_t)(ctx->num_cus > 0 ? ctx->num_cus * 32
+                                                             : 32)),
+                           dim3(64), 0, ctx->stream,
+                           (uint32_t *)ctx->ticket.p);
         if (hipMemcpyAsync(&bad, ctx->ticket.p, 4, hipMemcpyDeviceToHost,
                            ctx->stream) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess) {
@@ -210,6 +215,9 @@ void snapmi_ctx_destroy(snapmi_ctx *ctx)
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
     host_pipe_destroy(ctx);
+    for (void *p : {ctx->pin_in, ctx->pin_out, ctx->pin_desc})
+        if (p)
+            (void)hipHostFree(p);
     if (ctx->h_mail)
         (void)hipHostFree((void *)ctx->h_mail);
     for (DevBuf *b : {&ctx->blk_first, &ctx->slot_first, &ctx->blk_size,
@@ -1174,12 +1182,35 @@ struct OneDesc {
     snapmi_error err;
 };
 
+// host buffers of up to this many bytes go through the context's pinned
+// staging (one host memcpy each way, no pageable device copy)
+constexpr size_t kPinStage = 8u << 20;
+
 // compressed bytes from which the scalar decompress entry points use
 // snapmi_decompress_stream (SNAPMI_LONG_STREAM overrides)
 static const size_t kLongStream = [] {
     const char *e = getenv("SNAPMI_LONG_STREAM");
     return e ? (size_t)atoll(e) : (size_t)(256 << 10);
 }();
+
+// pinned host staging of a context (grow-only): pageable copies go through
+// the runtime's own staging buffer one at a time, process-wide - eight
+// threads calling snappy_compress would queue there
+int pin_reserve(snapmi_ctx *ctx, void **p, size_t *cap, size_t bytes)
+{
+    if (bytes <= *cap)
+        return SNAPMI_OK;
+    if (*p) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipHostFree(*p));
+        *p = nullptr;
+        *cap = 0;
+    }
+    const size_t want = bytes + bytes / 4 + 4096;
+    HIP_TRY(ctx, hipHostMalloc(p, want, hipHostMallocDefault));
+    *cap = want;
+    return SNAPMI_OK;
+}
 
 int run_one(snapmi_ctx *ctx, bool compress, const uint8_t *input,
             size_t input_len, uint8_t *output, size_t output_cap,
@@ -1205,21 +1236,36 @@ int run_one(snapmi_ctx *ctx, bool compress, const uint8_t *input,
         if (need && need < dev_out)
             dev_out = need;
     }
+    // (inputs up to a few MiB are staged through pinned memory of the
+    // context; larger ones are copied from where they lie)
+    const bool staged = input_len <= kPinStage && dev_out <= kPinStage;
     if ((rc = reserve(ctx, ctx->st_in, input_len + 16)) ||
         (rc = reserve(ctx, ctx->st_out, dev_out + 64)) ||
-        (rc = reserve(ctx, ctx->st_desc, sizeof(OneDesc))))
+        (rc = reserve(ctx, ctx->st_desc, sizeof(OneDesc))) ||
+        (rc = pin_reserve(ctx, &ctx->pin_desc, &ctx->pin_desc_cap,
+                          2 * sizeof(OneDesc))) ||
+        (staged && ((rc = pin_reserve(ctx, &ctx->pin_in, &ctx->pin_in_cap,
+                                      input_len + 16)) ||
+                    (rc = pin_reserve(ctx, &ctx->pin_out, &ctx->pin_out_cap,
+                                      dev_out + 64)))))
         return rc;
-    OneDesc h;
-    memset(&h, 0, sizeof h);
-    h.in_ptr = ctx->st_in.p;
-    h.in_len = input_len;
-    h.out_ptr = ctx->st_out.p;
-    h.out_cap = output_cap; // the caller's capacity is what is validated
+    OneDesc *hd = (OneDesc *)ctx->pin_desc; // [0] in, [1] back
+    memset(&hd[0], 0, sizeof hd[0]);
+    hd[0].in_ptr = ctx->st_in.p;
+    hd[0].in_len = input_len;
+    hd[0].out_ptr = ctx->st_out.p;
+    hd[0].out_cap = output_cap; // the caller's capacity is what is validated
     hipStream_t s = ctx->stream;
-    if (input_len)
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->st_in.p, input, input_len,
+    if (input_len) {
+        const void *from = input;
+        if (staged) {
+            memcpy(ctx->pin_in, input, input_len);
+            from = ctx->pin_in;
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->st_in.p, from, input_len,
                                     hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->st_desc.p, &h, sizeof h,
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->st_desc.p, &hd[0], sizeof hd[0],
                                 hipMemcpyHostToDevice, s));
     OneDesc *d = (OneDesc *)ctx->st_desc.p;
     if (compress) {
@@ -1239,9 +1285,16 @@ int run_one(snapmi_ctx *ctx, bool compress, const uint8_t *input,
     }
     if (rc)
         return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(&h, ctx->st_desc.p, sizeof h,
+    HIP_TRY(ctx, hipMemcpyAsync(&hd[1], ctx->st_desc.p, sizeof hd[1],
                                 hipMemcpyDeviceToHost, s));
+    if (staged) {
+        // the result comes along in the same round trip: as much as the
+        // kernels can have written (the length is not known to the host yet)
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->pin_out, ctx->st_out.p,
+                                    dev_out, hipMemcpyDeviceToHost, s));
+    }
     HIP_TRY(ctx, hipStreamSynchronize(s));
+    const OneDesc &h = hd[1];
     if (err)
         *err = h.err;
     if (h.err.kind != SNAPMI_OK)
@@ -1249,9 +1302,13 @@ int run_one(snapmi_ctx *ctx, bool compress, const uint8_t *input,
     if (h.out_len > output_cap)
         return fail_ctx(ctx, SNAPMI_E_DEVICE, "device wrote %llu > cap %zu",
                         (unsigned long long)h.out_len, output_cap);
-    if (h.out_len)
-        HIP_TRY(ctx, hipMemcpy(output, ctx->st_out.p, h.out_len,
-                               hipMemcpyDeviceToHost));
+    if (h.out_len) {
+        if (staged)
+            memcpy(output, ctx->pin_out, h.out_len);
+        else
+            HIP_TRY(ctx, hipMemcpy(output, ctx->st_out.p, h.out_len,
+                                   hipMemcpyDeviceToHost));
+    }
     *written = (size_t)h.out_len;
     return SNAPMI_OK;
 }

@@ -686,7 +686,8 @@ __global__ __launch_bounds__(64) void k_probe_lds_order(uint32_t *bad)
         for (uint32_t i = lane; i < 2048; i += 64)
             tab[i] = (uint16_t)(0x8000u + i);
         __builtin_amdgcn_wave_barrier(); // one wave: its LDS ops are in order
-        uint32_t r = (t * 64 + lane) * 2654435761u + 0x9E3779B9u;
+        uint32_t r = (t * 64 + lane + 131u * blockIdx.x) * 2654435761u +
+                     0x9E3779B9u;
         r ^= r >> 15;
         r *= 0x2C1B3C6Du;
         r ^= r >> 12;
@@ -741,6 +742,38 @@ __global__ __launch_bounds__(64) void k_probe_lds_order(uint32_t *bad)
                     m[b] != (uint8_t)(lane + 1))
                     sfail++;
             }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ... and the decoders' multi-piece form: elements of 1..64 bytes,
+        // whole 16-byte pieces, last piece first (four store instructions);
+        // every byte must end up with the element that owns it.  The launch
+        // fills the chip (32 waves per CU, each with LDS of its own), so the
+        // property is checked under the LDS contention of the real kernels,
+        // not by one idle wave.
+        for (uint32_t t = 0; t < 48; t++) {
+            uint32_t r = (t * 64 + lane + 977u * blockIdx.x) * 2654435761u;
+            r ^= r >> 13;
+            // mostly short elements, some of every length up to 64; the last
+            // lanes short enough that 64 elements fit in the 4 KiB
+            uint32_t len = (t & 1) ? 1 + (r >> 8) % 64 : 1 + (r >> 8) % 20;
+            if (t >= 40)
+                len = 17 + (r >> 8) % 48;
+            const uint32_t end = wave_inclusive_scan(len) + t;
+            const uint32_t pos = end - len;
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t c = 48;; c -= 16) {
+                if (c < len && pos + c + 16 <= 4096) {
+                    u32x4 x;
+                    x.x = x.y = x.z = x.w = 0x01010101u * (lane + 1);
+                    __builtin_memcpy(m + pos + c, &x, 16);
+                }
+                if (c == 0)
+                    break;
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t k = 0; k < len; k++)
+                if (pos + k < 4096 - 16 && m[pos + k] != (uint8_t)(lane + 1))
+                    sfail++;
             __builtin_amdgcn_wave_barrier();
         }
         if (__ballot(sfail != 0) != 0 && lane == 0)

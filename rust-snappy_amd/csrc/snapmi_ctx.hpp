@@ -27,6 +27,9 @@ struct snapmi_ctx {
     // 256 bytes of pinned, device-mapped host memory: kernels post small
     // results here (no copy-engine round trip behind a bulk copy)
     volatile uint32_t *h_mail = nullptr;
+    // pinned host staging of the scalar (host-pointer) entry points
+    void *pin_in = nullptr, *pin_out = nullptr, *pin_desc = nullptr;
+    size_t pin_in_cap = 0, pin_out_cap = 0, pin_desc_cap = 0;
     // slices of the host-buffer frame calls: input bytes per encode slice,
     // data chunks per decode slice
     // (measured, profiles/r3_host_pipeline.txt: the match finder's latency
