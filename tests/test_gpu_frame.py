@@ -846,3 +846,46 @@ def test_frame_compress_chunks_on_device_buffers(ctx):
     assert out[:n].cpu().numpy().tobytes() == want
     out, n = frame.compress_chunks_device(ctx, d_in, lens, ident=False)
     assert out[:n].cpu().numpy().tobytes() == want[10:]
+
+
+def test_host_calls_on_pinned_buffers(ctx):
+    """snapmi_frame_encode_host / _decode_host on pinned memory
+    (snapmi_host_alloc): the sliced pipeline (small slices forced), the copy
+    kernel that takes decoded bytes home - to an UNALIGNED destination - and
+    the bytes against the oracle."""
+    import ctypes as C
+    from rust_snappy_amd import _lib, frame
+    L = _lib.load()
+    data = b"".join(d for _, d in O.corpus_round())[:3_000_001]
+    n = len(data)
+    nch = (n + 65535) // 65536
+    lens = np.full(nch, 65536, dtype=np.uint32)
+    lens[-1] = n - (nch - 1) * 65536
+    h_in = frame.HostBuffer(n)
+    h_in.array[:] = np.frombuffer(data, dtype=np.uint8)
+    h_out = frame.HostBuffer(10 + n + 8 * nch)
+    ctx.set_option("host_encode_slice", 1 << 20)       # three slices
+    ctx.set_option("host_decode_slice_chunks", 7)      # seven slices
+    try:
+        k = frame.encode_host_into(ctx, h_in.view, lens, h_out)
+        want = O.frame_compress(data)
+        assert bytes(h_out.view[:k]) == want
+        for by_kernel in (1, 0):
+            ctx.set_option("host_copy_kernel", by_kernel)
+            h_back = frame.HostBuffer(nch * 65536 + 64)
+            stale = (C.c_uint8 * 10)()
+            written, consumed = C.c_size_t(0), C.c_size_t(0)
+            err = _lib.SnapmiError()
+            rc = L.snapmi_frame_decode_host(
+                ctx._h, C.c_void_p(h_out.ptr), k, 2, stale,
+                C.c_void_p(h_back.ptr + 3), nch * 65536, C.byref(written),
+                C.byref(consumed), C.byref(err))
+            assert rc == 0 and written.value == n and consumed.value == k
+            assert bytes(h_back.view[3:3 + n]) == data
+            h_back.close()
+    finally:
+        ctx.set_option("host_encode_slice", 2048 << 20)
+        ctx.set_option("host_decode_slice_chunks", 8192)
+        ctx.set_option("host_copy_kernel", 1)
+        h_in.close()
+        h_out.close()
