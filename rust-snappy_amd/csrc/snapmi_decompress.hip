@@ -1066,6 +1066,9 @@ __device__ __forceinline__ bool decode_windows2(Wide &x, const uint32_t lane)
 #define SNAPMI_G3 4
 #endif
 constexpr uint32_t kG3 = SNAPMI_G3;
+static_assert(kG3 == 2 || kG3 == 4,
+              "positions in a window are masked with 64 kG3 - 1; 8 groups do "
+              "not fit 64 VGPRs");
 // the last position (64 kG3 - 1), a tag, 60 literal bytes read as whole
 // 16-byte pieces
 constexpr uint32_t kTail3 = 64 * kG3 + 1 + 64 + 16;
@@ -1354,6 +1357,26 @@ __device__ __forceinline__ bool decode_windows3(Wide &x, const uint32_t lane,
         // the late elements: lane k = byte k of the element (exactly its
         // bytes, addressed bytewise: no mirror)
         uint64_t late = M_late;
+        if ((M_late & ~M_ring) == 0) {
+            // (the usual case: every late source is in the ring)
+            while (late) {
+                COUNT(x.n_dep);
+                const uint32_t i = (uint32_t)__builtin_ctzll(late);
+                late &= late - 1;
+                const uint32_t F = rdlane(dstp, i), ni = rdlane(olen, i);
+                const uint32_t qi = rdlane(q, i), oi = F - qi;
+                uint32_t kk = lane;
+                if (oi < ni) { // overlapping: byte k repeats byte k mod oi
+                    const uint32_t quo = (uint32_t)(
+                        ((float)lane + 0.5f) *
+                        __builtin_amdgcn_rcpf((float)oi));
+                    kk = lane - quo * oi;
+                }
+                if (lane < ni)
+                    rg[(F + lane) & (kRing2 - 1)] =
+                        rg[(qi + kk) & (kRing2 - 1)];
+            }
+        }
         while (late) {
             COUNT(x.n_dep);
             const uint32_t i = (uint32_t)__builtin_ctzll(late);
