@@ -873,8 +873,9 @@ int launch_decompress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     a.modes = d_modes;
     a.n_streams = (uint32_t)n;
     {
-        // (+ 64 bucket counters of the many-workgroup sort behind the order)
-        int rc = reserve(ctx, ctx->order, (n + 64) * sizeof(uint32_t));
+        // (+ 64 bucket counters of the many-workgroup sort behind the order,
+        // + the number of streams that are not tiny)
+        int rc = reserve(ctx, ctx->order, (n + 72) * sizeof(uint32_t));
         if (rc)
             return rc;
     }
@@ -912,9 +913,15 @@ int launch_decompress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     else if (ctx->decode_kernel == 2)
         hipLaunchKernelGGL(k_decompress_streams2, dim3((uint32_t)n), dim3(64),
                            0, s, a);
-    else
+    else {
         hipLaunchKernelGGL(k_decompress_streams3, dim3((uint32_t)n), dim3(64),
                            0, s, a);
+        // the streams of fewer than 256 compressed bytes, one per lane (how
+        // many there are only the device knows: workgroups without any leave
+        // at once, in both launches)
+        hipLaunchKernelGGL(k_decompress_tiny,
+                           dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, s, a);
+    }
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], s));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[3], s));
     HIP_TRY(ctx, hipGetLastError());

@@ -325,6 +325,11 @@ __global__ __launch_bounds__(256) void k_decompress_len(DecompressArgs a)
     set_error(a.errs, i, SNAPMI_OK, 0, 0, 0);
 }
 
+// Streams of fewer than kTiny = 2^kTinyLog2 compressed bytes are decoded one
+// per LANE (decode_tiny below); the sort puts them last, and the plan leaves
+// the number of streams in front of them in bucket_pos[64].
+constexpr uint32_t kTinyLog2 = 8;
+
 // ---------------------------------------------------------------------
 // Plan: dispatch order.  Streams differ in size by orders of magnitude and a
 // stream is decoded by one wavefront, so the longest streams must start
@@ -349,6 +354,8 @@ __global__ __launch_bounds__(1024) void k_plan_decompress(DecompressArgs a)
     if (threadIdx.x == 0) {
         uint32_t run = 0;
         for (uint32_t k = 0; k < 64; k++) {
+            if (k == 64 - kTinyLog2) // streams of kTiny bytes and more
+                a.bucket_pos[64] = run;
             const uint32_t c = hist[k];
             hist[k] = run;
             run += c;
@@ -391,6 +398,8 @@ __global__ __launch_bounds__(64) void k_plan_decompress_b(DecompressArgs a)
     if (threadIdx.x == 0) {
         uint32_t run = 0;
         for (uint32_t k = 0; k < 64; k++) {
+            if (k == 64 - kTinyLog2)
+                a.bucket_pos[64] = run;
             const uint32_t c = a.bucket_pos[k];
             a.bucket_pos[k] = run;
             run += c;
@@ -1427,6 +1436,119 @@ __device__ __forceinline__ bool decode_windows3(Wide &x, const uint32_t lane,
 }
 } // namespace
 
+// ---------------------------------------------------------------------
+// Tiny streams, one per LANE: the reference's loop (src/decompress.rs:75-95,
+// 130-343) as it stands, every lane on a stream of its own.  A wavefront per
+// stream spends ten microseconds of dependent round trips (descriptors,
+// header, first window, flush) on a stream of 150 bytes; here 64 streams
+// share them.  Literals move 16 bytes at a time where both buffers allow it,
+// copies bytewise (they may overlap).  Errors and their fields are the
+// reference's, lane by lane.
+// ---------------------------------------------------------------------
+namespace {
+#define SNAPMI_TINY_FAIL(kind, fa, fb, fc)                                    \
+    do {                                                                      \
+        set_error(a.errs, st, (kind), (fa), (fb), (fc));                      \
+        a.out_lens[st] = 0;                                                   \
+        return;                                                               \
+    } while (0)
+
+__device__ __forceinline__ void decode_tiny(const DecompressArgs &a,
+                                            const uint64_t st)
+{
+    gcptr in = (gcptr)a.in_ptrs[st];
+    const uint64_t in_len = a.in_lens[st];
+    gptr dst = (gptr)a.out_ptrs[st];
+    const uint32_t mode = a.modes ? a.modes[st] : 0;
+    const uint64_t cap = a.out_caps[st];
+    if (mode == 1) { // stored frame chunk (reference src/read.rs:173-199)
+        if (in_len > cap)
+            SNAPMI_TINY_FAIL(SNAPMI_BUFFER_TOO_SMALL, cap, in_len, 0);
+        for (uint64_t i = 0; i < in_len; i++)
+            dst[i] = in[i];
+        set_error(a.errs, st, SNAPMI_OK, 0, 0, 0);
+        a.out_lens[st] = in_len;
+        return;
+    }
+    uint32_t hdr = 0;
+    uint64_t dst_len = 0;
+    if (mode == 2) { // headerless piece: exactly out_caps bytes
+        dst_len = cap;
+    } else {
+        if (in_len == 0)
+            SNAPMI_TINY_FAIL(SNAPMI_EMPTY, 0, 0, 0);
+        if (read_header(in, in_len, &hdr, &dst_len, a.errs, st) != SNAPMI_OK) {
+            a.out_lens[st] = 0;
+            return;
+        }
+        if (dst_len > cap)
+            SNAPMI_TINY_FAIL(SNAPMI_BUFFER_TOO_SMALL, cap, dst_len, 0);
+    }
+    gcptr src = in + hdr;
+    const uint64_t src_len = in_len - hdr;
+    uint64_t s = 0, d = 0;
+    while (s < src_len) {
+        const uint32_t tag = src[s];
+        s += 1;
+        if ((tag & 3) == 0) {
+            // read_literal, src/decompress.rs:161-228
+            uint64_t len = (tag >> 2) + 1;
+            if (len >= 61) {
+                if (s + 4 > src_len)
+                    SNAPMI_TINY_FAIL(SNAPMI_LITERAL, 4, src_len - s,
+                                     dst_len - d);
+                const uint32_t nb = (uint32_t)len - 60;
+                const uint32_t raw = ld32u(src + s);
+                len = (uint64_t)(nb == 4 ? raw
+                                         : raw & ((1u << (8 * nb)) - 1)) +
+                      1;
+                s += nb;
+            }
+            if (src_len - s < len || dst_len - d < len)
+                SNAPMI_TINY_FAIL(SNAPMI_LITERAL, len, src_len - s,
+                                 dst_len - d);
+            uint64_t i = 0;
+            for (; i + 16 <= len; i += 16) {
+                const u32x4 t = ld128g(src + s + i);
+                __builtin_memcpy(dst + d + i, &t, 16);
+            }
+            for (; i < len; i++)
+                dst[d + i] = src[s + i];
+            s += len;
+            d += len;
+        } else {
+            // read_copy + TagEntry::offset, src/decompress.rs:233-343,433-474
+            const uint32_t kind = tag & 3;
+            const uint32_t nb = kind == 1 ? 1 : (kind == 2 ? 2 : 4);
+            const uint32_t len =
+                kind == 1 ? 4 + ((tag >> 2) & 7) : 1 + (tag >> 2);
+            uint64_t offset = kind == 1 ? (uint64_t)(tag >> 5) << 8 : 0;
+            if (s + nb > src_len)
+                SNAPMI_TINY_FAIL(SNAPMI_COPY_READ, nb, src_len - s, 0);
+            uint32_t v = 0;
+            for (uint32_t k = 0; k < nb; k++)
+                v |= (uint32_t)src[s + k] << (8 * k);
+            offset |= v;
+            s += nb;
+            if (d <= offset - 1) // wrapping, also catches offset == 0
+                SNAPMI_TINY_FAIL(SNAPMI_OFFSET, offset, d, 0);
+            const uint64_t end = d + len;
+            if (end > dst_len)
+                SNAPMI_TINY_FAIL(SNAPMI_COPY_WRITE, len, dst_len - d, 0);
+            // (bytewise and in order: the source may overlap the
+            // destination; a lane's own stores are visible to its loads)
+            for (uint32_t k = 0; k < len; k++)
+                dst[d + k] = dst[d - offset + k];
+            d = end;
+        }
+    }
+    if (d != dst_len)
+        SNAPMI_TINY_FAIL(SNAPMI_HEADER_MISMATCH, dst_len, d, 0);
+    set_error(a.errs, st, SNAPMI_OK, 0, 0, 0);
+    a.out_lens[st] = dst_len;
+}
+} // namespace
+
 // 8 waves per SIMD (64 VGPRs, 5 KiB of LDS each): a window is a chain of
 // LDS / HBM round trips, and two more waves to switch to are worth more than
 // a few spilled dwords (36.0 -> 32.2 ms at cfg2 for the second generation).
@@ -1442,6 +1564,10 @@ __global__ __launch_bounds__(64) void k_decompress_streams3(DecompressArgs a)
     uint8_t ring_mem[kRing2 + 16 + 64 * kG3 + 64];
     const uint32_t lane = threadIdx.x;
     if (a.gate && uni64(*a.gate) != a.gate_value)
+        return;
+    // workgroups [0, n_big): one stream each; the tiny streams behind them
+    // (the sort put them last) are k_decompress_tiny's, one per LANE
+    if (blockIdx.x >= uni(a.bucket_pos[64]))
         return;
     Wide x;
     if (!open_stream(a, lane, x, (l_u8 *)ring_mem))
@@ -1483,6 +1609,124 @@ __global__ __launch_bounds__(64) void k_decompress_sequential(DecompressArgs a)
     if (!open_stream(a, lane, x, (l_u8 *)ring_mem))
         return;
     decode_sequential(a, x.st, lane, x.src, x.src_len, x.dst, x.dst_len, 0, 0);
+}
+
+// Tiny streams (fewer than kTiny compressed bytes), one per LANE.  A stream
+// whose output is tiny as well (the usual case) is staged in LDS - input and
+// output dword-interleaved across the lanes, so that lane l's byte k is at
+// ((k >> 2) * 64 + l) * 4 + (k & 3) and the lanes of an access fall on
+// different banks - decoded there with the reference's loop, and stored with
+// 16-byte accesses: four LDS latencies per byte moved instead of two HBM
+// round trips.  The others run the same loop on global memory.
+__global__ __launch_bounds__(64) void k_decompress_tiny(DecompressArgs a)
+{
+    constexpr uint32_t kT = 1u << kTinyLog2;
+    __shared__ __attribute__((aligned(16))) uint32_t tin[kT / 4 * kWave];
+    __shared__ __attribute__((aligned(16))) uint32_t tout[kT / 4 * kWave];
+    if (a.gate && uni64(*a.gate) != a.gate_value)
+        return;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n_big = uni(a.bucket_pos[64]);
+    const uint64_t i = n_big + (uint64_t)blockIdx.x * kWave + lane;
+    if ((uint64_t)n_big + (uint64_t)blockIdx.x * kWave >= a.n_streams)
+        return;
+    if (i >= a.n_streams)
+        return;
+    const uint64_t st = a.order[i];
+    gcptr in = (gcptr)a.in_ptrs[st];
+    const uint32_t in_len = (uint32_t)a.in_lens[st]; // < kT
+    const uint32_t mode = a.modes ? a.modes[st] : 0;
+    // the header decides: a stream with a tiny output goes through LDS
+    uint64_t dl = 0;
+    uint32_t hdr = 0;
+    bool small = mode == 0 && in_len > 0;
+    if (small) {
+        hdr = read_varint(in, in_len, &dl);
+        small = hdr != 0 && dl <= kT && dl <= a.out_caps[st];
+    }
+    if (!small) {
+        decode_tiny(a, st);
+        return;
+    }
+    typedef __attribute__((address_space(3))) uint32_t l_u32t;
+    l_u8 *const bin = (l_u8 *)(l_u32t *)tin;
+    l_u8 *const bout = (l_u8 *)(l_u32t *)tout;
+    auto at = [lane](uint32_t k) { return ((k >> 2) * kWave + lane) * 4 + (k & 3); };
+    // stage the elements: whole dwords (reads stay inside the stream: the
+    // last partial dword bytewise)
+    const uint32_t slen = in_len - hdr;
+    gcptr src = in + hdr;
+    {
+        uint32_t k = 0;
+        for (; k + 4 <= slen; k += 4)
+            *(l_u32t *)(bin + at(k)) = ld32u(src + k);
+        for (; k < slen; k++)
+            bin[at(k)] = src[k];
+    }
+    const uint32_t dlen = (uint32_t)dl;
+    uint32_t s = 0, d = 0;
+    while (s < slen) {
+        const uint32_t tag = bin[at(s)];
+        s += 1;
+        if ((tag & 3) == 0) {
+            uint32_t len = (tag >> 2) + 1;
+            if (len >= 61) {
+                if (s + 4 > slen)
+                    SNAPMI_TINY_FAIL(SNAPMI_LITERAL, 4, slen - s, dlen - d);
+                const uint32_t nb = len - 60;
+                uint32_t raw = 0;
+                for (uint32_t k = 0; k < 4; k++)
+                    raw |= (uint32_t)bin[at(s + k)] << (8 * k);
+                // (u64: a length field of 0xFFFFFFFF + 1 must not wrap)
+                const uint64_t l64 =
+                    (uint64_t)(nb == 4 ? raw : raw & ((1u << (8 * nb)) - 1)) +
+                    1;
+                s += nb;
+                if (slen - s < l64 || dlen - d < l64)
+                    SNAPMI_TINY_FAIL(SNAPMI_LITERAL, l64, slen - s, dlen - d);
+                len = (uint32_t)l64;
+            } else if (slen - s < len || dlen - d < len) {
+                SNAPMI_TINY_FAIL(SNAPMI_LITERAL, len, slen - s, dlen - d);
+            }
+            for (uint32_t k = 0; k < len; k++)
+                bout[at(d + k)] = bin[at(s + k)];
+            s += len;
+            d += len;
+        } else {
+            const uint32_t kind = tag & 3;
+            const uint32_t nb = kind == 1 ? 1 : (kind == 2 ? 2 : 4);
+            const uint32_t len =
+                kind == 1 ? 4 + ((tag >> 2) & 7) : 1 + (tag >> 2);
+            uint64_t offset = kind == 1 ? (uint64_t)(tag >> 5) << 8 : 0;
+            if (s + nb > slen)
+                SNAPMI_TINY_FAIL(SNAPMI_COPY_READ, nb, slen - s, 0);
+            uint32_t v = 0;
+            for (uint32_t k = 0; k < nb; k++)
+                v |= (uint32_t)bin[at(s + k)] << (8 * k);
+            offset |= v;
+            s += nb;
+            if (d <= offset - 1) // wrapping, also catches offset == 0
+                SNAPMI_TINY_FAIL(SNAPMI_OFFSET, offset, d, 0);
+            if (d + len > dlen)
+                SNAPMI_TINY_FAIL(SNAPMI_COPY_WRITE, len, dlen - d, 0);
+            const uint32_t from = d - (uint32_t)offset;
+            for (uint32_t k = 0; k < len; k++)
+                bout[at(d + k)] = bout[at(from + k)];
+            d += len;
+        }
+    }
+    if (d != dlen)
+        SNAPMI_TINY_FAIL(SNAPMI_HEADER_MISMATCH, dlen, d, 0);
+    gptr dst = (gptr)a.out_ptrs[st];
+    {
+        uint32_t k = 0;
+        for (; k + 4 <= dlen; k += 4)
+            st32u(dst + k, *(const l_u32t *)(bout + at(k)));
+        for (; k < dlen; k++)
+            dst[k] = bout[at(k)];
+    }
+    set_error(a.errs, st, SNAPMI_OK, 0, 0, 0);
+    a.out_lens[st] = dlen;
 }
 
 // ---------------------------------------------------------------------

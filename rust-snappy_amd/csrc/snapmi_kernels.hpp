@@ -158,6 +158,7 @@ __global__ void k_plan_decompress_c(DecompressArgs a);
 __global__ void k_decompress_streams3(DecompressArgs a);
 __global__ void k_decompress_streams2(DecompressArgs a);
 __global__ void k_decompress_sequential(DecompressArgs a);
+__global__ void k_decompress_tiny(DecompressArgs a);
 __global__ void k_decompress_len(DecompressArgs a);
 
 } // namespace snapmi
