@@ -773,3 +773,95 @@ def test_many_small_streams_plan_on_many_workgroups(cctx, ctx):
     assert [int(x) for x in blens] == [len(x) for x in ins]
     for i in check:
         assert back.stream_bytes(i, blens[i]) == ins[i], i
+
+
+def test_decoder_boundaries_of_the_third_generation(ctx):
+    """Streams sized around every threshold the third-generation path has -
+    256 compressed bytes (lane-per-stream kernel, staged in LDS when the
+    output is at most 256 bytes too), 337 bytes of input left (kTail3: the
+    window loops change hands), literals of 60 / 61 bytes (the latter end a
+    window), windows cut at 2 048 output bytes, copies around the 4 KiB ring
+    and its 2 KiB of safe history - valid and mutated, against the oracle:
+    bytes, or the error variant with all of its fields."""
+    import foreign
+    rng = random.Random(20263)
+    txt = (O.CORPUS / "alice29.txt").read_bytes()
+    html = (O.CORPUS / "html").read_bytes()
+    comps = []
+    # compressed sizes around 256 and 337 + k * 256: take prefixes of text
+    # whose compressed length lands on the wanted size
+    want_sizes = set(list(range(240, 275)) + list(range(325, 350)) +
+                     [592, 593, 594, 848, 849, 850, 1104, 1105, 1106])
+    n = 200
+    seen = set()
+    while want_sizes - seen and n < 4000:
+        c = O.compress(txt[:n])
+        if len(c) in want_sizes and len(c) not in seen:
+            seen.add(len(c))
+            comps.append(c)
+        n += 1
+    assert len(seen) > 40
+    # tiny inputs with tiny and not so tiny outputs (RLE: 64-byte copies)
+    for k in (1, 2, 5, 60, 61, 64, 65, 200, 255, 256, 257, 300, 4000, 20000):
+        comps.append(O.compress(b"x" * k))
+        comps.append(O.compress(bytes(rng.randrange(256) for _ in range(k))))
+        comps.append(O.compress((b"ab" * k)[:k]))
+    # literal lengths around 60 / 61 between copies, hand-made
+    for ll in (59, 60, 61, 62, 64, 65, 100, 255, 256, 257):
+        body = bytes(rng.randrange(256) for _ in range(ll))
+        out = body + body[:40]
+        el = foreign.lit(body) + foreign.copy(ll, 40 if ll >= 40 else 4, 2) \
+            if ll >= 4 else foreign.lit(body)
+        if ll >= 40:
+            comps.append(foreign.varint(len(out)) + el)
+    # far / near copies around the ring's limits, many per window
+    data = bytearray(bytes(rng.randrange(256) for _ in range(9000)))
+    els, outb = [foreign.lit(bytes(data[:60]))], bytearray(data[:60])
+    pos = 60
+    while pos < 9000:
+        els.append(foreign.lit(bytes(data[pos:pos + 30])))
+        outb += data[pos:pos + 30]
+        pos += 30
+        for off in (1, 7, 15, 16, 17, 63, 64, 2000, 2031, 2032, 2033, 2047,
+                    2048, 2049, 4079, 4080, 4081, 4095, 4096, 4097, 8000):
+            if off <= len(outb):
+                ln = rng.choice([4, 11, 16, 17, 33, 64])
+                els.append(foreign.copy(off, ln, 2))
+                for _ in range(ln):
+                    outb.append(outb[-off])
+    comps.append(foreign.varint(len(outb)) + b"".join(els))
+    assert O.decompress(comps[-1]) == bytes(outb)
+    # html: wide windows (many long copies -> the 2 048-byte cut)
+    comps.append(O.compress(html))
+    valid = list(comps)
+    # mutations of everything above
+    for c in valid:
+        for _ in range(6):
+            b = bytearray(c)
+            kind = rng.random()
+            if kind < 0.5 and len(b) > 1:
+                for _ in range(rng.randrange(1, 4)):
+                    b[rng.randrange(len(b))] = rng.randrange(256)
+            elif kind < 0.8 and len(b) > 2:
+                b = b[:rng.randrange(1, len(b))]
+            else:
+                p = rng.randrange(len(b) + 1)
+                b[p:p] = bytes([rng.randrange(256)])
+            comps.append(bytes(b))
+    caps = []
+    for m in comps:
+        try:
+            caps.append(min(O.decompress_len(m), 1 << 20))
+        except O.SnapError:
+            caps.append(512)
+    got, errs = gpu_decompress(ctx, comps, caps)
+    ok = bad = 0
+    for m, cap, g, e in zip(comps, caps, got, errs):
+        try:
+            want = O.decompress(m, cap)
+            assert e[0] == 0 and g == want, (len(m), e)
+            ok += 1
+        except O.SnapError as oe:
+            assert (oe.kind, oe.a, oe.b, oe.c) == e, (len(m), e, oe)
+            bad += 1
+    assert ok >= len(valid) and bad > 100
