@@ -310,18 +310,27 @@ def files(args, ctx, dev):
 def tiny(args, ctx, dev):
     """The tiny-stream regime on its own: zflat03 (the first 200 bytes of
     fireworks.jpeg, bench/src/bench.rs:91) tiled to --gib = 10.7 M streams
-    at 2 GiB."""
+    at 2 GiB; beside it the first 200 bytes of alice29.txt (tiny streams
+    that do compress: literals and copies in every lane)."""
     import oracle_lib as O
+    res = None
     for bench_id, blob in O.corpus_round():
         if len(blob) == 200:
             n, c, reps, te, td = raw_tiles(ctx, dev, blob, args.gib,
                                            args.steps, O.compress(blob))
-            return {"config": f"{bench_id} tiled to {args.gib} GiB",
-                    "streams": reps, "ratio": round(c / n, 4),
-                    "compress_gibs": round(n / GIB / te, 2),
-                    "decompress_gibs": round(n / GIB / td, 2),
-                    "compress_ms": round(te * 1e3, 2),
-                    "decompress_ms": round(td * 1e3, 2)}
+            res = {"config": f"{bench_id} tiled to {args.gib} GiB",
+                   "streams": reps, "ratio": round(c / n, 4),
+                   "compress_gibs": round(n / GIB / te, 2),
+                   "decompress_gibs": round(n / GIB / td, 2),
+                   "compress_ms": round(te * 1e3, 2),
+                   "decompress_ms": round(td * 1e3, 2)}
+    text = (O.CORPUS / "alice29.txt").read_bytes()[:200]
+    n, c, reps, te, td = raw_tiles(ctx, dev, text, args.gib, args.steps,
+                                   O.compress(text))
+    res["text_200"] = {"ratio": round(c / n, 4),
+                       "compress_gibs": round(n / GIB / te, 2),
+                       "decompress_gibs": round(n / GIB / td, 2)}
+    return res
 
 
 def _host_corpus(gib):
@@ -607,6 +616,9 @@ def main():
                          "one JSON line each with a \"name\" key; a config "
                          "that fails prints {\"name\", \"error\"} and the "
                          "rest still run (bench.py's extras)")
+    ap.add_argument("--option", action="append", default=[],
+                    help="name=value: snapmi_ctx_set_option on the context "
+                         "(experiments: --option tiny_stream_kernel=0)")
     args = ap.parse_args()
     import __graft_entry__ as g
     g.build()
@@ -619,6 +631,9 @@ def main():
     dev = torch.device("cuda", local)
     ctx = raw.Context(local)
     ctx.set_option("lane_table_budget_pct", 75)   # the benchmark owns its GPU
+    for item in args.option:
+        name, value = item.split("=")
+        ctx.set_option(name, int(value))
     table = {"cfg3": cfg3, "cfg5": cfg5, "files": files, "pcie": pcie,
              "adapters": adapters, "stream": stream, "cfg4": cfg4,
              "tiny": tiny}

@@ -131,6 +131,10 @@ const char *snapmi_version(void);
  *                          CU run one block per CU with table AND input block
  *                          in LDS; 0 never; 2 whenever the wavefront kernel
  *                          would run
+ *   "tiny_stream_kernel"   1 (default): streams of fewer than 256 bytes are
+ *                          compressed one per LANE, input, table and output
+ *                          in LDS (k_compress_tiny); 0: they are one-block
+ *                          streams of the block kernels
  *   "lane_min_blocks"      batches with at least this many 64 KiB blocks use
  *                          the lane-per-block kernel (default 8192)
  *   "lane_segment_blocks"  blocks per lane-kernel launch (default 262144 =

@@ -273,6 +273,9 @@ int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value)
     else if (strcmp(name, "small_batch_kernel") == 0 && value >= 0 &&
              value <= 2)
         ctx->small_batch_kernel = (int)value;
+    else if (strcmp(name, "tiny_stream_kernel") == 0 && value >= 0 &&
+             value <= 1)
+        ctx->tiny_stream_kernel = (int)value;
     else if (strcmp(name, "frame_parallel_walk_min") == 0 && value >= 0)
         ctx->frame_parallel_walk_min = (uint64_t)value;
     else if (strcmp(name, "host_copy_kernel") == 0 && value >= 0 && value <= 3)
@@ -436,6 +439,8 @@ int snapmi_compress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
         const uint64_t len = h_in_lens[i];
         if (len == 0 || max_compress_len_u64(len) == 0)
             continue;
+        if (ctx->tiny_stream_kernel && len < kTinyCompress)
+            continue; // k_compress_tiny's: no block
         const uint64_t nb = (len + kMaxBlock - 1) / kMaxBlock;
         blocks += nb;
         slots += nb - 1;
@@ -516,6 +521,7 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     a.lane_stride = kMaxTable;
     a.n_lanes = 0;
     a.tok_base = 0;
+    a.tiny_limit = ctx->tiny_stream_kernel ? kTinyCompress : 0;
     // Small batches are latency-bound: the wavefront kernel finishes a block
     // in ~2 ms, a lane needs tens of ms.  Large batches are throughput-bound
     // and go to the lane-per-block kernel.
@@ -742,6 +748,12 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
         hipLaunchKernelGGL(k_plan_compress, dim3(1), dim3(1024), 0, s, a);
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], s));
+    // streams under 256 bytes, one per lane (a wavefront of streams that are
+    // all larger returns at once: 16 384 idle wavefronts for a million 64 KiB
+    // chunks)
+    if (a.tiny_limit)
+        hipLaunchKernelGGL(k_compress_tiny, dim3((uint32_t)((n + 63) / 64)),
+                           dim3(64), 0, s, a);
     if (blocks) {
         hipStream_t ws = s; // stream of the wavefront kernel
         if (waves_mode) {

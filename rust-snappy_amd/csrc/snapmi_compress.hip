@@ -895,6 +895,110 @@ __global__ __launch_bounds__(64) void k_compress_block_lds(CompressArgs a)
 }
 
 // ---------------------------------------------------------------------
+// K1t: streams of fewer than 256 bytes, ONE PER LANE, everything in LDS.
+//
+// A block of a couple of hundred bytes costs the lane kernel ~190 rounds of
+// an HBM (or L2) round trip, and the wavefront kernels a whole wavefront for
+// ~100 probes.  Its whole state is tiny, though: the input, the reference's
+// smallest table (256 entries, src/compress.rs:491-518 - and a position
+// fits a byte) and the output (never more than the input + 4 bytes,
+// snapmi_tiny.hpp) are three columns of 64 / 64 / 65 dwords per lane, 48.25
+// KiB per wavefront, three wavefronts per CU.  Every access of the parse is
+// then an LDS access of ~100 cycles and the lane runs the reference's loop
+// as it is written (snapmi_tiny.hpp: the test suite runs the same text over
+// byte arrays on the CPU, tests/test_tiny_lane_cpu.py).  The columns are dword-
+// interleaved (byte k of lane l at ((k >> 2) * 64 + l) * 4 + (k & 3)), so
+// lanes at the same position hit 64 different banks.
+// k_plan_compress gives these streams no blocks (CompressArgs::tiny_limit),
+// so the block kernels never see them.
+// ---------------------------------------------------------------------
+namespace {
+struct TinyColumns {
+    typedef __attribute__((address_space(3))) uint32_t l_u32;
+    typedef __attribute__((address_space(3))) uint8_t l_u8;
+    l_u32 *in, *tb, *out; // this lane's columns: dword w at [w * 64]
+    __device__ __forceinline__ static uint32_t at(uint32_t k)
+    {
+        return (k >> 2) * 256 + (k & 3); // byte offset inside the column
+    }
+    __device__ __forceinline__ uint32_t in8(uint32_t k) const
+    {
+        return ((const l_u8 *)in)[at(k)];
+    }
+    __device__ __forceinline__ uint32_t in32(uint32_t k) const
+    {
+        const l_u32 *w = in + (k >> 2) * 64; // k + 4 <= n <= 255: w[64] exists
+        return __builtin_amdgcn_alignbyte(w[64], w[0], k & 3);
+    }
+    __device__ __forceinline__ uint32_t tab(uint32_t h) const
+    {
+        return ((const l_u8 *)tb)[at(h)];
+    }
+    __device__ __forceinline__ void tab_set(uint32_t h, uint32_t v)
+    {
+        ((l_u8 *)tb)[at(h)] = (uint8_t)v;
+    }
+    __device__ __forceinline__ void out8(uint32_t k, uint32_t v)
+    {
+        ((l_u8 *)out)[at(k)] = (uint8_t)v;
+    }
+    __device__ __forceinline__ void out32(uint32_t k, uint32_t v)
+    {
+        out[(k >> 2) * 64] = v;
+    }
+};
+} // namespace
+
+__global__ __launch_bounds__(64) void k_compress_tiny(CompressArgs a)
+{
+    constexpr uint32_t kW = kTinyCompress / 4;         // dwords per column
+    constexpr uint32_t kWo = (kTinyOutMax + 3) / 4;    // 65
+    __shared__ uint32_t tin[kW * 64];
+    __shared__ uint32_t ttab[kW * 64];
+    __shared__ uint32_t tout[kWo * 64];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t i = (uint64_t)blockIdx.x * 64 + lane;
+    if (i >= a.n_streams)
+        return;
+    const uint64_t len = a.in_lens[i];
+    if (len == 0 || len >= a.tiny_limit)
+        return; // not this kernel's
+    if (a.out_caps && a.out_caps[i] < max_compress_len_u64(len))
+        return; // BufferTooSmall, reported by k_plan_compress
+    const uint32_t n = (uint32_t)len;
+    TinyColumns m;
+    m.in = (TinyColumns::l_u32 *)tin + lane;
+    m.tb = (TinyColumns::l_u32 *)ttab + lane;
+    m.out = (TinyColumns::l_u32 *)tout + lane;
+    gcptr src = (gcptr)a.in_ptrs[i];
+    {
+        // whole dwords; the last partial one bytewise (reads stay inside
+        // the stream)
+        uint32_t k = 0;
+        for (; k + 4 <= n; k += 4)
+            m.in[(k >> 2) * 64] = ld32u(src + k);
+        uint32_t last = 0;
+        for (uint32_t j = 0; k + j < n; j++)
+            last |= (uint32_t)src[k + j] << (8 * j);
+        m.in[(k >> 2) * 64] = last; // (k >> 2 <= 63)
+    }
+    if (n >= kMinNonLiteral)
+        for (uint32_t w = 0; w < kW; w++) // fresh table: src/compress.rs:506
+            m.tb[w * 64] = 0;
+    const uint32_t d = tiny_compress(m, n);
+    gptr dst = (gptr)a.out_ptrs[i];
+    {
+        uint32_t k = 0;
+        for (; k + 4 <= d; k += 4)
+            st32u(dst + k, m.out[(k >> 2) * 64]);
+        const uint32_t last = m.out[(k >> 2) * 64];
+        for (uint32_t j = 0; k + j < d; j++)
+            dst[k + j] = (uint8_t)(last >> (8 * j));
+    }
+    a.out_lens[i] = d;
+}
+
+// ---------------------------------------------------------------------
 // K1b: lane-per-block match finder.
 //
 // The wavefront-per-block kernel above is bound by a dependent chain per
@@ -1394,31 +1498,50 @@ __device__ __forceinline__ uint2 wg_scan2(uint32_t x, uint32_t y,
     return make_uint2(bx + sx - x, by + sy - y); // exclusive
 }
 
+namespace {
+// blocks of stream i, or 0 for a stream that is rejected, empty or tiny
+// (reference src/compress.rs:104-125)
+__device__ __forceinline__ uint32_t plan_blocks(const CompressArgs &a,
+                                                uint32_t i, bool report)
+{
+    const uint64_t len = a.in_lens[i];
+    const uint64_t need = max_compress_len_u64(len);
+    if (report)
+        a.out_lens[i] = 0;
+    if (need == 0) {
+        if (report)
+            set_error(a.errs, i, SNAPMI_TOO_BIG, len, kMaxInput, 0);
+        return 0;
+    }
+    if (a.out_caps && a.out_caps[i] < need) {
+        if (report)
+            set_error(a.errs, i, SNAPMI_BUFFER_TOO_SMALL, a.out_caps[i], need,
+                      0);
+        return 0;
+    }
+    if (len == 0) { // src/compress.rs:120-125
+        if (report) {
+            ((gptr)a.out_ptrs[i])[0] = 0;
+            a.out_lens[i] = 1;
+            set_error(a.errs, i, SNAPMI_OK, 0, 0, 0);
+        }
+        return 0;
+    }
+    if (report)
+        set_error(a.errs, i, SNAPMI_OK, 0, 0, 0);
+    if (len < a.tiny_limit)
+        return 0; // k_compress_tiny's: no blocks, it writes out_lens
+    return (uint32_t)((len + kMaxBlock - 1) / kMaxBlock);
+}
+} // namespace
+
 __global__ __launch_bounds__(1024) void k_plan_compress(CompressArgs a)
 {
     __shared__ uint2 wave_tot[16];
     uint32_t carry_b = 0, carry_s = 0;
     for (uint32_t base = 0; base < a.n_streams; base += blockDim.x) {
         const uint32_t i = base + threadIdx.x;
-        uint32_t nb = 0;
-        if (i < a.n_streams) {
-            const uint64_t len = a.in_lens[i];
-            const uint64_t need = max_compress_len_u64(len);
-            a.out_lens[i] = 0;
-            if (need == 0) {
-                set_error(a.errs, i, SNAPMI_TOO_BIG, len, kMaxInput, 0);
-            } else if (a.out_caps && a.out_caps[i] < need) {
-                set_error(a.errs, i, SNAPMI_BUFFER_TOO_SMALL, a.out_caps[i],
-                          need, 0);
-            } else if (len == 0) { // src/compress.rs:120-125
-                ((gptr)a.out_ptrs[i])[0] = 0;
-                a.out_lens[i] = 1;
-                set_error(a.errs, i, SNAPMI_OK, 0, 0, 0);
-            } else {
-                nb = (uint32_t)((len + kMaxBlock - 1) / kMaxBlock);
-                set_error(a.errs, i, SNAPMI_OK, 0, 0, 0);
-            }
-        }
+        const uint32_t nb = i < a.n_streams ? plan_blocks(a, i, true) : 0;
         uint2 tot;
         const uint2 ex = wg_scan2(nb, nb ? nb - 1 : 0, wave_tot, &tot);
         uint32_t fb = carry_b + ex.x, fs = carry_s + ex.y;
@@ -1492,41 +1615,6 @@ __global__ __launch_bounds__(1024) void k_scan_sizes(CompressArgs a)
 // workgroup scans its 1024 items and leaves its total, (b) one workgroup
 // scans the totals, (c) every workgroup adds its offset.
 // ---------------------------------------------------------------------
-namespace {
-// blocks of stream i, or 0 for a stream that is rejected or empty
-// (reference src/compress.rs:104-125)
-__device__ __forceinline__ uint32_t plan_blocks(const CompressArgs &a,
-                                                uint32_t i, bool report)
-{
-    const uint64_t len = a.in_lens[i];
-    const uint64_t need = max_compress_len_u64(len);
-    if (report)
-        a.out_lens[i] = 0;
-    if (need == 0) {
-        if (report)
-            set_error(a.errs, i, SNAPMI_TOO_BIG, len, kMaxInput, 0);
-        return 0;
-    }
-    if (a.out_caps && a.out_caps[i] < need) {
-        if (report)
-            set_error(a.errs, i, SNAPMI_BUFFER_TOO_SMALL, a.out_caps[i], need,
-                      0);
-        return 0;
-    }
-    if (len == 0) { // src/compress.rs:120-125
-        if (report) {
-            ((gptr)a.out_ptrs[i])[0] = 0;
-            a.out_lens[i] = 1;
-            set_error(a.errs, i, SNAPMI_OK, 0, 0, 0);
-        }
-        return 0;
-    }
-    if (report)
-        set_error(a.errs, i, SNAPMI_OK, 0, 0, 0);
-    return (uint32_t)((len + kMaxBlock - 1) / kMaxBlock);
-}
-} // namespace
-
 __global__ __launch_bounds__(1024) void k_plan_compress_a(CompressArgs a)
 {
     __shared__ uint2 wave_tot[16];

@@ -62,6 +62,10 @@ struct snapmi_ctx {
     // 1 = for batches of at most two blocks per CU (default), 0 = never,
     // 2 = whenever the wavefront kernel would run (tests)
     int small_batch_kernel = 1;
+    // k_compress_tiny (streams of fewer than 256 bytes, one per LANE, all of
+    // their state in LDS): 1 = on (default), 0 = such streams are one-block
+    // streams of the block kernels (cross-check, and what round 2 measured)
+    int tiny_stream_kernel = 1;
     // the lane kernel's segment is matched in two halves and the first
     // half's tokens are encoded on the side stream meanwhile: 1 = when the
     // segment has at least 1.4 blocks per lane, 0 = never (default: measured

@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include "snapmi.h"
+#include "snapmi_tiny.hpp"
 
 namespace snapmi {
 
@@ -43,6 +44,9 @@ struct CompressArgs {
     // k_scan_sizes_*): one per 1024 streams / blocks, + 1
     uint2 *plan_part;
     unsigned long long *scan_part;
+    // streams of 1 .. tiny_limit - 1 bytes get no blocks: k_compress_tiny
+    // compresses them, one per lane (0: every stream goes through blocks)
+    uint32_t tiny_limit;
 };
 
 // wavefronts (= hash tables) per persistent compress workgroup: 5 x 32 KiB
@@ -88,6 +92,7 @@ __global__ void k_scan_sizes_b(CompressArgs a, uint32_t nparts);
 __global__ void k_scan_sizes_c(CompressArgs a);
 __global__ void k_compress_blocks(CompressArgs a);
 __global__ void k_compress_block_lds(CompressArgs a);
+__global__ void k_compress_tiny(CompressArgs a);
 __global__ void k_match_blocks(CompressArgs a);
 __global__ void k_encode_tokens(CompressArgs a);
 __global__ void k_scan_sizes(CompressArgs a);

@@ -865,3 +865,68 @@ def test_decoder_boundaries_of_the_third_generation(ctx):
             assert (oe.kind, oe.a, oe.b, oe.c) == e, (len(m), e, oe)
             bad += 1
     assert ok >= len(valid) and bad > 100
+
+
+def test_tiny_streams_one_per_lane(built):
+    """k_compress_tiny: streams of 1..255 bytes, one per LANE with input,
+    table and output in LDS (the algorithm itself is checked on the CPU by
+    test_tiny_lane_cpu.py).  Every length around the limit and every kind of
+    data in ONE batch next to empty and larger streams, inputs and outputs
+    packed back to back (every alignment; a byte written past a stream's end
+    would damage its neighbour), some capacities one byte short.  The same
+    batch with the kernel off (such streams are then one-block streams of the
+    block kernels) must give the same bytes."""
+    import torch
+    import rust_snappy_amd as R
+    from rust_snappy_amd import batch
+    rng = random.Random(99)
+    blob = b"".join(d for _, d in O.corpus_round())
+    ins = []
+    for n in list(range(0, 300)) + [1000, 65536, 70000]:
+        o = rng.randrange(0, len(blob) - 70000)
+        ins.append(blob[o:o + n])
+        ins.append(bytes(rng.randrange(2) for _ in range(n)))
+        ins.append(bytes(n))
+        ins.append(bytes(rng.randrange(256) for _ in range(n)))
+        unit = bytes(rng.randrange(256) for _ in range(rng.randrange(1, 40)))
+        ins.append((unit * (n // len(unit) + 1))[:n])
+    rng.shuffle(ins)
+    lens = [len(x) for x in ins]
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+    host = np.frombuffer(b"".join(ins) + b"\0", dtype=np.uint8).copy()
+    src = batch.StreamBatch(torch.from_numpy(host).cuda(), offs, lens)
+    need = [R.raw.max_compress_len(n) for n in lens]
+    short = {i for i in range(len(ins)) if i % 7 == 3}
+    caps = [need[i] - 1 if i in short else need[i] for i in range(len(ins))]
+    coffs = np.concatenate([[0], np.cumsum(caps)[:-1]]).astype(np.int64)
+    want = [O.compress(x) for x in ins]
+    for tiny in (1, 0):
+        c = R.raw.Context(0)
+        c.set_option("tiny_stream_kernel", tiny)
+        dst = batch.StreamBatch(
+            torch.full((int(sum(caps)) + 16,), 0xEE, dtype=torch.uint8,
+                       device="cuda"), coffs, caps)
+        out_lens = torch.full((len(ins),), -1, dtype=torch.int64,
+                              device="cuda")
+        errs = torch.zeros(32 * len(ins), dtype=torch.uint8, device="cuda")
+        R.raw.compress_batch(c, src.d_ptrs, src.d_lens, dst.d_ptrs,
+                             dst.d_lens, out_lens, errs,
+                             host_in_lens=src.h_lens)
+        c.synchronize()
+        e = batch.read_errors(errs)
+        flat = dst.data.cpu().numpy().tobytes()
+        ol = out_lens.cpu().numpy()
+        for i in range(len(ins)):
+            if i in short:
+                assert e[i] == (2, caps[i], need[i], 0), (tiny, i, e[i])
+                assert ol[i] == 0
+                # nothing of a rejected stream is written
+                assert flat[coffs[i]:coffs[i] + caps[i]] == b"\xEE" * caps[i]
+            else:
+                assert e[i][0] == 0, (tiny, i, e[i])
+                assert flat[coffs[i]:coffs[i] + ol[i]] == want[i], \
+                    (tiny, i, lens[i])
+        c.close()
+    # (bytes behind a stream's end inside its own capacity may differ between
+    # kernels - the block kernels over-copy there - so only lengths + content
+    # were compared above)
