@@ -311,7 +311,8 @@ def tiny(args, ctx, dev):
     """The tiny-stream regime on its own: zflat03 (the first 200 bytes of
     fireworks.jpeg, bench/src/bench.rs:91) tiled to --gib = 10.7 M streams
     at 2 GiB; beside it the first 200 bytes of alice29.txt (tiny streams
-    that do compress: literals and copies in every lane)."""
+    that do compress: literals and copies in every lane) and its first
+    1 KiB / 4 KiB."""
     import oracle_lib as O
     res = None
     for bench_id, blob in O.corpus_round():
@@ -324,12 +325,16 @@ def tiny(args, ctx, dev):
                    "decompress_gibs": round(n / GIB / td, 2),
                    "compress_ms": round(te * 1e3, 2),
                    "decompress_ms": round(td * 1e3, 2)}
-    text = (O.CORPUS / "alice29.txt").read_bytes()[:200]
-    n, c, reps, te, td = raw_tiles(ctx, dev, text, args.gib, args.steps,
-                                   O.compress(text))
-    res["text_200"] = {"ratio": round(c / n, 4),
-                       "compress_gibs": round(n / GIB / te, 2),
-                       "decompress_gibs": round(n / GIB / td, 2)}
+    # (1 KiB and 4 KiB: the record / page sizes between the lane-per-stream
+    # kernels and whole 64 KiB blocks - one-block streams of the block kernels)
+    for key, size in (("text_200", 200), ("text_1k", 1024),
+                      ("text_4k", 4096)):
+        text = (O.CORPUS / "alice29.txt").read_bytes()[:size]
+        n, c, reps, te, td = raw_tiles(ctx, dev, text, args.gib, args.steps,
+                                       O.compress(text))
+        res[key] = {"ratio": round(c / n, 4),
+                    "compress_gibs": round(n / GIB / te, 2),
+                    "decompress_gibs": round(n / GIB / td, 2)}
     return res
 
 

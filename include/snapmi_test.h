@@ -44,6 +44,10 @@ extern "C" {
  *                          snapmi_ctx_create had failed (lane kernel only)
  *   "frame_crc_side_stream"  0: the frame encoder's CRC kernel runs on the
  *                          main stream
+ *   "decode_many_min"      batches of more streams than this are decoded by
+ *                          k_decompress_streams3_many, 16 streams of the
+ *                          sorted order per workgroup (default 1 048 576; the
+ *                          suite lowers it to reach the kernel with 40 000)
  *   "frame_walk_segment"   segment of the parallel chunk-header walk (>= 128
  *                          KiB; default 32 MiB)
  * Returns SNAPMI_E_ARGUMENT for an unknown name.

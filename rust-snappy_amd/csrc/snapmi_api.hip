@@ -300,6 +300,8 @@ int snapmi_ctx_set_test_option(snapmi_ctx *ctx, const char *name,
         return SNAPMI_E_ARGUMENT;
     if (strcmp(name, "lane_waves_per_cu") == 0 && value >= 1 && value <= 32)
         ctx->lane_waves_per_cu = (uint32_t)value;
+    else if (strcmp(name, "decode_many_min") == 0 && value >= 0)
+        ctx->decode_many_min = (uint64_t)value;
     else if (strcmp(name, "lane_max_waves") == 0 && value >= 0 &&
              value <= 0x7FFFFFFF)
         ctx->lane_max_waves = (uint32_t)value;
@@ -435,12 +437,15 @@ int snapmi_compress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
         h_in_lens = fetched.data();
     }
     uint64_t blocks = 0, slots = 0;
+    const uint64_t tiny = ctx->tiny_stream_kernel ? kTinyCompress : 0;
     for (size_t i = 0; i < n; i++) {
         const uint64_t len = h_in_lens[i];
+        // (first the cheap test: a batch of ten million tiny streams is
+        // walked here once per call)
+        if (len < tiny)
+            continue; // k_compress_tiny's, or empty: no block
         if (len == 0 || max_compress_len_u64(len) == 0)
             continue;
-        if (ctx->tiny_stream_kernel && len < kTinyCompress)
-            continue; // k_compress_tiny's: no block
         const uint64_t nb = (len + kMaxBlock - 1) / kMaxBlock;
         blocks += nb;
         slots += nb - 1;
@@ -926,8 +931,14 @@ int launch_decompress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
         hipLaunchKernelGGL(k_decompress_streams2, dim3((uint32_t)n), dim3(64),
                            0, s, a);
     else {
-        hipLaunchKernelGGL(k_decompress_streams3, dim3((uint32_t)n), dim3(64),
-                           0, s, a);
+        if (n > ctx->decode_many_min)
+            hipLaunchKernelGGL(
+                k_decompress_streams3_many,
+                dim3((uint32_t)((n + kManyStreams - 1) / kManyStreams)),
+                dim3(64), 0, s, a);
+        else
+            hipLaunchKernelGGL(k_decompress_streams3, dim3((uint32_t)n),
+                               dim3(64), 0, s, a);
         // the streams of fewer than 256 compressed bytes, one per lane (how
         // many there are only the device knows: workgroups without any leave
         // at once, in both launches)

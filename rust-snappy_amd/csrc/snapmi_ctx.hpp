@@ -66,6 +66,9 @@ struct snapmi_ctx {
     // their state in LDS): 1 = on (default), 0 = such streams are one-block
     // streams of the block kernels (cross-check, and what round 2 measured)
     int tiny_stream_kernel = 1;
+    // batches of more streams than this are decoded by
+    // k_decompress_streams3_many (kManyStreams streams per workgroup)
+    uint64_t decode_many_min = 1u << 20;
     // the lane kernel's segment is matched in two halves and the first
     // half's tokens are encoded on the side stream meanwhile: 1 = when the
     // segment has at least 1.4 blocks per lane, 0 = never (default: measured

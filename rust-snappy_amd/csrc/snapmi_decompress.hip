@@ -598,9 +598,10 @@ struct Wide {
 // error is written).
 __device__ __forceinline__ bool open_stream(const DecompressArgs &a,
                                             const uint32_t lane, Wide &x,
-                                            l_u8 *ring_mem)
+                                            l_u8 *ring_mem,
+                                            const uint32_t slot)
 {
-    const uint64_t st = a.order[blockIdx.x];
+    const uint64_t st = a.order[slot]; // slot: position in the sorted order
     gcptr in = (gcptr)a.in_ptrs[st];
     const uint64_t in_len = a.in_lens[st];
     const bool piece = a.modes && a.modes[st] == 2;
@@ -1570,7 +1571,7 @@ __global__ __launch_bounds__(64) void k_decompress_streams3(DecompressArgs a)
     if (blockIdx.x >= uni(a.bucket_pos[64]))
         return;
     Wide x;
-    if (!open_stream(a, lane, x, (l_u8 *)ring_mem))
+    if (!open_stream(a, lane, x, (l_u8 *)ring_mem, blockIdx.x))
         return;
     bool irregular = x.too_big();
     if (!irregular)
@@ -1578,6 +1579,40 @@ __global__ __launch_bounds__(64) void k_decompress_streams3(DecompressArgs a)
     if (!irregular)
         irregular = decode_windows2(x, lane);
     close_stream(a, lane, x, irregular);
+}
+
+// The same decoder for batches of millions of streams: a workgroup takes
+// kManyStreams consecutive positions of the sorted order (neighbours there
+// are of one size class), so the dispatcher hands out a sixteenth of the
+// workgroups - at 10.7 M streams of 200 bytes, all of them k_decompress_tiny's,
+// the 10.7 M empty workgroups of the launch above were 1.1 ms of a 4.4 ms pass.
+// (No occupancy attribute: the loop around the body costs registers, and held
+// to 64 VGPRs it spills; four wavefronts per SIMD are plenty for streams that
+// small.)
+__global__ __launch_bounds__(64) void k_decompress_streams3_many(
+    DecompressArgs a)
+{
+    __shared__ __attribute__((aligned(16)))
+    uint8_t ring_mem[kRing2 + 16 + 64 * kG3 + 64];
+    const uint32_t lane = threadIdx.x;
+    if (a.gate && uni64(*a.gate) != a.gate_value)
+        return;
+    const uint32_t n_big = uni(a.bucket_pos[64]);
+    for (uint32_t j = 0; j < kManyStreams; j++) {
+        const uint32_t slot = blockIdx.x * kManyStreams + j;
+        if (slot >= n_big)
+            return;
+        Wide x;
+        if (!open_stream(a, lane, x, (l_u8 *)ring_mem, slot))
+            continue;
+        bool irregular = x.too_big();
+        if (!irregular)
+            irregular =
+                decode_windows3(x, lane, (l_u8 *)ring_mem + kRing2 + 16);
+        if (!irregular)
+            irregular = decode_windows2(x, lane);
+        close_stream(a, lane, x, irregular);
+    }
 }
 
 // The second generation alone (option decode_kernel = 2): kept as the
@@ -1590,7 +1625,7 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
     if (a.gate && uni64(*a.gate) != a.gate_value)
         return;
     Wide x;
-    if (!open_stream(a, lane, x, (l_u8 *)ring_mem))
+    if (!open_stream(a, lane, x, (l_u8 *)ring_mem, blockIdx.x))
         return;
     const bool irregular = x.too_big() || decode_windows2(x, lane);
     close_stream(a, lane, x, irregular);
@@ -1606,7 +1641,7 @@ __global__ __launch_bounds__(64) void k_decompress_sequential(DecompressArgs a)
     if (a.gate && uni64(*a.gate) != a.gate_value)
         return;
     Wide x;
-    if (!open_stream(a, lane, x, (l_u8 *)ring_mem))
+    if (!open_stream(a, lane, x, (l_u8 *)ring_mem, blockIdx.x))
         return;
     decode_sequential(a, x.st, lane, x.src, x.src_len, x.dst, x.dst_len, 0, 0);
 }

@@ -164,6 +164,10 @@ __global__ void k_decompress_streams3(DecompressArgs a);
 __global__ void k_decompress_streams2(DecompressArgs a);
 __global__ void k_decompress_sequential(DecompressArgs a);
 __global__ void k_decompress_tiny(DecompressArgs a);
+// streams per workgroup of k_decompress_streams3_many (batches of more than
+// snapmi_ctx::decode_many_min streams)
+constexpr uint32_t kManyStreams = 16;
+__global__ void k_decompress_streams3_many(DecompressArgs a);
 __global__ void k_decompress_len(DecompressArgs a);
 
 } // namespace snapmi

@@ -768,11 +768,33 @@ def test_many_small_streams_plan_on_many_workgroups(cctx, ctx):
         by_input.setdefault(x, set()).add(int(lens[i]))
     assert all(len(v) == 1 for v in by_input.values())
     comp = batch.StreamBatch(dst.data, dst.offsets, lens)
-    back, blens, derrs = batch.decompress(ctx, comp)
-    assert all(e[0] == 0 for e in derrs)
-    assert [int(x) for x in blens] == [len(x) for x in ins]
-    for i in check:
-        assert back.stream_bytes(i, blens[i]) == ins[i], i
+    # (second pass: k_decompress_streams3_many, 16 streams of the sorted order
+    # per workgroup - the kernel of batches of more than a million streams)
+    for many_min in (1 << 20, 1000):
+        ctx.set_test_option("decode_many_min", many_min)
+        back, blens, derrs = batch.decompress(ctx, comp)
+        assert all(e[0] == 0 for e in derrs)
+        assert [int(x) for x in blens] == [len(x) for x in ins]
+        for i in check:
+            assert back.stream_bytes(i, blens[i]) == ins[i], i
+    # errors come through it as well: damage three streams (1 000, 4 096 and
+    # 70 000 bytes: their headers then promise more than the buffers hold)
+    bad = [16, 20007, 39988]
+    raw_comp = comp.data.clone()
+    for i in bad:
+        o = int(comp.offsets[i])
+        raw_comp[o] = 0xFF                     # header byte: wrong length
+    comp_bad = batch.StreamBatch(raw_comp, comp.offsets, lens)
+    results = []
+    for many_min in (1 << 20, 1000):
+        ctx.set_test_option("decode_many_min", many_min)
+        _, blens2, derrs2 = batch.decompress(
+            ctx, comp_bad, caps=[len(x) for x in ins])
+        results.append(([int(x) for x in blens2], derrs2))
+    ctx.set_test_option("decode_many_min", 1 << 20)
+    assert results[0] == results[1]
+    assert all(results[0][1][i][0] != 0 for i in bad)
+    assert sum(1 for e in results[0][1] if e[0] != 0) == len(bad)
 
 
 def test_decoder_boundaries_of_the_third_generation(ctx):
