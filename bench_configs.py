@@ -312,7 +312,7 @@ def tiny(args, ctx, dev):
     fireworks.jpeg, bench/src/bench.rs:91) tiled to --gib = 10.7 M streams
     at 2 GiB; beside it the first 200 bytes of alice29.txt (tiny streams
     that do compress: literals and copies in every lane) and its first
-    1 KiB / 4 KiB."""
+    400 / 1 000 / 2 000 / 4 096 bytes."""
     import oracle_lib as O
     res = None
     for bench_id, blob in O.corpus_round():
@@ -325,9 +325,10 @@ def tiny(args, ctx, dev):
                    "decompress_gibs": round(n / GIB / td, 2),
                    "compress_ms": round(te * 1e3, 2),
                    "decompress_ms": round(td * 1e3, 2)}
-    # (1 KiB and 4 KiB: the record / page sizes between the lane-per-stream
-    # kernels and whole 64 KiB blocks - one-block streams of the block kernels)
-    for key, size in (("text_200", 200), ("text_1k", 1024),
+    # (400 .. 2 000 bytes: the three classes of k_compress_small; 4 KiB: a
+    # one-block stream of the block kernels)
+    for key, size in (("text_200", 200), ("text_400", 400),
+                      ("text_1k", 1000), ("text_2k", 2000),
                       ("text_4k", 4096)):
         text = (O.CORPUS / "alice29.txt").read_bytes()[:size]
         n, c, reps, te, td = raw_tiles(ctx, dev, text, args.gib, args.steps,

@@ -134,7 +134,12 @@ const char *snapmi_version(void);
  *   "tiny_stream_kernel"   1 (default): streams of fewer than 256 bytes are
  *                          compressed one per LANE, input, table and output
  *                          in LDS (k_compress_tiny); 0: they are one-block
- *                          streams of the block kernels
+ *                          streams of the block kernels (and so are the
+ *                          streams of the next option)
+ *   "small_stream_kernel"  1 (default): streams of 256 .. 2047 bytes are
+ *                          compressed a few per wavefront, one per lane, with
+ *                          their state in LDS (k_compress_small); 0: they are
+ *                          one-block streams of the block kernels
  *   "lane_min_blocks"      batches with at least this many 64 KiB blocks use
  *                          the lane-per-block kernel (default 8192)
  *   "lane_segment_blocks"  blocks per lane-kernel launch (default 262144 =

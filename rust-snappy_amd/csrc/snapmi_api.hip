@@ -276,6 +276,9 @@ int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value)
     else if (strcmp(name, "tiny_stream_kernel") == 0 && value >= 0 &&
              value <= 1)
         ctx->tiny_stream_kernel = (int)value;
+    else if (strcmp(name, "small_stream_kernel") == 0 && value >= 0 &&
+             value <= 2)
+        ctx->small_stream_kernel = (int)value;
     else if (strcmp(name, "frame_parallel_walk_min") == 0 && value >= 0)
         ctx->frame_parallel_walk_min = (uint64_t)value;
     else if (strcmp(name, "host_copy_kernel") == 0 && value >= 0 && value <= 3)
@@ -409,6 +412,23 @@ int snapmi_decompress_len(const uint8_t *input, size_t input_len,
     return SNAPMI_OK;
 }
 
+} // extern "C"
+namespace snapmi {
+// streams shorter than this are compressed by the lane-per-stream kernels
+// (k_compress_tiny under 256 bytes, k_compress_small under 2 KiB) and get no
+// blocks; 0: every stream goes through the block kernels
+static uint64_t small_stream_limit(const snapmi_ctx *ctx)
+{
+    if (!ctx->tiny_stream_kernel)
+        return 0;
+    return ctx->small_stream_kernel == 2
+               ? kSmallCompress
+               : (ctx->small_stream_kernel ? kSmallCompress / 2
+                                           : kTinyCompress);
+}
+} // namespace snapmi
+extern "C" {
+
 // ----------------------------------------------------------------------
 // batched device-resident API
 // ----------------------------------------------------------------------
@@ -437,13 +457,19 @@ int snapmi_compress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
         h_in_lens = fetched.data();
     }
     uint64_t blocks = 0, slots = 0;
-    const uint64_t tiny = ctx->tiny_stream_kernel ? kTinyCompress : 0;
+    // streams under this length are the lane-per-stream kernels': no block
+    const uint64_t small = small_stream_limit(ctx);
+    uint32_t classes = 0; // which of those kernels have anything to do
     for (size_t i = 0; i < n; i++) {
         const uint64_t len = h_in_lens[i];
         // (first the cheap test: a batch of ten million tiny streams is
         // walked here once per call)
-        if (len < tiny)
-            continue; // k_compress_tiny's, or empty: no block
+        if (len < small) {
+            classes |= len < kTinyCompress ? (len ? 1u : 0u)
+                                           : (len < 512 ? 2u
+                                                        : (len < 1024 ? 4u : 8u));
+            continue;
+        }
         if (len == 0 || max_compress_len_u64(len) == 0)
             continue;
         const uint64_t nb = (len + kMaxBlock - 1) / kMaxBlock;
@@ -451,7 +477,7 @@ int snapmi_compress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
         slots += nb - 1;
     }
     return launch_compress(ctx, d_in_ptrs, d_in_lens, d_out_ptrs, d_out_caps,
-                           d_out_lens, d_errs, n, blocks, slots);
+                           d_out_lens, d_errs, n, blocks, slots, classes);
 }
 
 } // extern "C"
@@ -483,7 +509,7 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                     const uint64_t *d_in_lens, void *const *d_out_ptrs,
                     const uint64_t *d_out_caps, uint64_t *d_out_lens,
                     snapmi_error *d_errs, size_t n, uint64_t blocks,
-                    uint64_t slots)
+                    uint64_t slots, uint32_t small_classes)
 {
     if (blocks > 0x7FFFFFFFu)
         return fail_ctx(ctx, SNAPMI_E_ARGUMENT,
@@ -526,7 +552,7 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     a.lane_stride = kMaxTable;
     a.n_lanes = 0;
     a.tok_base = 0;
-    a.tiny_limit = ctx->tiny_stream_kernel ? kTinyCompress : 0;
+    a.small_limit = (uint32_t)small_stream_limit(ctx);
     // Small batches are latency-bound: the wavefront kernel finishes a block
     // in ~2 ms, a lane needs tens of ms.  Large batches are throughput-bound
     // and go to the lane-per-block kernel.
@@ -756,9 +782,24 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     // streams under 256 bytes, one per lane (a wavefront of streams that are
     // all larger returns at once: 16 384 idle wavefronts for a million 64 KiB
     // chunks)
-    if (a.tiny_limit)
-        hipLaunchKernelGGL(k_compress_tiny, dim3((uint32_t)((n + 63) / 64)),
-                           dim3(64), 0, s, a);
+    // (small_classes: what the caller knows of the lengths - a class without
+    // a stream is not launched)
+    {
+        const dim3 grid((uint32_t)((n + 63) / 64));
+        if (a.small_limit && (small_classes & 1))
+            hipLaunchKernelGGL(k_compress_tiny, grid, dim3(64), 0, s, a);
+        if (a.small_limit > kTinyCompress) {
+            if (small_classes & 2)
+                hipLaunchKernelGGL(k_compress_small512, grid, dim3(64), 0, s,
+                                   a);
+            if (small_classes & 4)
+                hipLaunchKernelGGL(k_compress_small1k, grid, dim3(64), 0, s,
+                                   a);
+            if (small_classes & 8)
+                hipLaunchKernelGGL(k_compress_small2k, grid, dim3(64), 0, s,
+                                   a);
+        }
+    }
     if (blocks) {
         hipStream_t ws = s; // stream of the wavefront kernel
         if (waves_mode) {

@@ -909,14 +909,18 @@ __global__ __launch_bounds__(64) void k_compress_block_lds(CompressArgs a)
 // byte arrays on the CPU, tests/test_tiny_lane_cpu.py).  The columns are dword-
 // interleaved (byte k of lane l at ((k >> 2) * 64 + l) * 4 + (k & 3)), so
 // lanes at the same position hit 64 different banks.
-// k_plan_compress gives these streams no blocks (CompressArgs::tiny_limit),
+// k_plan_compress gives these streams no blocks (CompressArgs::small_limit),
 // so the block kernels never see them.
 // ---------------------------------------------------------------------
 namespace {
-struct TinyColumns {
+#ifndef SNAPMI_TINY_STAGE_OUT
+#define SNAPMI_TINY_STAGE_OUT 0 // 1: an output column in LDS (experiment)
+#endif
+template <bool kStage> struct TinyColumns {
     typedef __attribute__((address_space(3))) uint32_t l_u32;
     typedef __attribute__((address_space(3))) uint8_t l_u8;
     l_u32 *in, *tb, *out; // this lane's columns: dword w at [w * 64]
+    gptr gout;            // !kStage: the stream's place in the caller's buffer
     __device__ __forceinline__ static uint32_t at(uint32_t k)
     {
         return (k >> 2) * 256 + (k & 3); // byte offset inside the column
@@ -940,19 +944,26 @@ struct TinyColumns {
     }
     __device__ __forceinline__ void out8(uint32_t k, uint32_t v)
     {
-        ((l_u8 *)out)[at(k)] = (uint8_t)v;
+        if (kStage)
+            ((l_u8 *)out)[at(k)] = (uint8_t)v;
+        else
+            gout[k] = (uint8_t)v;
     }
     __device__ __forceinline__ void out32(uint32_t k, uint32_t v)
     {
-        out[(k >> 2) * 64] = v;
+        if (kStage)
+            out[(k >> 2) * 64] = v;
+        else
+            st32u(gout + k, v);
     }
 };
 } // namespace
 
 __global__ __launch_bounds__(64) void k_compress_tiny(CompressArgs a)
 {
+    constexpr bool kStage = SNAPMI_TINY_STAGE_OUT != 0;
     constexpr uint32_t kW = kTinyCompress / 4;         // dwords per column
-    constexpr uint32_t kWo = (kTinyOutMax + 3) / 4;    // 65
+    constexpr uint32_t kWo = kStage ? (kTinyOutMax + 3) / 4 : 1; // 65
     __shared__ uint32_t tin[kW * 64];
     __shared__ uint32_t ttab[kW * 64];
     __shared__ uint32_t tout[kWo * 64];
@@ -961,15 +972,17 @@ __global__ __launch_bounds__(64) void k_compress_tiny(CompressArgs a)
     if (i >= a.n_streams)
         return;
     const uint64_t len = a.in_lens[i];
-    if (len == 0 || len >= a.tiny_limit)
+    if (len == 0 || len >= kTinyCompress || len >= a.small_limit)
         return; // not this kernel's
     if (a.out_caps && a.out_caps[i] < max_compress_len_u64(len))
         return; // BufferTooSmall, reported by k_plan_compress
     const uint32_t n = (uint32_t)len;
-    TinyColumns m;
-    m.in = (TinyColumns::l_u32 *)tin + lane;
-    m.tb = (TinyColumns::l_u32 *)ttab + lane;
-    m.out = (TinyColumns::l_u32 *)tout + lane;
+    typedef TinyColumns<kStage> Columns;
+    Columns m;
+    m.in = (typename Columns::l_u32 *)tin + lane;
+    m.tb = (typename Columns::l_u32 *)ttab + lane;
+    m.out = (typename Columns::l_u32 *)tout + lane;
+    m.gout = (gptr)a.out_ptrs[i];
     gcptr src = (gcptr)a.in_ptrs[i];
     {
         // whole dwords; the last partial one bytewise (reads stay inside
@@ -987,7 +1000,7 @@ __global__ __launch_bounds__(64) void k_compress_tiny(CompressArgs a)
             m.tb[w * 64] = 0;
     const uint32_t d = tiny_compress(m, n);
     gptr dst = (gptr)a.out_ptrs[i];
-    {
+    if (kStage) {
         uint32_t k = 0;
         for (; k + 4 <= d; k += 4)
             st32u(dst + k, m.out[(k >> 2) * 64]);
@@ -996,6 +1009,141 @@ __global__ __launch_bounds__(64) void k_compress_tiny(CompressArgs a)
             dst[k + j] = (uint8_t)(last >> (8 * j));
     }
     a.out_lens[i] = d;
+}
+
+// ---------------------------------------------------------------------
+// K1s: streams of 256 .. 1023 (2047) bytes, a FEW per wavefront, input and
+// table in LDS.
+//
+// The same idea one size class up.  A block of 1 KiB costs the lane kernel
+// as many HBM table accesses per byte as a 64 KiB block (more: every block
+// starts with an empty table), 24-28 ms per GiB whatever the size; its state,
+// though, is 1 KiB of input + the reference's table for that length (1 024
+// entries of u16) = 3 KiB, so 48 such streams fit a CU's LDS.  They are kept
+// as contiguous per-lane regions, kL lanes of a wavefront each running the
+// reference's loop on its own stream (snapmi_tiny.hpp) after all 64 lanes
+// have brought the inputs in (16 bytes per lane and access).  The output goes
+// straight to the caller's buffer, lane by lane: an output column in LDS
+// costs a quarter of the streams per CU, and those are what the rate is made
+// of (measured, profiles/r3_small_stream_variants.txt: 93.6 -> 116 GiB/s at
+// 400 bytes, 43.5 -> 56.0 at 1 000; half the lanes per wavefront and twice
+// the wavefronts, with or without the column: slower - the rounds are bound
+// by instruction issue as much as by latency, and a wavefront issues for all
+// of its lanes at once).  Classes by the stream's length: [256, 512) eight
+// lanes per wavefront, [512, 1024) four, twelve wavefronts (12 KiB each) per
+// CU.  [1024, 2048) with two lanes exists but is off by default: 26 GiB/s
+// against the lane kernel's 35 (option small_stream_kernel = 2).
+// A wavefront looks at 64 consecutive streams of the batch and works through
+// the ones of its class kL at a time (no list, no ticket).
+// ---------------------------------------------------------------------
+namespace {
+struct SmallRegion {
+    typedef __attribute__((address_space(3))) uint8_t l_u8;
+    typedef __attribute__((address_space(3), may_alias)) uint16_t l_u16s;
+    l_u8 *in;
+    l_u16s *tb;
+    gptr out; // the stream's place in the caller's buffer
+    __device__ __forceinline__ uint32_t in8(uint32_t k) const { return in[k]; }
+    __device__ __forceinline__ uint32_t in32(uint32_t k) const
+    {
+        // (LDS takes unaligned dwords: tests/hw/lds_unaligned.hip)
+        return ld32u((lcptr)(in + k));
+    }
+    __device__ __forceinline__ uint32_t tab(uint32_t h) const { return tb[h]; }
+    __device__ __forceinline__ void tab_set(uint32_t h, uint32_t v)
+    {
+        tb[h] = (uint16_t)v;
+    }
+    __device__ __forceinline__ void out8(uint32_t k, uint32_t v)
+    {
+        out[k] = (uint8_t)v;
+    }
+    __device__ __forceinline__ void out32(uint32_t k, uint32_t v)
+    {
+        st32u(out + k, v);
+    }
+};
+
+template <uint32_t kCap, uint32_t kL>
+__device__ __forceinline__ void compress_small(const CompressArgs &a)
+{
+    // per-lane region: input, table (kCap entries)
+    constexpr uint32_t kRegion = kCap + 2 * kCap;
+    constexpr uint32_t kLo = kCap == 2 * kTinyCompress ? kTinyCompress
+                                                       : kCap / 2;
+    __shared__ __attribute__((aligned(16))) uint8_t mem[kL * kRegion];
+    typedef SmallRegion::l_u8 l_u8;
+    typedef __attribute__((address_space(3), may_alias)) u32x4 l_u32x4;
+    l_u8 *const base = (l_u8 *)mem;
+    const uint32_t lane = threadIdx.x;
+    const uint64_t i = (uint64_t)blockIdx.x * 64 + lane;
+    uint64_t len = i < a.n_streams ? a.in_lens[i] : 0;
+    if (len >= a.small_limit ||
+        (a.out_caps && len && a.out_caps[i] < max_compress_len_u64(len)))
+        len = 0; // the block kernels' / reported by k_plan_compress
+    uint64_t M = __ballot(len >= kLo && len < kCap);
+    while (M) {
+        // lane j < kL takes the j-th stream of the class that is left
+        uint32_t mine = 64; // position of this lane's stream in the wavefront
+        {
+            uint64_t m = M;
+            for (uint32_t j = 0; j < kL && m; j++) {
+                const uint32_t b = (uint32_t)__builtin_ctzll(m);
+                m &= m - 1;
+                if (lane == j)
+                    mine = b;
+            }
+            M = m;
+        }
+        // bring the inputs in and clear the tables, all lanes at it
+        uint32_t n = 0;
+        for (uint32_t j = 0; j < kL; j++) {
+            const uint32_t b = rdlane(mine, j);
+            if (b == 64)
+                break;
+            const uint64_t st = (uint64_t)blockIdx.x * 64 + b;
+            const uint32_t nj = uni((uint32_t)a.in_lens[st]);
+            if (lane == j)
+                n = nj;
+            gcptr src = (gcptr)uni64((uint64_t)a.in_ptrs[st]);
+            l_u8 *const r = base + j * kRegion;
+            for (uint32_t k = lane * 16; k + 16 <= nj; k += 1024)
+                *(l_u32x4 *)(r + k) = ld128g(src + k);
+            if (lane < (nj & 15))
+                r[(nj & ~15u) + lane] = src[(nj & ~15u) + lane];
+            // (the table this length needs: 512 .. kCap entries of 2 bytes)
+            uint32_t tbytes = 1024;
+            while (tbytes < 2 * nj)
+                tbytes *= 2;
+            for (uint32_t k = lane * 16; k < tbytes; k += 1024)
+                *(l_u32x4 *)(r + kCap + k) = (u32x4){0, 0, 0, 0};
+        }
+        // (one wavefront: its LDS accesses complete in order; the barriers
+        // keep the compiler from moving them across)
+        __syncthreads();
+        if (mine != 64) {
+            const uint64_t st = (uint64_t)blockIdx.x * 64 + mine;
+            SmallRegion m;
+            m.in = base + lane * kRegion;
+            m.tb = (SmallRegion::l_u16s *)(m.in + kCap);
+            m.out = (gptr)a.out_ptrs[st];
+            a.out_lens[st] = tiny_compress(m, n);
+        }
+        __syncthreads(); // (the next round's inputs overwrite the regions)
+    }
+}
+} // namespace
+__global__ __launch_bounds__(64) void k_compress_small512(CompressArgs a)
+{
+    compress_small<512, 8>(a);
+}
+__global__ __launch_bounds__(64) void k_compress_small1k(CompressArgs a)
+{
+    compress_small<1024, 4>(a);
+}
+__global__ __launch_bounds__(64) void k_compress_small2k(CompressArgs a)
+{
+    compress_small<2048, 2>(a);
 }
 
 // ---------------------------------------------------------------------
@@ -1529,8 +1677,8 @@ __device__ __forceinline__ uint32_t plan_blocks(const CompressArgs &a,
     }
     if (report)
         set_error(a.errs, i, SNAPMI_OK, 0, 0, 0);
-    if (len < a.tiny_limit)
-        return 0; // k_compress_tiny's: no blocks, it writes out_lens
+    if (len < a.small_limit)
+        return 0; // k_compress_tiny's / _small's: no blocks, they write out_lens
     return (uint32_t)((len + kMaxBlock - 1) / kMaxBlock);
 }
 } // namespace

@@ -66,6 +66,11 @@ struct snapmi_ctx {
     // their state in LDS): 1 = on (default), 0 = such streams are one-block
     // streams of the block kernels (cross-check, and what round 2 measured)
     int tiny_stream_kernel = 1;
+    // k_compress_small (streams of 256 bytes and more, a few per wavefront,
+    // state in LDS; needs tiny_stream_kernel): 1 = up to 1 023 bytes
+    // (default), 2 = up to 2 047 (measured slower than the lane kernel from
+    // 1 KiB on), 0 = off
+    int small_stream_kernel = 1;
     // batches of more streams than this are decoded by
     // k_decompress_streams3_many (kManyStreams streams per workgroup)
     uint64_t decode_many_min = 1u << 20;
@@ -183,7 +188,7 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                     const uint64_t *d_in_lens, void *const *d_out_ptrs,
                     const uint64_t *d_out_caps, uint64_t *d_out_lens,
                     snapmi_error *d_errs, size_t n, uint64_t blocks,
-                    uint64_t slots);
+                    uint64_t slots, uint32_t small_classes = 0xF);
 // raw decompress; d_modes optional (1 = stored chunk, plain copy)
 int launch_decompress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                       const uint64_t *d_in_lens, void *const *d_out_ptrs,

@@ -44,9 +44,10 @@ struct CompressArgs {
     // k_scan_sizes_*): one per 1024 streams / blocks, + 1
     uint2 *plan_part;
     unsigned long long *scan_part;
-    // streams of 1 .. tiny_limit - 1 bytes get no blocks: k_compress_tiny
-    // compresses them, one per lane (0: every stream goes through blocks)
-    uint32_t tiny_limit;
+    // streams of 1 .. small_limit - 1 bytes get no blocks: k_compress_tiny
+    // (under 256 bytes, one per lane) and k_compress_small (under 2 KiB, a
+    // few per wavefront) compress them (0: every stream goes through blocks)
+    uint32_t small_limit;
 };
 
 // wavefronts (= hash tables) per persistent compress workgroup: 5 x 32 KiB
@@ -93,6 +94,9 @@ __global__ void k_scan_sizes_c(CompressArgs a);
 __global__ void k_compress_blocks(CompressArgs a);
 __global__ void k_compress_block_lds(CompressArgs a);
 __global__ void k_compress_tiny(CompressArgs a);
+__global__ void k_compress_small512(CompressArgs a); // [256, 512) bytes
+__global__ void k_compress_small1k(CompressArgs a);  // [512, 1024)
+__global__ void k_compress_small2k(CompressArgs a);  // [1024, 2048)
 __global__ void k_match_blocks(CompressArgs a);
 __global__ void k_encode_tokens(CompressArgs a);
 __global__ void k_scan_sizes(CompressArgs a);

@@ -1,25 +1,26 @@
-// snapmi: one raw stream of fewer than 256 bytes compressed by ONE thread.
+// snapmi: one small raw stream compressed by ONE thread.
 //
 // The batch compressor gives a 64 KiB block to a lane (tables in HBM) or to a
-// wavefront (table in LDS).  A stream of a couple of hundred bytes is neither:
-// its whole state - input, the reference's smallest hash table (256 entries,
-// and every position fits a byte), output - is under 800 bytes, so 64 of them
-// fit a wavefront's share of LDS and a round costs LDS latency instead of an
-// HBM round trip (k_compress_tiny, snapmi_compress.hip).
+// wavefront (table in LDS).  A stream of a few hundred bytes is neither: its
+// whole state - input, the reference's table for that length (256 entries
+// for inputs up to 256 bytes, the next power of two above the length beyond),
+// output - is a few KiB at most, so many of them fit a CU's LDS and a probe
+// costs an LDS round trip instead of an HBM one (k_compress_tiny: streams
+// under 256 bytes, 64 per wavefront; k_compress_small: streams under 2 KiB, a
+// few per wavefront; snapmi_compress.hip).
 //
 // The algorithm is the reference's, statement for statement
 // (src/compress.rs:99-154 compress, :195-317 compress_block, :378-412
 // extend_match, :323-369 emit_copy, :433-474 emit_literal, :491-518 table
-// size for inputs under 256 bytes: 256 entries, shift 24), written over a
-// memory policy M so that the very same text is run on the host by
-// tests/test_tiny_lane_cpu.py (byte arrays) and on the device (one lane's
-// dword-interleaved LDS columns):
+// size), for a stream of ONE block (n <= 65 536), written over a memory
+// policy M so that the very same text is run on the host by
+// tests/test_tiny_lane_cpu.py (byte arrays) and on the device (LDS):
 //
 //   uint32_t M::in8(k)         input byte k
 //   uint32_t M::in32(k)        input bytes k .. k+3, little endian (k + 4 <= n)
-//   uint32_t M::tab(h)         table entry h (0 .. 255), zero at the start
-//   void     M::tab_set(h, v)
-//   void     M::out8(k, v)     output byte k (k < kTinyOutMax)
+//   uint32_t M::tab(h)         table entry h, zero at the start
+//   void     M::tab_set(h, v)  v < n
+//   void     M::out8(k, v)     output byte k
 //   void     M::out32(k, v)    output bytes k .. k+3, k a multiple of 4
 #ifndef SNAPMI_TINY_HPP
 #define SNAPMI_TINY_HPP
@@ -34,14 +35,18 @@
 
 namespace snapmi {
 
-// streams of 1 .. kTinyCompress - 1 bytes are k_compress_tiny's
+// streams of 1 .. kTinyCompress - 1 bytes are k_compress_tiny's, streams of
+// kTinyCompress .. kSmallCompress - 1 bytes k_compress_small's
 constexpr uint32_t kTinyCompress = 256;
-// What such a stream can grow to: 2 bytes of header + the elements, and the
-// elements of a block never exceed the input by more than the tag of its last
-// literal (1 or 2 bytes) - a literal of L bytes in front of a copy costs
-// L + 1 (+ 1 over 60 bytes) and the copy 2 or 3 bytes for at least 4 (12)
-// bytes of input, so no literal + copy pair expands.
+constexpr uint32_t kSmallCompress = 2048;
+// What such a stream can grow to.  A literal of L bytes costs L + 1 (+ 1 over
+// 60 bytes, + 2 over 256), and while every offset is under 2048 a copy costs
+// 2 bytes for 4 .. 11 bytes of input or 3 for 12 and more: a literal + copy
+// pair expands only when the literal is longer than 256 bytes, and then by
+// one byte.  Under 256 bytes of input: header (2) + the last literal's tag
+// (2).  Under 2048: header (2) + at most 7 such pairs + the last tag (3).
 constexpr uint32_t kTinyOutMax = kTinyCompress - 1 + 2 + 2;
+constexpr uint32_t kSmallOutSlack = 2 + 7 + 3; // output <= input + this
 
 template <class M>
 SNAPMI_LANE_FN uint32_t tiny_put_literal(M &m, uint32_t d, uint32_t from,
@@ -50,9 +55,13 @@ SNAPMI_LANE_FN uint32_t tiny_put_literal(M &m, uint32_t d, uint32_t from,
     const uint32_t n1 = len - 1; // src/compress.rs:433-474
     if (n1 <= 59) {
         m.out8(d++, n1 << 2);
-    } else {
+    } else if (n1 < 256) {
         m.out8(d++, 60u << 2);
         m.out8(d++, n1);
+    } else {
+        m.out8(d++, 61u << 2);
+        m.out8(d++, n1 & 255);
+        m.out8(d++, n1 >> 8);
     }
     // bytes up to the output's next dword, whole dwords, the rest
     uint32_t k = 0;
@@ -69,51 +78,65 @@ template <class M>
 SNAPMI_LANE_FN uint32_t tiny_put_copy(M &m, uint32_t d, uint32_t offset,
                                       uint32_t len)
 {
-    // src/compress.rs:323-357 (offsets are under 256 here)
+    // src/compress.rs:323-357
     while (len >= 68) {
         m.out8(d++, (63u << 2) | 2);
-        m.out8(d++, offset);
-        m.out8(d++, 0);
+        m.out8(d++, offset & 255);
+        m.out8(d++, offset >> 8);
         len -= 64;
     }
     if (len > 64) {
         m.out8(d++, (59u << 2) | 2);
-        m.out8(d++, offset);
-        m.out8(d++, 0);
+        m.out8(d++, offset & 255);
+        m.out8(d++, offset >> 8);
         len -= 60;
     }
-    if (len <= 11) {
-        m.out8(d++, ((len - 4) << 2) | 1);
-        m.out8(d++, offset);
+    if (len <= 11 && offset <= 2047) {
+        m.out8(d++, ((offset >> 8) << 5) | ((len - 4) << 2) | 1);
+        m.out8(d++, offset & 255);
     } else {
         m.out8(d++, ((len - 1) << 2) | 2);
-        m.out8(d++, offset);
-        m.out8(d++, 0);
+        m.out8(d++, offset & 255);
+        m.out8(d++, offset >> 8);
     }
     return d;
 }
 
-SNAPMI_LANE_FN uint32_t tiny_hash(uint32_t x)
+SNAPMI_LANE_FN uint32_t tiny_hash(uint32_t x, uint32_t shift)
 {
-    return (x * 0x1E35A7BDu) >> 24; // src/compress.rs:523-525, 256 entries
+    return (x * 0x1E35A7BDu) >> shift; // src/compress.rs:523-525
 }
 
-// n = 1 .. kTinyCompress - 1 input bytes; returns the stream's length
+// entries of the table of a block of n bytes: src/compress.rs:491-518
+SNAPMI_LANE_FN uint32_t tiny_table_size(uint32_t n)
+{
+    uint32_t size = 256;
+    while (size < 16384 && size < n)
+        size *= 2;
+    return size;
+}
+
+// n = 1 .. 65 536 input bytes (one block); returns the stream's length
 template <class M> SNAPMI_LANE_FN uint32_t tiny_compress(M &m, uint32_t n)
 {
     uint32_t d = 0;
-    if (n < 128) { // the header: src/compress.rs:127
-        m.out8(d++, n);
-    } else {
-        m.out8(d++, (n & 127) | 128);
-        m.out8(d++, n >> 7);
+    for (uint32_t v = n;;) { // the header: src/compress.rs:127
+        if (v < 128) {
+            m.out8(d++, v);
+            break;
+        }
+        m.out8(d++, (v & 127) | 128);
+        v >>= 7;
     }
     if (n < 17) // src/compress.rs:140-146
         return tiny_put_literal(m, d, 0, n);
 
+    uint32_t shift = 24;
+    for (uint32_t size = 256; size < 16384 && size < n; size *= 2)
+        shift--;
     const uint32_t s_limit = n - 15;
     uint32_t s = 1, next_emit = 0;
-    uint32_t next_hash = tiny_hash(m.in32(1));
+    uint32_t next_hash = tiny_hash(m.in32(1), shift);
     bool done = false;
     while (!done) {
         // the skip loop, src/compress.rs:204-245
@@ -129,7 +152,7 @@ template <class M> SNAPMI_LANE_FN uint32_t tiny_compress(M &m, uint32_t n)
             }
             cand = m.tab(next_hash);
             m.tab_set(next_hash, s);
-            next_hash = tiny_hash(m.in32(s_next));
+            next_hash = tiny_hash(m.in32(s_next), shift);
             if (m.in32(s) == m.in32(cand))
                 break;
         }
@@ -165,12 +188,12 @@ template <class M> SNAPMI_LANE_FN uint32_t tiny_compress(M &m, uint32_t n)
                 break;
             }
             const uint32_t x0 = m.in32(s - 1), x1 = m.in32(s);
-            m.tab_set(tiny_hash(x0), s - 1);
-            const uint32_t h = tiny_hash(x1);
+            m.tab_set(tiny_hash(x0, shift), s - 1);
+            const uint32_t h = tiny_hash(x1, shift);
             cand = m.tab(h);
             m.tab_set(h, s);
             if (x1 != m.in32(cand)) {
-                next_hash = tiny_hash(m.in32(s + 1));
+                next_hash = tiny_hash(m.in32(s + 1), shift);
                 s++;
                 break;
             }

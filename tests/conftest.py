@@ -60,9 +60,10 @@ def cctx(request, built):
     c.set_option("small_batch_kernel", 2 if request.param == "waves_lds"
                  else 0)
     c.set_option("lane_min_blocks", 1)
-    # streams under 256 bytes are k_compress_tiny's by default; two of the
-    # six configurations keep them with the block kernels, so the block
-    # kernels' handling of the smallest blocks stays covered
+    # streams under 256 bytes / under 2 KiB are k_compress_tiny's /
+    # k_compress_small's by default; two of the six configurations keep them
+    # with the block kernels, so the block kernels' handling of small blocks
+    # stays covered
     c.set_option("tiny_stream_kernel",
                  0 if request.param in ("waves", "lanes_segmented") else 1)
     if request.param == "lanes_segmented":

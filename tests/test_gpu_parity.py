@@ -890,21 +890,26 @@ def test_decoder_boundaries_of_the_third_generation(ctx):
 
 
 def test_tiny_streams_one_per_lane(built):
-    """k_compress_tiny: streams of 1..255 bytes, one per LANE with input,
-    table and output in LDS (the algorithm itself is checked on the CPU by
-    test_tiny_lane_cpu.py).  Every length around the limit and every kind of
-    data in ONE batch next to empty and larger streams, inputs and outputs
-    packed back to back (every alignment; a byte written past a stream's end
-    would damage its neighbour), some capacities one byte short.  The same
-    batch with the kernel off (such streams are then one-block streams of the
-    block kernels) must give the same bytes."""
+    """k_compress_tiny (streams of 1..255 bytes, one per LANE with input,
+    table and output in LDS) and k_compress_small (256..2047 bytes, a few per
+    wavefront; three size classes) - the algorithm itself is checked on the
+    CPU by test_tiny_lane_cpu.py.  Every length up to 300, around every class
+    limit and a sample between, every kind of data, in ONE batch next to
+    empty and larger streams, inputs and outputs packed back to back (every
+    alignment; a byte written past a stream's end would damage its
+    neighbour), some capacities one byte short.  The same batch with the
+    kernels off (such streams are then one-block streams of the block
+    kernels) must give the same bytes."""
     import torch
     import rust_snappy_amd as R
     from rust_snappy_amd import batch
     rng = random.Random(99)
     blob = b"".join(d for _, d in O.corpus_round())
     ins = []
-    for n in list(range(0, 300)) + [1000, 65536, 70000]:
+    sizes = list(range(0, 300)) + list(range(300, 2100, 37)) + [
+        510, 511, 512, 513, 1022, 1023, 1024, 1025, 2046, 2047, 2048, 2049,
+        4096, 65536, 70000]
+    for n in sizes:
         o = rng.randrange(0, len(blob) - 70000)
         ins.append(blob[o:o + n])
         ins.append(bytes(rng.randrange(2) for _ in range(n)))
@@ -922,9 +927,10 @@ def test_tiny_streams_one_per_lane(built):
     caps = [need[i] - 1 if i in short else need[i] for i in range(len(ins))]
     coffs = np.concatenate([[0], np.cumsum(caps)[:-1]]).astype(np.int64)
     want = [O.compress(x) for x in ins]
-    for tiny in (1, 0):
+    for tiny in (3, 1, 0):
         c = R.raw.Context(0)
-        c.set_option("tiny_stream_kernel", tiny)
+        c.set_option("tiny_stream_kernel", tiny & 1)
+        c.set_option("small_stream_kernel", tiny >> 1)
         dst = batch.StreamBatch(
             torch.full((int(sum(caps)) + 16,), 0xEE, dtype=torch.uint8,
                        device="cuda"), coffs, caps)
