@@ -136,10 +136,12 @@ const char *snapmi_version(void);
  *                          in LDS (k_compress_tiny); 0: they are one-block
  *                          streams of the block kernels (and so are the
  *                          streams of the next option)
- *   "small_stream_kernel"  1 (default): streams of 256 .. 2047 bytes are
+ *   "small_stream_kernel"  1 (default): streams of 256 .. 1023 bytes are
  *                          compressed a few per wavefront, one per lane, with
- *                          their state in LDS (k_compress_small); 0: they are
- *                          one-block streams of the block kernels
+ *                          input and table in LDS (k_compress_small); 2: up
+ *                          to 2047 bytes (slower than the block kernels from
+ *                          1 KiB on); 0: they are one-block streams of the
+ *                          block kernels
  *   "lane_min_blocks"      batches with at least this many 64 KiB blocks use
  *                          the lane-per-block kernel (default 8192)
  *   "lane_segment_blocks"  blocks per lane-kernel launch (default 262144 =

@@ -895,20 +895,24 @@ __global__ __launch_bounds__(64) void k_compress_block_lds(CompressArgs a)
 }
 
 // ---------------------------------------------------------------------
-// K1t: streams of fewer than 256 bytes, ONE PER LANE, everything in LDS.
+// K1t: streams of fewer than 256 bytes, ONE PER LANE, input and table in LDS.
 //
 // A block of a couple of hundred bytes costs the lane kernel ~190 rounds of
 // an HBM (or L2) round trip, and the wavefront kernels a whole wavefront for
-// ~100 probes.  Its whole state is tiny, though: the input, the reference's
-// smallest table (256 entries, src/compress.rs:491-518 - and a position
-// fits a byte) and the output (never more than the input + 4 bytes,
-// snapmi_tiny.hpp) are three columns of 64 / 64 / 65 dwords per lane, 48.25
-// KiB per wavefront, three wavefronts per CU.  Every access of the parse is
-// then an LDS access of ~100 cycles and the lane runs the reference's loop
-// as it is written (snapmi_tiny.hpp: the test suite runs the same text over
-// byte arrays on the CPU, tests/test_tiny_lane_cpu.py).  The columns are dword-
+// ~100 probes.  Its whole state is tiny, though: the input and the
+// reference's smallest table (256 entries, src/compress.rs:491-518 - and a
+// position fits a byte) are two columns of 64 dwords per lane, 32 KiB per
+// wavefront, four wavefronts per CU.  Every read of the parse is then an LDS
+// access of ~100 cycles and the lane runs the reference's loop as it is
+// written (snapmi_tiny.hpp: the test suite runs the same text over byte
+// arrays on the CPU, tests/test_tiny_lane_cpu.py).  The columns are dword-
 // interleaved (byte k of lane l at ((k >> 2) * 64 + l) * 4 + (k & 3)), so
-// lanes at the same position hit 64 different banks.
+// lanes at the same position hit 64 different banks.  The output goes
+// straight to the caller's buffer, element by element: it is never read
+// back, and a third column (65 dwords per lane) meant three wavefronts per
+// CU instead of four - 202 against 276 GiB/s on 200-byte streams
+// (profiles/r3_tiny_output_direct.txt; SNAPMI_TINY_STAGE_OUT=1 builds that
+// variant).
 // k_plan_compress gives these streams no blocks (CompressArgs::small_limit),
 // so the block kernels never see them.
 // ---------------------------------------------------------------------
