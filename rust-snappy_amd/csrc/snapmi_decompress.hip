@@ -326,9 +326,29 @@ __global__ __launch_bounds__(256) void k_decompress_len(DecompressArgs a)
 }
 
 // Streams of fewer than kTiny = 2^kTinyLog2 compressed bytes are decoded one
-// per LANE (decode_tiny below); the sort puts them last, and the plan leaves
-// the number of streams in front of them in bucket_pos[64].
+// per LANE (k_decompress_tiny below); the sort puts them last, and the plan
+// leaves the number of streams in front of them in bucket_pos[64].
 constexpr uint32_t kTinyLog2 = 8;
+
+// The size class a stream is sorted by: floor(log2(compressed length)) -
+// except that a raw stream of under kTiny bytes whose header promises MORE
+// than kTiny bytes of output (a run of zeros: 200 bytes of copies are 4 KiB)
+// is put with the first class of the wavefront decoder.  The lane-per-stream
+// kernel keeps its output in LDS, kTiny bytes per lane; what does not fit
+// would be left to one lane moving bytes through global memory.
+__device__ __forceinline__ uint32_t plan_class(const DecompressArgs &a,
+                                               uint32_t i)
+{
+    const uint64_t len = a.in_lens[i];
+    uint32_t bk = len ? 63 - (uint32_t)__builtin_clzll(len) : 0;
+    if (len && bk < kTinyLog2 && !(a.modes && a.modes[i])) {
+        uint64_t dl = 0;
+        if (read_varint((gcptr)a.in_ptrs[i], len, &dl) != 0 &&
+            dl > (1u << kTinyLog2))
+            bk = kTinyLog2;
+    }
+    return bk;
+}
 
 // ---------------------------------------------------------------------
 // Plan: dispatch order.  Streams differ in size by orders of magnitude and a
@@ -346,8 +366,7 @@ __global__ __launch_bounds__(1024) void k_plan_decompress(DecompressArgs a)
         hist[threadIdx.x] = 0;
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < a.n_streams; i += blockDim.x) {
-        const uint64_t len = a.in_lens[i];
-        const uint32_t bk = len ? 63 - (uint32_t)__builtin_clzll(len) : 0;
+        const uint32_t bk = plan_class(a, i);
         atomicAdd(&hist[63 - bk], 1u); // reversed: big buckets first
     }
     __syncthreads();
@@ -363,8 +382,7 @@ __global__ __launch_bounds__(1024) void k_plan_decompress(DecompressArgs a)
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < a.n_streams; i += blockDim.x) {
-        const uint64_t len = a.in_lens[i];
-        const uint32_t bk = len ? 63 - (uint32_t)__builtin_clzll(len) : 0;
+        const uint32_t bk = plan_class(a, i);
         a.order[atomicAdd(&hist[63 - bk], 1u)] = i;
     }
 }
@@ -382,8 +400,7 @@ __global__ __launch_bounds__(1024) void k_plan_decompress_a(DecompressArgs a)
     __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < a.n_streams) {
-        const uint64_t len = a.in_lens[i];
-        const uint32_t bk = len ? 63 - (uint32_t)__builtin_clzll(len) : 0;
+        const uint32_t bk = plan_class(a, i);
         atomicAdd(&hist[63 - bk], 1u); // reversed: big buckets first
     }
     __syncthreads();
@@ -418,8 +435,7 @@ __global__ __launch_bounds__(1024) void k_plan_decompress_c(DecompressArgs a)
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t bk = 0, mine = 0;
     if (i < a.n_streams) {
-        const uint64_t len = a.in_lens[i];
-        bk = 63 - (len ? 63 - (uint32_t)__builtin_clzll(len) : 0);
+        bk = 63 - plan_class(a, i);
         mine = atomicAdd(&hist[bk], 1u); // my place among this workgroup's
     }
     __syncthreads();

@@ -20,7 +20,8 @@ ctx.set_option("lane_table_budget_pct", 75)
 for item in sys.argv[3:]:
     k, v = item.split("=")
     ctx.set_option(k, int(v))
-text = (O.CORPUS / "alice29.txt").read_bytes()[:size]
+# (size 0: a sparse page - 4 KiB of zeros, 196 compressed bytes)
+text = (O.CORPUS / "alice29.txt").read_bytes()[:size] if size else bytes(4096)
 n, c, reps, te, td = B.raw_tiles(ctx, dev, text, gib, 3, O.compress(text))
 print(json.dumps({"size": size, "streams": reps, "ratio": round(c / n, 4),
                   "compress_gibs": round(n / B.GIB / te, 2),

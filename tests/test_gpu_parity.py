@@ -958,3 +958,41 @@ def test_tiny_streams_one_per_lane(built):
     # (bytes behind a stream's end inside its own capacity may differ between
     # kernels - the block kernels over-copy there - so only lengths + content
     # were compared above)
+
+
+@pytest.mark.parametrize("count", [60, 20000])
+def test_tiny_compressed_streams_with_large_output(ctx, count):
+    """Streams of under 256 COMPRESSED bytes whose output is larger (runs,
+    sparse pages: 4 KiB of zeros are 197 bytes) are sorted with the wavefront
+    decoder's first class by the plan (plan_class reads their header); the
+    lane-per-stream kernel keeps the ones whose output fits its LDS column.
+    Both plan kernels (one workgroup / many), next to ordinary tiny streams
+    and to broken headers of the same size."""
+    from rust_snappy_amd import batch
+    rng = random.Random(count)
+    plain = [bytes(n) for n in (255, 256, 257, 300, 1000, 4096, 5000)]
+    plain += [b"ab" * 2000, b"xyz" * 90, b"q" * 256, b"q" * 257]
+    ins = []
+    for i in range(count):
+        if i % 3 == 0:
+            ins.append(plain[(i // 3) % len(plain)])
+        else:
+            ins.append(bytes(rng.randrange(4) for _ in range(
+                rng.randrange(0, 240))))
+    comps = [O.compress(x) for x in ins]
+    assert max(len(c) for c in comps[::3]) < 256
+    # broken: a header that promises 4 GiB - 1, and one that never ends
+    comps[1] = b"\xff\xff\xff\xff\x0f" + comps[1][1:]
+    comps[2] = b"\xff" * 7
+    got, errs = gpu_decompress(ctx, comps, caps=[max(len(x), 1) for x in ins])
+    for i, x in enumerate(ins):
+        if i in (1, 2):
+            assert errs[i][0] != 0
+            try:
+                O.decompress(comps[i], max(len(x), 1))
+                raise AssertionError("the oracle accepts the broken stream")
+            except O.SnapError as e:
+                assert errs[i][0] == e.kind, (i, errs[i], e.key())
+        else:
+            assert errs[i][0] == 0, (i, errs[i])
+            assert got[i] == x, i
