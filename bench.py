@@ -227,8 +227,9 @@ def measure_traffic(args, kernels):
 def run_extras(args, local_rank, dev, rank, world):
     """BASELINE configs beside the headline one, for the driver's record:
     cfg3 (framed text, 64 GiB), cfg5 (incompressible, 32 GiB), the 12
-    per-file rates, one long raw stream, cfg4 at N = 1 and the PCIe-inclusive
-    host-to-host rate of the frame entry points - in a child
+    per-file rates, one long raw stream, cfg4 at N = 1, the PCIe-inclusive
+    host-to-host rate of the frame entry points and the streams of 200 ..
+    4 096 bytes (the lane-per-stream kernels) - in a child
     process (bench_configs.py --plan), so that nothing they do can take the
     headline line down; at N > 1 cfg4 only (the framed stream sharded over
     the ranks, gathered on rank 0), one child per rank with a process group
@@ -240,7 +241,7 @@ def run_extras(args, local_rank, dev, rank, world):
         g3 = args.extras_gib or 64.0
         g5 = args.extras_gib or 32.0
         plan = (f"cfg3:{g3:g},cfg5:{g5:g},files:2,stream:2,cfg4:8,pcie:4,"
-                "adapters:4")
+                "adapters:4,tiny:1")
         cmd = [sys.executable, str(ROOT / "bench_configs.py"), "--plan", plan]
         try:
             p = subprocess.run(cmd, capture_output=True, text=True,

@@ -333,7 +333,8 @@ constexpr uint32_t kTinyLog2 = 8;
 // The size class a stream is sorted by: floor(log2(compressed length)) -
 // except that a raw stream of under kTiny bytes whose header promises MORE
 // than kTiny bytes of output (a run of zeros: 200 bytes of copies are 4 KiB)
-// is put with the first class of the wavefront decoder.  The lane-per-stream
+// (or a piece of a long stream with as much) is put with the first class of
+// the wavefront decoder.  The lane-per-stream
 // kernel keeps its output in LDS, kTiny bytes per lane; what does not fit
 // would be left to one lane moving bytes through global memory.
 __device__ __forceinline__ uint32_t plan_class(const DecompressArgs &a,
@@ -341,10 +342,15 @@ __device__ __forceinline__ uint32_t plan_class(const DecompressArgs &a,
 {
     const uint64_t len = a.in_lens[i];
     uint32_t bk = len ? 63 - (uint32_t)__builtin_clzll(len) : 0;
-    if (len && bk < kTinyLog2 && !(a.modes && a.modes[i])) {
+    if (len && bk < kTinyLog2) {
+        const uint32_t mode = a.modes ? a.modes[i] : 0;
         uint64_t dl = 0;
-        if (read_varint((gcptr)a.in_ptrs[i], len, &dl) != 0 &&
-            dl > (1u << kTinyLog2))
+        if (mode == 2) // a piece of a long stream: its output is out_caps
+            dl = a.out_caps[i];
+        else if (mode == 0 &&
+                 read_varint((gcptr)a.in_ptrs[i], len, &dl) == 0)
+            dl = 0; // no header: the lane-per-stream kernel reports it
+        if (dl > (1u << kTinyLog2))
             bk = kTinyLog2;
     }
     return bk;
@@ -1598,10 +1604,13 @@ __global__ __launch_bounds__(64) void k_decompress_streams3(DecompressArgs a)
 }
 
 // The same decoder for batches of millions of streams: a workgroup takes
-// kManyStreams consecutive positions of the sorted order (neighbours there
-// are of one size class), so the dispatcher hands out a sixteenth of the
-// workgroups - at 10.7 M streams of 200 bytes, all of them k_decompress_tiny's,
-// the 10.7 M empty workgroups of the launch above were 1.1 ms of a 4.4 ms pass.
+// kManyStreams positions of the sorted order, so the dispatcher hands out a
+// sixteenth of the workgroups - at 10.7 M streams of 200 bytes, all of them
+// k_decompress_tiny's, the 10.7 M empty workgroups of the launch above were
+// 1.1 ms of a 4.4 ms pass.  The positions are a whole grid apart (workgroup w:
+// w, w + G, w + 2G ...): every workgroup starts with one of the G longest
+// streams and gets one of every size stratum, so a few giant streams in such
+// a batch do not end up behind each other in one wavefront.
 // (No occupancy attribute: the loop around the body costs registers, and held
 // to 64 VGPRs it spills; four wavefronts per SIMD are plenty for streams that
 // small.)
@@ -1615,7 +1624,7 @@ __global__ __launch_bounds__(64) void k_decompress_streams3_many(
         return;
     const uint32_t n_big = uni(a.bucket_pos[64]);
     for (uint32_t j = 0; j < kManyStreams; j++) {
-        const uint32_t slot = blockIdx.x * kManyStreams + j;
+        const uint32_t slot = blockIdx.x + j * gridDim.x;
         if (slot >= n_big)
             return;
         Wide x;

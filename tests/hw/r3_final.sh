@@ -3,7 +3,7 @@
 tag=${1:-r3_v1}
 R=$PWD
 mkdir -p $R/gpurun_out
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 | tee $R/gpurun_out/tests_$tag.txt
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl\|amdgpu.ids" | tail -3 | tee $R/gpurun_out/tests_$tag.txt
 ( time timeout 1200 python bench.py > $R/gpurun_out/bench_$tag.json 2> $R/gpurun_out/bench_$tag.log ) 2> $R/gpurun_out/bench_${tag}_time.txt
 tail -3 $R/gpurun_out/bench_$tag.log; tail -3 $R/gpurun_out/bench_${tag}_time.txt
 cd /tmp && export TMPDIR=/tmp
@@ -22,6 +22,7 @@ w=$(find $R/gpurun_out/pmc_${tag}_WRITE_SIZE -name "*counter_collection.csv" | h
 python $R/profiles/pmc_traffic.py $f $w "cfg2: 12-stream zflat/uflat round x2934 = 8.002 GiB, 35208 raw streams" > $R/gpurun_out/pmc_traffic_$tag.json
 rm -rf $R/gpurun_out/pmc_${tag}_FETCH_SIZE $R/gpurun_out/pmc_${tag}_WRITE_SIZE
 cd $R
+[ "$2" = nosq ] && exit 0   # (the decoder kernels' SQ counters: only when those kernels changed)
 for k in 2 3; do
   SNAPMI_TESTING=1 SNAPMI_DECODE_KERNEL=$k bash tests/hw/pmc_dec.sh ${tag}_k$k 8 \
     "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
