@@ -404,7 +404,8 @@ def pcie(args, ctx, dev):
 def adapters(args, ctx, dev):
     """The streaming adapters the north star keeps: FrameEncoder.write_all of
     one large host buffer (rust-snappy_amd/frame.py, the mirror of
-    snap::write::FrameEncoder) and FrameDecoder.read_to_end of the result."""
+    snap::write::FrameEncoder), FrameDecoder.read_to_end of the result (Python
+    bytes) and FrameDecoder.readinto of it (the caller's pinned buffer)."""
     import io
     import oracle_lib as O
     from rust_snappy_amd import frame
@@ -454,6 +455,23 @@ def adapters(args, ctx, dev):
     back = frame.FrameDecoder(io.BytesIO(framed), ctx).read_to_end()
     td = time.perf_counter() - t0
     assert back == bytes(h_in.view[:m]), "adapter round trip"
+    del back
+    # io::Read::read as the reference has it - into the caller's buffer
+    # (pinned, with room for a batch: the bytes come straight from the call)
+    h_back = frame.HostBuffer(m + (256 << 20))
+    dec = frame.FrameDecoder(io.BytesIO(framed), ctx)
+    t0 = time.perf_counter()
+    pos = 0
+    while True:
+        k = dec.readinto(h_back.view[pos:])
+        if k == 0:
+            break
+        pos += k
+    ti = time.perf_counter() - t0
+    assert pos == m and bytes(h_back.view[:1 << 20]) == bytes(
+        h_in.view[:1 << 20]) and bytes(h_back.view[m - (1 << 20):m]) == bytes(
+        h_in.view[m - (1 << 20):m]), "readinto round trip"
+    h_back.close()
     h_in.close()
     return {"config": "Python streaming adapters over the host-buffer calls: "
                       "FrameEncoder.write_all of one pinned buffer (no copy "
@@ -461,6 +479,7 @@ def adapters(args, ctx, dev):
             "gib": round(n / GIB, 3), "framed_bytes": sink_n(sink, framed),
             "frame_encoder_write_all_gibs": round(n / GIB / best, 2),
             "frame_decoder_read_to_end_gibs": round(m / GIB / td, 2),
+            "frame_decoder_readinto_pinned_gibs": round(m / GIB / ti, 2),
             "decoder_gib": round(m / GIB, 3)}
 
 

@@ -463,7 +463,8 @@ class FrameDecoder:
         self.r = rdr
         self.ctx = ctx or raw.default_context()
         self.batch_bytes = max(int(batch_bytes), 1 << 17)
-        self._carry = bytearray()  # bytes read but not decoded (a cut chunk)
+        self._carry = b""        # bytes read but not decoded (a cut chunk)
+        self._outbuf = None      # pinned room for a batch's output
         self._out = b""
         self._pos = 0
         self._err = None
@@ -488,43 +489,103 @@ class FrameDecoder:
         has no more at the moment - a pipe, a socket, a request/response
         peer that waits for our answer before it sends on)."""
         rd = getattr(self.r, "read1", None) or self.r.read
-        while len(self._carry) < want and not self._eof:
-            ask = want - len(self._carry)
-            b = rd(ask)   # (if it raises, what was read so far stays in _carry)
-            if not b:
-                self._eof = True
-                break
-            self._carry += b
-            if len(b) < ask:
-                break
-        data, self._carry = bytes(self._carry), bytearray()
-        return data
+        pieces = [self._carry] if self._carry else []
+        have = len(self._carry)
+        try:
+            while have < want and not self._eof:
+                ask = want - have
+                b = rd(ask)   # (if it raises, what was read so far is kept)
+                if not b:
+                    self._eof = True
+                    break
+                pieces.append(b)
+                have += len(b)
+                if len(b) < ask:
+                    break
+        finally:
+            # (one piece - the usual batch from a file or a buffer - is
+            # handed on as it is, without a copy)
+            data = (pieces[0] if len(pieces) == 1
+                    else b"".join(pieces)) if pieces else b""
+            self._carry = data
+        self._carry = b""
+        return bytes(data) if not isinstance(data, bytes) else data
 
-    def _fill(self):
+    def _room(self, nbytes):
+        """Pinned memory for one batch's output, kept from batch to batch:
+        the copy home is asynchronous into it (a fresh bytearray per batch
+        cost a page fault per 4 KiB and a pageable copy)."""
+        if self._outbuf is None or self._outbuf.nbytes < nbytes:
+            if self._outbuf is not None:
+                self._outbuf.close()
+            self._outbuf = HostBuffer(nbytes)
+        return self._outbuf.view[:nbytes]
+
+    def _fill(self, direct=None):
+        """Decode the next batch.  Into `direct` (a writable memoryview of
+        the caller's, readinto) when that has room for whatever the batch can
+        hold - the bytes are then the caller's without another copy and their
+        number is returned; into the decoder's own pinned room otherwise
+        (returns 0, the bytes wait in _out)."""
         want = self.batch_bytes
         while True:
             data = self._pull(want)
             if not data:
-                return
+                return 0
             # room for every chunk the batch can hold: a chunk is at least 8
             # bytes of header and yields at most 65536 bytes, but a batch of
             # 64 KiB chunks needs about its own size; decode_host consumes
             # only as many chunks as fit and is called again for the rest
-            out = bytearray(max(2 * len(data), 1 << 20) // MAX_BLOCK_SIZE
-                            * MAX_BLOCK_SIZE)
+            room = (max(2 * len(data), 1 << 20) // MAX_BLOCK_SIZE
+                    * MAX_BLOCK_SIZE)
+            mine = direct is None or len(direct) < room
+            out = self._room(room) if mine else direct[:room]
             n, used, err = decode_host(self.ctx, data, out, self._seen_ident,
                                        self._eof, self._stale)
             if err is None and used == 0:   # not one whole chunk yet
-                self._carry = bytearray(data)
+                self._carry = data
                 want = len(data) + self.batch_bytes
                 if self._eof:
                     raise Error(101, message="frame_decode_host made no "
                                              "progress at end of input")
                 continue
             break
-        self._carry = bytearray(data[used:] if err is None else b"")
+        self._carry = data[used:] if err is None else b""
         self._seen_ident = self._seen_ident or used > 0
-        self._out, self._pos, self._err = bytes(out[:n]), 0, err
+        self._err = err
+        if mine:
+            self._out, self._pos = bytes(out[:n]), 0
+            return 0
+        self._out, self._pos = b"", 0
+        return n
+
+    def readinto(self, b):
+        """io::Read::read (reference src/read.rs:104-239): up to len(b)
+        bytes into the writable buffer `b`; 0 at the end of the stream.  A
+        buffer with room for a whole batch (pinned: HostBuffer.view) takes
+        the decoded bytes straight from the device call."""
+        mv = memoryview(b).cast("B")
+        if len(mv) == 0:
+            return 0
+        while True:
+            if self._pos < len(self._out):
+                k = min(len(mv), len(self._out) - self._pos)
+                mv[:k] = self._out[self._pos:self._pos + k]
+                self._pos += k
+                return k
+            if self._err is not None:
+                raise self._err
+            if self._io_err is not None:
+                e, self._io_err = self._io_err, None
+                raise e
+            if self._eof and not self._carry:
+                return 0
+            n = self._fill(mv)   # (the reader's error: nothing is lost,
+            if n:                # what it read before stays in _carry)
+                return n
+            if not self._out and self._err is None and self._eof \
+                    and not self._carry:
+                return 0
 
     def read(self, size=-1):
         """Up to `size` bytes (all remaining for size < 0).  An error is

@@ -889,3 +889,58 @@ def test_host_calls_on_pinned_buffers(ctx):
         ctx.set_option("host_copy_kernel", 1)
         h_in.close()
         h_out.close()
+
+
+def test_frame_decoder_readinto(ctx):
+    """io::Read::read as the reference has it (src/read.rs:104): into the
+    caller's buffer.  A buffer with room for a batch takes the bytes straight
+    from the device call, a small one gets them from the decoder's own room;
+    an error comes behind the bytes in front of it."""
+    from rust_snappy_amd import frame
+    data = (O.CORPUS / "lcet10.txt").read_bytes() * 3
+    framed = O.frame_compress(data)
+    for size in (1 << 22, 65536, 1000, 7):
+        dec = frame.FrameDecoder(io.BytesIO(framed), ctx, batch_bytes=1 << 18)
+        buf, got = bytearray(size), bytearray()
+        while True:
+            k = dec.readinto(buf)
+            if k == 0:
+                break
+            assert 0 < k <= size
+            got += buf[:k]
+            if size == 7 and len(got) > 5000:
+                got += dec.read(-1)          # (the rest in one go)
+                break
+        assert bytes(got) == data, size
+        assert dec.readinto(buf) == 0
+    hb = frame.HostBuffer(len(data) + (1 << 21))
+    dec = frame.FrameDecoder(io.BytesIO(framed), ctx, batch_bytes=1 << 18)
+    pos = 0
+    while True:
+        k = dec.readinto(hb.view[pos:])
+        if k == 0:
+            break
+        pos += k
+    assert bytes(hb.view[:pos]) == data
+    hb.close()
+    # a damaged chunk behind good ones
+    bad = bytearray(framed)
+    bad[len(framed) // 2] ^= 0x55
+    dec = frame.FrameDecoder(io.BytesIO(bytes(bad)), ctx, batch_bytes=1 << 18)
+    buf, got, err = bytearray(1 << 22), bytearray(), None
+    while True:
+        try:
+            k = dec.readinto(buf)
+        except frame.Error as e:
+            err = e
+            break
+        if k == 0:
+            break
+        got += buf[:k]
+    assert err is not None
+    assert len(got) > 0 and bytes(got) == data[:len(got)]
+    try:
+        O.frame_decompress(bytes(bad))
+        raise AssertionError("the oracle accepts the damaged stream")
+    except O.SnapError as e:
+        assert err.kind == e.kind and err.abc == (e.a, e.b, e.c), (err, e)
