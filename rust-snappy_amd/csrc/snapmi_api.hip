@@ -273,6 +273,8 @@ int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value)
     else if (strcmp(name, "small_batch_kernel") == 0 && value >= 0 &&
              value <= 2)
         ctx->small_batch_kernel = (int)value;
+    else if (strcmp(name, "lane_speculate") == 0 && value >= 0 && value <= 1)
+        ctx->lane_speculate = (int)value;
     else if (strcmp(name, "tiny_stream_kernel") == 0 && value >= 0 &&
              value <= 1)
         ctx->tiny_stream_kernel = (int)value;
@@ -858,8 +860,12 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                 a.blk_hi = (uint32_t)mid;
                 if (!waves_mode) // (shared with the wavefront kernel if on)
                     HIP_TRY(ctx, hipMemsetAsync(ctx->ticket.p, 0, 64, s));
-                hipLaunchKernelGGL(k_match_blocks, dim3(a.n_lanes / 64),
-                                   dim3(64), 0, s, a);
+                // no more blocks than lanes: a lane's rounds are latency and
+                // the memory system is idle - the kernel that also fetches
+                // the next probe's entry (k_match_blocks_spec)
+                const bool spec = ctx->lane_speculate && hi - lo <= a.n_lanes;
+                hipLaunchKernelGGL(spec ? k_match_blocks_spec : k_match_blocks,
+                                   dim3(a.n_lanes / 64), dim3(64), 0, s, a);
                 if (mid < hi) {
                     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
                     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2,
@@ -871,8 +877,9 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                     a.blk_lo = (uint32_t)mid;
                     a.blk_hi = (uint32_t)hi;
                     HIP_TRY(ctx, hipMemsetAsync(ctx->ticket.p, 0, 64, s));
-                    hipLaunchKernelGGL(k_match_blocks, dim3(a.n_lanes / 64),
-                                       dim3(64), 0, s, a);
+                    hipLaunchKernelGGL(
+                        spec ? k_match_blocks_spec : k_match_blocks,
+                        dim3(a.n_lanes / 64), dim3(64), 0, s, a);
                 }
                 if (hi == blocks) // dominant_ms: first match start .. last end
                     HIP_TRY(ctx, hipEventRecord(ctx->ev[5], s));

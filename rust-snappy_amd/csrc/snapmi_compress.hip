@@ -1189,7 +1189,19 @@ __device__ __forceinline__ uint64_t ld64p(gcptr p)
     __builtin_memcpy(&v, p, 8);
     return v;
 }
-__global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
+namespace {
+// kSpec: the launch has no more blocks than lanes (a lane's rounds are then
+// pure latency and the memory system is idle), so a probe's round also
+// fetches the table entry of the probe that FOLLOWS IF IT MISSES - its
+// position is known at the start of the round (src/compress.rs:207-216: the
+// skip schedule; after a copy, s + 1) and its bytes are in the registers the
+// window was read into - and a miss goes on to that probe in the same round.
+// Same table states in the same order (what this round wrote is forwarded),
+// same tokens; up to half the rounds on text.  With more blocks than lanes
+// the extra table reads would cost the random-access rate the launch is
+// bound by: the plain kernel.
+template <bool kSpec>
+__device__ __forceinline__ void match_blocks(const CompressArgs &a)
 {
     // per-lane input window: two 128-byte lines of the lane's block
     __shared__ __attribute__((aligned(16))) uint32_t ring[64 * 64];
@@ -1364,6 +1376,21 @@ __global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
         gcptr pa = mode == kExtend ? src + c : (gcptr)(tab + hcur);
         pa = stall ? src_al + hi : pa;
         B16 A = ld128u(pa);
+        // kSpec: the probe behind this one, delta bytes on (r3 ends at
+        // pos + 15: its 12 bytes are in the registers for delta <= 3)
+        uint32_t t0 = 0, t1 = 0, t2 = 0, h2 = 0;
+        bool spec = false;
+        B16 A2 = {{0, 0, 0, 0}};
+        if (kSpec) {
+            const uint32_t delta = mode == kChain ? 1 : s_next - s;
+            spec = mode <= kChain && delta <= 3 && !stall;
+            t0 = __builtin_amdgcn_alignbyte(r1, r0, delta);
+            t1 = __builtin_amdgcn_alignbyte(r2, r1, delta);
+            t2 = __builtin_amdgcn_alignbyte(r3, r2, delta);
+            h2 = hash32(t0, shift);
+            if (spec)
+                A2 = ld128u((gcptr)(tab + h2));
+        }
         // (the load is issued HERE, in front of the window's line: a compiler
         // barrier, or it may be sunk behind the fill's wait - two latencies
         // in every round that fills)
@@ -1380,6 +1407,8 @@ __global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
         // one wait for the whole round: A is materialised before the branch
         // that uses it (the fill's wait, when there was one, covered it)
         asm volatile("" : "+v"(A.w[0]));
+        if (kSpec)
+            asm volatile("" : "+v"(A2.w[0]));
         if (stall)
             continue;
 
@@ -1452,6 +1481,65 @@ __global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
                 tail = p + 16 > n;
             }
         }
+        if (kSpec && advance && spec) {
+            // the first probe missed: its advance (src/compress.rs:207-216),
+            // then the probe at the new s with the entry fetched for it
+            const uint32_t s_old = s;
+            const bool was_chain = mode == kChain;
+            s = s_next;
+            const uint32_t step = skip >> 5;
+            s_next = s + step;
+            skip += step;
+            mode = kProbe;
+            advance = false;
+            if (s_next > s_limit) {
+                finished = true;
+            } else {
+                // what this round wrote is newer than what it read
+                if (h2 == hcur) {
+                    A2.w[0] = r0;
+                    A2.w[1] = r1;
+                    A2.w[2] = r2;
+                    A2.w[3] = ((uint32_t)epoch << 16) | s_old;
+                } else if (was_chain && h2 == hprev) {
+                    A2.w[0] = q0;
+                    A2.w[1] = q1;
+                    A2.w[2] = q2;
+                    A2.w[3] = ((uint32_t)epoch << 16) | (s_old - 1);
+                }
+                const unsigned long long p8 =
+                    ((unsigned long long)t1 << 32) | t0;
+                const uint32_t p4 = t2;
+                const bool live = (A2.w[3] >> 16) == (uint32_t)epoch;
+                const uint32_t cand = live ? A2.w[3] & 0xFFFFu : 0;
+                const unsigned long long c8 =
+                    live ? ((unsigned long long)A2.w[1] << 32) | A2.w[0]
+                         : first8;
+                const uint32_t c4 = live ? A2.w[2] : first4b;
+                tab[h2] = (u64x2){
+                    p8, (epoch << 48) | ((unsigned long long)s << 32) | p4};
+                if ((uint32_t)c8 == t0) {
+                    const unsigned long long d8 = c8 ^ p8;
+                    const uint32_t d4 = c4 ^ p4;
+                    const uint32_t m =
+                        d8 ? (uint32_t)__builtin_ctzll(d8) >> 3
+                           : 8 + (d4 ? (uint32_t)__builtin_ctz(d4) >> 3 : 4);
+                    mpos = s;
+                    mcand = cand;
+                    if (m < 12) {
+                        matched = true;
+                        mend = s + m;
+                    } else {
+                        p = s + 12;
+                        c = cand + 12;
+                        mode = kExtend;
+                        tail = p + 16 > n;
+                    }
+                } else {
+                    advance = true;
+                }
+            }
+        }
         if (tail) { // rare: finish the match bytewise up to the block end
             while (p < n && src[p] == src[c]) {
                 p++;
@@ -1517,6 +1605,16 @@ __global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
         }
     }
     a.lane_epochs[g] = epoch;
+}
+} // namespace
+
+__global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
+{
+    match_blocks<false>(a);
+}
+__global__ __launch_bounds__(64) void k_match_blocks_spec(CompressArgs a)
+{
+    match_blocks<true>(a);
 }
 
 // ---------------------------------------------------------------------

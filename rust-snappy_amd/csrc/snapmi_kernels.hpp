@@ -98,6 +98,7 @@ __global__ void k_compress_small512(CompressArgs a); // [256, 512) bytes
 __global__ void k_compress_small1k(CompressArgs a);  // [512, 1024)
 __global__ void k_compress_small2k(CompressArgs a);  // [1024, 2048)
 __global__ void k_match_blocks(CompressArgs a);
+__global__ void k_match_blocks_spec(CompressArgs a); // launches with blocks <= lanes
 __global__ void k_encode_tokens(CompressArgs a);
 __global__ void k_scan_sizes(CompressArgs a);
 __global__ void k_compact(CompressArgs a);

@@ -68,6 +68,10 @@ def cctx(request, built):
                  0 if request.param in ("waves", "lanes_segmented") else 1)
     if request.param == "lanes_segmented":
         c.set_option("lane_segment_blocks", 64)
+        # (launches with no more blocks than lanes - every launch of this
+        # suite's batches - run k_match_blocks_spec; this configuration keeps
+        # the plain kernel covered)
+        c.set_option("lane_speculate", 0)
     # matched in two halves, the first half encoded on the side stream
     c.set_test_option("lane_overlap_encode",
                  2 if request.param == "lanes_overlap" else 0)
