@@ -144,12 +144,11 @@ const char *snapmi_version(void);
  *                          block kernels
  *   "lane_min_blocks"      batches with at least this many 64 KiB blocks use
  *                          the lane-per-block kernel (default 8192)
- *   "lane_speculate"       1 (default): a lane-kernel launch with no more
- *                          blocks than lanes (up to 6 GiB here) also fetches,
- *                          in a probe's round, the table entry of the probe
- *                          that follows a miss - fewer dependent rounds per
- *                          block where a block's latency is what is waited
- *                          for; 0: never
+ *   "lane_speculate"       1 (default): a lane-kernel launch of at most 24 576
+ *                          blocks (1.5 GiB) also fetches, in a probe's round,
+ *                          the table entry of the probe that follows a miss -
+ *                          fewer dependent rounds per block where a block's
+ *                          latency is what is waited for; 0: never
  *   "lane_segment_blocks"  blocks per lane-kernel launch (default 262144 =
  *                          16 GiB of input; bounds the token scratch)
  *   "lane_table_spread"    1 (default): the lane kernel's hash tables are

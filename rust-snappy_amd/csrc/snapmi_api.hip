@@ -489,6 +489,8 @@ namespace snapmi {
 // batches of up to this many streams / blocks are planned and scanned by one
 // workgroup (one launch instead of three)
 constexpr size_t kPlanOneWg = 16384;
+// lane-kernel launches of up to this many blocks run k_match_blocks_spec
+constexpr uint64_t kSpeculateMaxBlocks = 24576;
 
 // k_scan_sizes over the blocks [a.blk_lo, min(a.blk_hi, host_blocks))
 static void launch_scan_sizes(const CompressArgs &a, hipStream_t s)
@@ -860,10 +862,17 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                 a.blk_hi = (uint32_t)mid;
                 if (!waves_mode) // (shared with the wavefront kernel if on)
                     HIP_TRY(ctx, hipMemsetAsync(ctx->ticket.p, 0, 64, s));
-                // no more blocks than lanes: a lane's rounds are latency and
-                // the memory system is idle - the kernel that also fetches
-                // the next probe's entry (k_match_blocks_spec)
-                const bool spec = ctx->lane_speculate && hi - lo <= a.n_lanes;
+                // A launch of few blocks waits for the latency of its
+                // rounds with the memory system idle: the kernel that also
+                // fetches the next probe's entry (k_match_blocks_spec) takes
+                // 10-15 % off 2 048 .. 16 384 blocks of text.  From 32 768
+                // blocks on the launch is at the random-access rate of HBM
+                // even with one block per lane (1.6e10 rounds a second, as at
+                // 146 700 blocks) and the extra reads buy nothing
+                // (profiles/r3_lane_speculation.txt).
+                const bool spec = ctx->lane_speculate &&
+                                  hi - lo <= a.n_lanes &&
+                                  hi - lo <= kSpeculateMaxBlocks;
                 hipLaunchKernelGGL(spec ? k_match_blocks_spec : k_match_blocks,
                                    dim3(a.n_lanes / 64), dim3(64), 0, s, a);
                 if (mid < hi) {

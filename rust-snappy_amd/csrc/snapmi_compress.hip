@@ -1190,16 +1190,19 @@ __device__ __forceinline__ uint64_t ld64p(gcptr p)
     return v;
 }
 namespace {
-// kSpec: the launch has no more blocks than lanes (a lane's rounds are then
-// pure latency and the memory system is idle), so a probe's round also
-// fetches the table entry of the probe that FOLLOWS IF IT MISSES - its
-// position is known at the start of the round (src/compress.rs:207-216: the
-// skip schedule; after a copy, s + 1) and its bytes are in the registers the
-// window was read into - and a miss goes on to that probe in the same round.
-// Same table states in the same order (what this round wrote is forwarded),
-// same tokens; up to half the rounds on text.  With more blocks than lanes
-// the extra table reads would cost the random-access rate the launch is
-// bound by: the plain kernel.
+// kSpec: for launches of few blocks (snapmi_api.hip: at most 24 576), where
+// what is waited for is the latency of a block's dependent rounds and the
+// memory system is idle.  A probe's round also fetches the table entry of
+// the probe that FOLLOWS IF IT MISSES - its position is known at the start
+// of the round (src/compress.rs:207-216: the skip schedule; after a copy,
+// s + 1) and its bytes are in the registers the window was read into - and a
+// miss goes on to that probe in the same round.  Same table states in the
+// same order (what this round wrote is forwarded), same tokens
+// (tests/model_match_lane.py: the round order as a model, against the
+// oracle); 27-39 % fewer rounds on text, each a fifth more expensive: 10-15 %
+// off 2 048 .. 16 384 blocks.  A launch of 32 768 blocks and more is at the
+// random-access rate of HBM even with one block per lane, and the extra
+// table reads buy nothing there: the plain kernel.
 template <bool kSpec>
 __device__ __forceinline__ void match_blocks(const CompressArgs &a)
 {

@@ -62,9 +62,10 @@ struct snapmi_ctx {
     // 1 = for batches of at most two blocks per CU (default), 0 = never,
     // 2 = whenever the wavefront kernel would run (tests)
     int small_batch_kernel = 1;
-    // 1 (default): a lane-kernel launch with no more blocks than lanes runs
-    // k_match_blocks_spec (a probe's round also fetches the entry of the
-    // probe that follows a miss); 0: always the plain kernel
+    // 1 (default): a lane-kernel launch of at most kSpeculateMaxBlocks blocks
+    // (and no more blocks than lanes) runs k_match_blocks_spec (a probe's
+    // round also fetches the entry of the probe that follows a miss); 0:
+    // always the plain kernel
     int lane_speculate = 1;
     // k_compress_tiny (streams of fewer than 256 bytes, one per LANE, all of
     // their state in LDS): 1 = on (default), 0 = such streams are one-block
