@@ -1198,8 +1198,8 @@ namespace {
 // s + 1) and its bytes are in the registers the window was read into - and a
 // miss goes on to that probe in the same round.  Same table states in the
 // same order (what this round wrote is forwarded), same tokens
-// (tests/model_match_lane.py: the round order as a model, against the
-// oracle); 27-39 % fewer rounds on text, each a fifth more expensive: 10-15 %
+// (tests/model_match_lane.py: the round order as a model, checked on the
+// CPU); 27-39 % fewer rounds on text, each a fifth more expensive: 10-15 %
 // off 2 048 .. 16 384 blocks.  A launch of 32 768 blocks and more is at the
 // random-access rate of HBM even with one block per lane, and the extra
 // table reads buy nothing there: the plain kernel.
