@@ -432,7 +432,18 @@ def test_frame_decoder_returns_good_chunks_before_the_error(ctx):
     with pytest.raises(R.Error) as ei:
         dec.read(1)
     assert ei.value.variant == "UnexpectedEof"
-    # device entry point: valid prefix length next to the error
+
+
+def test_device_decode_reports_the_valid_prefix(ctx):
+    """The device entry point behind the decoder: the length of the output in
+    front of the failing chunk comes back next to the error."""
+    from rust_snappy_amd import frame
+    data = (O.CORPUS / "alice29.txt").read_bytes()           # 3 chunks
+    f = bytearray(O.frame_compress(data))
+    offs = frame.index_host(bytes(f))
+    f[int(offs[1]) + 8 + 20] ^= 0xFF                          # 2nd chunk body
+    with pytest.raises(O.SnapError) as oe:
+        O.frame_decompress(bytes(f))
     d_in = torch.frombuffer(bytearray(f), dtype=torch.uint8).cuda()
     for index in (None, torch.from_numpy(offs).cuda()):
         good, err = frame.decompress_batch_device(ctx, d_in, len(f), 3, index)
