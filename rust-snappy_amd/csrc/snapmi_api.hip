@@ -417,8 +417,9 @@ int snapmi_decompress_len(const uint8_t *input, size_t input_len,
 } // extern "C"
 namespace snapmi {
 // streams shorter than this are compressed by the lane-per-stream kernels
-// (k_compress_tiny under 256 bytes, k_compress_small under 2 KiB) and get no
-// blocks; 0: every stream goes through the block kernels
+// (k_compress_tiny under 256 bytes, k_compress_small under 1 KiB - under
+// 2 KiB with small_stream_kernel = 2) and get no blocks; 0: every stream goes
+// through the block kernels
 static uint64_t small_stream_limit(const snapmi_ctx *ctx)
 {
     if (!ctx->tiny_stream_kernel)
@@ -783,11 +784,11 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
         hipLaunchKernelGGL(k_plan_compress, dim3(1), dim3(1024), 0, s, a);
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], s));
-    // streams under 256 bytes, one per lane (a wavefront of streams that are
-    // all larger returns at once: 16 384 idle wavefronts for a million 64 KiB
-    // chunks)
-    // (small_classes: what the caller knows of the lengths - a class without
-    // a stream is not launched)
+    // the lane-per-stream kernels: streams under 256 bytes one per lane,
+    // streams under 1 KiB a few per wavefront (a wavefront of streams that
+    // are all larger returns at once: 16 384 idle wavefronts for a million
+    // 64 KiB chunks).  small_classes: what the caller knows of the lengths -
+    // a class without a stream is not launched.
     {
         const dim3 grid((uint32_t)((n + 63) / 64));
         if (a.small_limit && (small_classes & 1))

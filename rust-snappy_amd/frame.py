@@ -491,10 +491,18 @@ class FrameDecoder:
         rd = getattr(self.r, "read1", None) or self.r.read
         pieces = [self._carry] if self._carry else []
         have = len(self._carry)
+
+        def joined():
+            # (one piece - the usual batch from a file or a buffer - is
+            # handed on as it is, without a copy)
+            if len(pieces) == 1 and isinstance(pieces[0], bytes):
+                return pieces[0]
+            return b"".join(pieces)
+
         try:
             while have < want and not self._eof:
                 ask = want - have
-                b = rd(ask)   # (if it raises, what was read so far is kept)
+                b = rd(ask)
                 if not b:
                     self._eof = True
                     break
@@ -502,14 +510,11 @@ class FrameDecoder:
                 have += len(b)
                 if len(b) < ask:
                     break
-        finally:
-            # (one piece - the usual batch from a file or a buffer - is
-            # handed on as it is, without a copy)
-            data = (pieces[0] if len(pieces) == 1
-                    else b"".join(pieces)) if pieces else b""
-            self._carry = data
+        except BaseException:
+            self._carry = joined()   # what was read before the error is kept
+            raise
         self._carry = b""
-        return bytes(data) if not isinstance(data, bytes) else data
+        return joined()
 
     def _room(self, nbytes):
         """Pinned memory for one batch's output, kept from batch to batch:
