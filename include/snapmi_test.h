@@ -44,6 +44,8 @@ extern "C" {
  *                          snapmi_ctx_create had failed (lane kernel only)
  *   "frame_crc_side_stream"  0: the frame encoder's CRC kernel runs on the
  *                          main stream
+ *   "lane_speculate_max_blocks"  lane-kernel launches of at most this many
+ *                          blocks run k_match_blocks_spec (default 24 576)
  *   "decode_many_min"      batches of more streams than this are decoded by
  *                          k_decompress_streams3_many, 16 streams of the
  *                          sorted order per workgroup (default 1 048 576; the

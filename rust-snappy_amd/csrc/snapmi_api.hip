@@ -307,6 +307,8 @@ int snapmi_ctx_set_test_option(snapmi_ctx *ctx, const char *name,
         ctx->lane_waves_per_cu = (uint32_t)value;
     else if (strcmp(name, "decode_many_min") == 0 && value >= 0)
         ctx->decode_many_min = (uint64_t)value;
+    else if (strcmp(name, "lane_speculate_max_blocks") == 0 && value >= 0)
+        ctx->lane_speculate_max_blocks = (uint64_t)value;
     else if (strcmp(name, "lane_max_waves") == 0 && value >= 0 &&
              value <= 0x7FFFFFFF)
         ctx->lane_max_waves = (uint32_t)value;
@@ -490,8 +492,6 @@ namespace snapmi {
 // batches of up to this many streams / blocks are planned and scanned by one
 // workgroup (one launch instead of three)
 constexpr size_t kPlanOneWg = 16384;
-// lane-kernel launches of up to this many blocks run k_match_blocks_spec
-constexpr uint64_t kSpeculateMaxBlocks = 24576;
 
 // k_scan_sizes over the blocks [a.blk_lo, min(a.blk_hi, host_blocks))
 static void launch_scan_sizes(const CompressArgs &a, hipStream_t s)
@@ -873,7 +873,7 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                 // (profiles/r3_lane_speculation.txt).
                 const bool spec = ctx->lane_speculate &&
                                   hi - lo <= a.n_lanes &&
-                                  hi - lo <= kSpeculateMaxBlocks;
+                                  hi - lo <= ctx->lane_speculate_max_blocks;
                 hipLaunchKernelGGL(spec ? k_match_blocks_spec : k_match_blocks,
                                    dim3(a.n_lanes / 64), dim3(64), 0, s, a);
                 if (mid < hi) {

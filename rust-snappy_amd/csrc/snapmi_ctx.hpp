@@ -62,11 +62,14 @@ struct snapmi_ctx {
     // 1 = for batches of at most two blocks per CU (default), 0 = never,
     // 2 = whenever the wavefront kernel would run (tests)
     int small_batch_kernel = 1;
-    // 1 (default): a lane-kernel launch of at most kSpeculateMaxBlocks blocks
-    // (and no more blocks than lanes) runs k_match_blocks_spec (a probe's
-    // round also fetches the entry of the probe that follows a miss); 0:
-    // always the plain kernel
+    // 1 (default): a lane-kernel launch of at most lane_speculate_max_blocks
+    // blocks (and no more blocks than lanes) runs k_match_blocks_spec (a
+    // probe's round also fetches the entry of the probe that follows a
+    // miss); 0: always the plain kernel.  Measured: -10..15 % at 2 048 ..
+    // 16 384 blocks of text, nothing at 32 768 (test option to move the
+    // limit: lane_speculate_max_blocks).
     int lane_speculate = 1;
+    uint64_t lane_speculate_max_blocks = 24576;
     // k_compress_tiny (streams of fewer than 256 bytes, one per LANE, all of
     // their state in LDS): 1 = on (default), 0 = such streams are one-block
     // streams of the block kernels (cross-check, and what round 2 measured)
