@@ -128,6 +128,8 @@ int snapmi_ctx_create(int device, void *hip_stream, snapmi_ctx **out)
                 atoll(e) < 1 ? 1 : (uint64_t)atoll(e);
         if (const char *e = getenv("SNAPMI_DECODE_KERNEL"))
             ctx->decode_kernel = atoi(e) == 0 ? 0 : (atoi(e) == 2 ? 2 : 3);
+        if (const char *e = getenv("SNAPMI_SPAN_KERNEL"))
+            ctx->span_kernel = atoi(e) != 0;
         if (const char *m = getenv("SNAPMI_COMPRESS"))
             ctx->compress_mode = strcmp(m, "waves") == 0
                                      ? 0
@@ -275,6 +277,8 @@ int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value)
         ctx->small_batch_kernel = (int)value;
     else if (strcmp(name, "lane_speculate") == 0 && value >= 0 && value <= 1)
         ctx->lane_speculate = (int)value;
+    else if (strcmp(name, "span_kernel") == 0 && value >= 0 && value <= 1)
+        ctx->span_kernel = (int)value;
     else if (strcmp(name, "tiny_stream_kernel") == 0 && value >= 0 &&
              value <= 1)
         ctx->tiny_stream_kernel = (int)value;
@@ -828,15 +832,18 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
             if (lds_input) {
                 const uint32_t wgs = (uint32_t)(
                     blocks < (uint64_t)ctx->num_cus ? blocks : ctx->num_cus);
-                hipLaunchKernelGGL(k_compress_block_lds, dim3(wgs), dim3(64),
-                                   0, ws, a);
+                hipLaunchKernelGGL(ctx->span_kernel ? k_compress_span_lds
+                                                    : k_compress_block_lds,
+                                   dim3(wgs), dim3(64), 0, ws, a);
             } else {
                 const uint64_t want =
                     (blocks + kCompressWaves - 1) / kCompressWaves;
                 const uint32_t wgs = (uint32_t)(
                     want < (uint64_t)ctx->num_cus ? want : ctx->num_cus);
-                hipLaunchKernelGGL(k_compress_blocks, dim3(wgs),
-                                   dim3(kCompressWaves * 64), 0, ws, a);
+                hipLaunchKernelGGL(ctx->span_kernel ? k_compress_spans
+                                                    : k_compress_blocks,
+                                   dim3(wgs), dim3(kCompressWaves * 64), 0, ws,
+                                   a);
             }
         }
         if (lanes_mode) {

@@ -52,6 +52,7 @@
 
 #include "snapmi_device.hpp"
 #include "snapmi_kernels.hpp"
+#include "snapmi_span.hpp"
 
 namespace snapmi {
 
@@ -889,6 +890,373 @@ __global__ __launch_bounds__(64) void k_compress_block_lds(CompressArgs a)
             a.ntok[b] = 0xFFFFFFFFu;
         compress_one_block<true>(
             a, b, lane, table, tbase, c2, c3, cB, cBn,
+            (__attribute__((address_space(3))) uint8_t *)block_mem);
+        b = uni(next_ticket(a.ticket, lane, nblocks));
+    }
+}
+
+// ---------------------------------------------------------------------
+// K1s: wavefront per block, a WINDOW of 63 consecutive positions per step.
+//
+// k_compress_blocks pays one LDS atomic, one candidate gather and one ballot
+// per emitted copy (~2 100 cycles, ~10 000 copies per 64 KiB of text).  Here
+// a step fetches what the table holds and how many bytes match for EVERY
+// position of a 63-byte window - whether the parse will look them up or not -
+// and the sequential part of the reference (which positions are looked up,
+// which are inserted: src/compress.rs:195-317) becomes a walk over results
+// that are already in registers: span_walk (snapmi_span.hpp, the text
+// tests/test_span_wave_cpu.py runs on the host, byte for byte).  Nine
+// copies per step on text, ~1 100 steps per block instead of ~10 000.
+//   * lane L holds position s - 1 + L; ONE lane-ordered ds_mskor_rtn_b32
+//     writes every position of the window into the table and returns what was
+//     there - the reference's candidate, or the position of a lower lane with
+//     the same hash ("C bit");
+//   * one gather of the 16 bytes at every candidate, one compare: hit mask
+//     and match lengths of the whole window;
+//   * the walk (scalar unit: ~15 instructions per copy) marks the positions
+//     the reference really inserts; one lane-ordered ds_mskor_b32 then puts
+//     every slot right (touched lanes write their position, untouched lanes
+//     without a C bit give back what they displaced);
+//   * a run of more than 32 misses continues with k_compress_blocks' schedule
+//     step (64 probes of the growing stride per step, first hit wins); a match
+//     of 16 bytes or more is finished by extend_match.
+// Same persistent five-wave workgroups, same tables, same token encoder as
+// k_compress_blocks; kLds as there (k_compress_span_lds: input block in LDS).
+// ---------------------------------------------------------------------
+__device__ __forceinline__ void lds_mskor(uint32_t byte_addr, uint32_t mask,
+                                          uint32_t data)
+{
+    asm volatile("ds_mskor_b32 %0, %1, %2"
+                 :
+                 : "v"(byte_addr), "v"(mask), "v"(data)
+                 : "memory");
+}
+
+namespace {
+struct SpanLanes {
+    uint32_t mv, ov; // this lane's match length and exchanged table entry
+    __device__ __forceinline__ uint32_t m(uint32_t l) const
+    {
+        return rdlane(mv, l);
+    }
+    __device__ __forceinline__ uint32_t old(uint32_t l) const
+    {
+        return rdlane(ov, l);
+    }
+};
+struct SpanSink {
+    TokenSink *out;
+    uint32_t emit; // where the pending literal starts
+    __device__ __forceinline__ void token(uint32_t lit, uint32_t len,
+                                          uint32_t off)
+    {
+        out->record(emit, lit, off, len);
+        emit += lit + len;
+    }
+};
+} // namespace
+
+template <bool kLds>
+__device__ __forceinline__ void compress_one_block_span(
+    const CompressArgs &a, const uint32_t b, const uint32_t lane,
+    const lptr16 table, const uint32_t tbase,
+    __attribute__((address_space(3))) uint8_t *lblock = nullptr)
+{
+    // stream lookup: blk_first[st] <= b < blk_first[st + 1]
+    uint32_t lo_s = 0, hi_s = a.n_streams;
+    while (hi_s - lo_s > 1) {
+        const uint32_t mid = (lo_s + hi_s) >> 1;
+        if (a.blk_first[mid] <= b)
+            lo_s = mid;
+        else
+            hi_s = mid;
+    }
+    const uint32_t st_i = lo_s;
+    const uint32_t k = b - a.blk_first[st_i];
+    const uint64_t total = a.in_lens[st_i];
+    const uint64_t boff = (uint64_t)k * kMaxBlock;
+    gcptr src = (gcptr)a.in_ptrs[st_i] + boff;
+    const uint64_t avail = total - boff;
+    const uint32_t n = avail < kMaxBlock ? (uint32_t)avail : kMaxBlock;
+
+    gptr dst;
+    if (k == 0) {
+        dst = (gptr)a.out_ptrs[st_i];
+        if (lane == 0) { // varint(total): src/compress.rs:128
+            uint64_t v = total;
+            uint32_t i = 0;
+            while (v >= 0x80) {
+                dst[i++] = (uint8_t)v | 0x80;
+                v >>= 7;
+            }
+            dst[i] = (uint8_t)v;
+        }
+        dst += varint_len(total);
+    } else {
+        const uint32_t slot = a.slot_first[st_i] + k - 1;
+        if (slot >= a.host_slots)
+            return; // stream rejected by k_plan_compress (E_ARGUMENT)
+        dst = (gptr)a.scratch + (uint64_t)slot * kSlotBytes;
+    }
+    TokenSink out;
+    out.init(src, n, dst, lane);
+    if (n < kMinNonLiteral) { // src/compress.rs:140-146
+        out.record(0, n, 0, 0);
+        out.flush();
+        if (lane == 0)
+            a.blk_size[b] = out.d;
+        return;
+    }
+    typename std::conditional<kLds, lcptr, gcptr>::type msrc;
+    if constexpr (kLds) {
+        typedef __attribute__((address_space(3))) u32x4 l_u32x4;
+        typedef __attribute__((address_space(1))) u32x4 g_u32x4c;
+        const uint32_t mis = (uint32_t)(uintptr_t)src & 15u;
+        l_u32x4 *to = (l_u32x4 *)lblock;
+        const g_u32x4c *from = (const g_u32x4c *)(src - mis);
+        const uint32_t lines = (n + mis + 15) / 16;
+        for (uint32_t i = lane; i < lines; i += kWave)
+            to[i] = from[i];
+        __builtin_amdgcn_wave_barrier();
+        msrc = (lcptr)lblock + mis;
+    } else {
+        msrc = src;
+    }
+    // table sizing + zero fill: src/compress.rs:491-518
+    uint32_t shift = 32 - 8, tsize = 256;
+    while (tsize < kMaxTable && tsize < n) {
+        shift--;
+        tsize *= 2;
+    }
+    for (uint32_t i = 8 * lane; i < tsize; i += 8 * kWave)
+        *(__attribute__((address_space(3))) u32x4 *)&table[i] =
+            (u32x4){0, 0, 0, 0};
+    __builtin_amdgcn_wave_barrier();
+
+    const uint32_t s_limit = n - kInputMargin;
+    const uint32_t n16 = n - 16, n4 = n - 4;
+    SpanState st;
+    st.s = 1;
+    st.q = 0;
+    st.chain = 0;
+    st.next_emit = 0;
+    uint32_t run0 = 1; // schedule steps: where the run began
+    // Register window of the input for the hashes (global input only): lane l
+    // of wv[j] holds the dword at block offset wbase + 64 j + l; five
+    // registers, so that a step may move s by up to 128 positions and the
+    // next step's hash inputs are still a lane rotation (ds_bpermute) of
+    // registers that arrived long ago.
+    uint32_t wbase = 0, wv0 = 0, wv1 = 0, wv2 = 0, wv3 = 0, wv4 = 0;
+    if constexpr (!kLds) {
+        wv0 = ld32u(msrc + (lane < n4 ? lane : n4));
+        wv1 = ld32u(msrc + (lane + 64 < n4 ? lane + 64 : n4));
+        wv2 = ld32u(msrc + (lane + 128 < n4 ? lane + 128 : n4));
+        wv3 = ld32u(msrc + (lane + 192 < n4 ? lane + 192 : n4));
+        wv4 = ld32u(msrc + (lane + 256 < n4 ? lane + 256 : n4));
+    }
+    SpanSink sink;
+    sink.out = &out;
+    sink.emit = 0;
+#ifdef SNAPMI_PROFILE
+    uint64_t pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t t_last = __builtin_readcyclecounter();
+    uint64_t n_batches = 0, n_copies = 0;
+#endif
+    for (;;) {
+#ifdef SNAPMI_PROFILE
+        n_batches++;
+#endif
+        TICK(0);
+        if (!st.chain && st.q >= kSpanRun) {
+            // ---- schedule step (k_compress_blocks' batch for q > 0): lane l
+            // is probe q + l of the run that began at run0
+            const uint32_t p = run0 + kDelta.d[st.q + lane];
+            const uint32_t nextp = run0 + kDelta.d[st.q + lane + 1];
+            const bool valid = nextp <= s_limit; // src/compress.rs:212-214
+            const B16 x = ld128u(msrc + (p < n16 ? p : n16));
+            const uint32_t h = hash32(x.w[0], shift);
+            uint32_t cand = 0;
+            if (valid) {
+                const uint32_t sh = (h & 1) * 16;
+                const uint32_t old = lds_mskor_rtn(tbase + (h >> 1) * 4,
+                                                   0xFFFFu << sh, p << sh);
+                cand = (old >> sh) & 0xFFFFu;
+            }
+            const B16 y = ld128u(msrc + cand);
+            const uint32_t m = common16(x, y);
+            const uint64_t hits = __ballot(valid && m >= 4 && cand < p);
+            if (hits == 0) {
+                if (__ballot(!valid) != 0)
+                    break;
+                st.q += kWave;
+                continue;
+            }
+            const uint32_t kh = (uint32_t)__builtin_ctzll(hits);
+            const uint32_t pk = rdlane(p, kh);
+            const uint32_t ck = rdlane(cand, kh);
+            uint32_t len = rdlane(m, kh);
+            if (valid && lane > kh && cand <= pk)
+                table[h] = (uint16_t)cand;
+            if (len == 16)
+                len += extend_match(msrc, n, ck + 16, pk + 16, lane);
+            sink.token(pk - sink.emit, len, pk - ck);
+#ifdef SNAPMI_PROFILE
+            n_copies++;
+#endif
+            st.s = pk + len;
+            st.next_emit = st.s;
+            st.chain = 1;
+            st.q = 0;
+            if (st.s >= s_limit) // src/compress.rs:275-277
+                break;
+        } else {
+            // ---- window step: lane L = position s - 1 + L
+            const uint32_t base = st.s;
+            const uint32_t lo = base - st.chain; // first position exchanged
+            const uint32_t P = base - 1 + lane;
+            const bool active = lane ? P <= n16 : st.chain != 0;
+            uint32_t hx;
+            if constexpr (kLds) {
+                hx = ld32u(msrc + (P < n4 ? P : n4));
+            } else {
+                const uint32_t idx = base - 1 - wbase + lane; // < 128
+                const int sel = (int)((idx & 63) << 2);
+                const uint32_t g0 =
+                    (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)wv0);
+                const uint32_t g1 =
+                    (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)wv1);
+                hx = idx < 64 ? g0 : g1;
+            }
+            const B16 x = ld128u(msrc + (P < n16 ? P : n16));
+            TICK(1);
+            const uint32_t h = hash32(hx, shift);
+            const uint32_t sh = (h & 1) * 16;
+            const uint32_t taddr = tbase + (h >> 1) * 4;
+            uint32_t old = 0;
+            if (active)
+                old = (lds_mskor_rtn(taddr, 0xFFFFu << sh, P << sh) >> sh) &
+                      0xFFFFu;
+            TICK(2);
+            const B16 y = ld128u(msrc + old);
+            TICK(3);
+            SpanLanes ln;
+            ln.mv = common16(x, y);
+            ln.ov = old;
+            const bool cbit = active && old >= lo;
+            const uint64_t hits = __ballot(active && lane && ln.mv >= 4);
+            const uint64_t cbits = __ballot(cbit);
+            uint64_t touched = 0;
+            uint32_t at = 0;
+            st.next_emit = sink.emit;
+            const uint32_t rc =
+                span_walk(st, hits, cbits, s_limit, ln, sink, touched, at);
+            TICK(4);
+            // the table as the reference leaves it: one lane-ordered store
+            {
+                const bool t = (touched >> lane) & 1;
+                if (active && (t || !cbit))
+                    lds_mskor(taddr, 0xFFFFu << sh, (t ? P : old) << sh);
+            }
+            TICK(5);
+            if (rc == kSpanLong) {
+                const uint32_t pk = st.s, ck = rdlane(old, at);
+                const uint32_t len =
+                    16 + extend_match(msrc, n, ck + 16, pk + 16, lane);
+                sink.token(pk - sink.emit, len, pk - ck);
+                st.s = pk + len;
+                st.chain = 1;
+                st.q = 0;
+                if (st.s >= s_limit)
+                    break;
+            } else if (rc == kSpanDone) {
+                break;
+            } else if (!st.chain && st.q >= kSpanRun) {
+                run0 = st.s - st.q;
+            }
+            TICK(6);
+        }
+        // keep the register window covering s - 1 .. s + 126
+        if constexpr (!kLds) {
+            uint32_t D = st.s - 1 - wbase;
+            if (D >= 192) {
+                wbase = st.s - 1;
+                const uint32_t w0 = wbase + lane;
+                wv0 = ld32u(msrc + (w0 < n4 ? w0 : n4));
+                wv1 = ld32u(msrc + (w0 + 64 < n4 ? w0 + 64 : n4));
+                wv2 = ld32u(msrc + (w0 + 128 < n4 ? w0 + 128 : n4));
+                wv3 = ld32u(msrc + (w0 + 192 < n4 ? w0 + 192 : n4));
+                wv4 = ld32u(msrc + (w0 + 256 < n4 ? w0 + 256 : n4));
+            } else {
+                while (D >= 64) {
+                    wv0 = wv1;
+                    wv1 = wv2;
+                    wv2 = wv3;
+                    wv3 = wv4;
+                    wbase += 64;
+                    D -= 64;
+                    const uint32_t wp = wbase + 256 + lane;
+                    wv4 = ld32u(msrc + (wp < n4 ? wp : n4));
+                }
+            }
+        }
+        TICK(7);
+    }
+    if (sink.emit < n) // done(): src/compress.rs:417-426
+        out.record(sink.emit, n - sink.emit, 0, 0);
+    if (out.t)
+        out.flush();
+    if (lane == 0)
+        a.blk_size[b] = out.d;
+#ifdef SNAPMI_PROFILE
+    TICK(8);
+    if (lane == 0 && a.prof) {
+        for (int i = 0; i < 9; i++)
+            atomicAdd(&a.prof[i], (unsigned long long)pt[i]);
+        atomicAdd(&a.prof[10], (unsigned long long)n_batches);
+        atomicAdd(&a.prof[11], (unsigned long long)n_copies);
+        atomicAdd(&a.prof[12], 1ull);
+    }
+#endif
+}
+
+__global__ __launch_bounds__(kCompressWaves * 64) void k_compress_spans(
+    CompressArgs a)
+{
+    __shared__ __attribute__((aligned(16)))
+    uint16_t tables[kCompressWaves][kMaxTable];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    const lptr16 table = (lptr16)&tables[wave][0];
+    const uint32_t tbase = (uint32_t)(uintptr_t)table;
+    uint32_t nblocks = a.blk_first[a.n_streams];
+    if (nblocks > a.host_blocks)
+        nblocks = a.host_blocks;
+    uint32_t b = uni(next_ticket(a.ticket, lane, nblocks));
+    while (b != 0xFFFFFFFFu) {
+        if (lane == 0 && a.ntok)
+            a.ntok[b] = 0xFFFFFFFFu; // encoded here, not by k_encode_tokens
+        compress_one_block_span<false>(a, b, lane, table, tbase);
+        b = uni(next_ticket(a.ticket, lane, nblocks));
+    }
+}
+
+// one block per CU, table and input block in LDS (the smallest batches)
+__global__ __launch_bounds__(64) void k_compress_span_lds(CompressArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t table_mem[kMaxTable];
+    __shared__ __attribute__((aligned(16))) uint8_t block_mem[kMaxBlock + 32];
+    const uint32_t lane = threadIdx.x;
+    const lptr16 table = (lptr16)&table_mem[0];
+    const uint32_t tbase = (uint32_t)(uintptr_t)table;
+    uint32_t nblocks = a.blk_first[a.n_streams];
+    if (nblocks > a.host_blocks)
+        nblocks = a.host_blocks;
+    uint32_t b = uni(next_ticket(a.ticket, lane, nblocks));
+    while (b != 0xFFFFFFFFu) {
+        if (lane == 0 && a.ntok)
+            a.ntok[b] = 0xFFFFFFFFu;
+        compress_one_block_span<true>(
+            a, b, lane, table, tbase,
             (__attribute__((address_space(3))) uint8_t *)block_mem);
         b = uni(next_ticket(a.ticket, lane, nblocks));
     }

@@ -62,6 +62,12 @@ struct snapmi_ctx {
     // 1 = for batches of at most two blocks per CU (default), 0 = never,
     // 2 = whenever the wavefront kernel would run (tests)
     int small_batch_kernel = 1;
+    // the wavefront-per-block kernels' step: 1 (default) = a window of 63
+    // consecutive positions per step, every parse event inside it resolved
+    // by a walk over registers (k_compress_spans / k_compress_span_lds);
+    // 0 = one copy per step (k_compress_blocks / k_compress_block_lds, the
+    // kernels of rounds 1-3: kept as the cross-check)
+    int span_kernel = 1;
     // 1 (default): a lane-kernel launch of at most lane_speculate_max_blocks
     // blocks (and no more blocks than lanes) runs k_match_blocks_spec (a
     // probe's round also fetches the entry of the probe that follows a

@@ -93,6 +93,8 @@ __global__ void k_scan_sizes_b(CompressArgs a, uint32_t nparts);
 __global__ void k_scan_sizes_c(CompressArgs a);
 __global__ void k_compress_blocks(CompressArgs a);
 __global__ void k_compress_block_lds(CompressArgs a);
+__global__ void k_compress_spans(CompressArgs a);    // window steps, 5 tables/CU
+__global__ void k_compress_span_lds(CompressArgs a); // ... one block per CU
 __global__ void k_compress_tiny(CompressArgs a);
 __global__ void k_compress_small512(CompressArgs a); // [256, 512) bytes
 __global__ void k_compress_small1k(CompressArgs a);  // [512, 1024)

@@ -36,11 +36,12 @@ def ctx(request, built):
 
 
 @pytest.fixture(scope="session",
-                params=["waves", "waves_lds", "lanes", "lanes_segmented",
-                        "lanes_overlap", "both"])
+                params=["spans", "spans_lds", "waves", "waves_lds", "lanes",
+                        "lanes_segmented", "lanes_overlap", "both"])
 def cctx(request, built):
-    """A context per compressor kernel: the two wavefront-per-block kernels,
-    the lane-per-block kernel (one launch, and split into segments of 64
+    """A context per compressor kernel: the wavefront-per-block kernels (window
+    steps and, as the cross-check, one copy per step; five tables per CU and
+    one block per CU), the lane-per-block kernel (one launch, and split into segments of 64
     blocks) and both at once, each forced for every batch size, so every
     parity test of the encoder runs through all of them.  "lanes" and
     "lanes_segmented" encode every block at its final position
@@ -51,14 +52,19 @@ def cctx(request, built):
         pytest.skip("no GPU")
     import rust_snappy_amd as R
     c = R.raw.Context(0)
-    c.set_option("compress_mode", {"waves": 0, "waves_lds": 0, "lanes": 1,
+    c.set_option("compress_mode", {"spans": 0, "spans_lds": 0, "waves": 0,
+                                   "waves_lds": 0, "lanes": 1,
                                    "lanes_segmented": 1, "lanes_overlap": 1,
                                    "both": 2}[
         request.param])
-    # waves: five tables per CU, input from L2; waves_lds: one block per CU,
-    # table and input block in LDS (the kernel of the smallest batches)
-    c.set_option("small_batch_kernel", 2 if request.param == "waves_lds"
-                 else 0)
+    # spans / waves: five tables per CU, input from L2; *_lds: one block per
+    # CU, table and input block in LDS (the kernel of the smallest batches).
+    # spans*: a window of 63 positions per step (k_compress_spans, the
+    # default); waves*: one copy per step (k_compress_blocks, rounds 1-3)
+    c.set_option("small_batch_kernel",
+                 2 if request.param in ("waves_lds", "spans_lds") else 0)
+    c.set_option("span_kernel",
+                 0 if request.param in ("waves", "waves_lds") else 1)
     c.set_option("lane_min_blocks", 1)
     # streams under 256 bytes / under 2 KiB are k_compress_tiny's /
     # k_compress_small's by default; two of the six configurations keep them

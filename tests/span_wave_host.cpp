@@ -1,0 +1,244 @@
+// TEST INFRASTRUCTURE: k_compress_spans (rust-snappy_amd/csrc/snapmi_compress.hip)
+// on the host.  The uniform half of a step - span_walk() of
+// rust-snappy_amd/csrc/snapmi_span.hpp, the very text the kernel compiles - runs
+// as it is; the 64 lanes around it (hash, the lane-ordered table exchange,
+// the 16-byte compare, the lane-ordered store that puts the table right, the
+// schedule-ordered step of long miss runs) are emulated one lane after the
+// other in ascending order, which is the order gfx950 applies the lanes of one
+// DS instruction in (tests/hw/lds_atomic_order.hip, lds_write_order.hip).
+// tests/test_span_wave_cpu.py compares the stream with the oracle's.  Never
+// linked into the product library.
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+#include "snapmi_span.hpp"
+
+namespace {
+using namespace snapmi;
+
+struct Delta {
+    uint32_t d[448];
+    Delta()
+    {
+        uint32_t skip = 32, p = 0;
+        for (int i = 0; i < 448; i++) {
+            d[i] = p < 0x100000u ? p : 0x100000u;
+            const uint32_t step = skip >> 5;
+            p += step;
+            skip += step;
+        }
+    }
+};
+const Delta kDelta;
+
+uint32_t le32(const uint8_t *p)
+{
+    uint32_t v;
+    memcpy(&v, p, 4);
+    return v;
+}
+uint32_t common(const uint8_t *a, const uint8_t *b, uint32_t lim)
+{
+    uint32_t m = 0;
+    while (m < lim && a[m] == b[m])
+        m++;
+    return m;
+}
+
+struct Token {
+    uint32_t lit, len, off;
+};
+struct Sink {
+    std::vector<Token> t;
+    void token(uint32_t lit, uint32_t len, uint32_t off)
+    {
+        t.push_back({lit, len, off});
+    }
+};
+struct Lanes {
+    uint32_t mv[64], ov[64];
+    uint32_t m(uint32_t l) const { return mv[l]; }
+    uint32_t old(uint32_t l) const { return ov[l]; }
+};
+
+struct Out {
+    uint8_t *p;
+    uint32_t cap, bad;
+    const uint8_t *in;
+    uint32_t in8(uint32_t k) { return in[k]; }
+    uint32_t in32(uint32_t k) { return le32(in + k); }
+    void out8(uint32_t k, uint32_t v)
+    {
+        if (k >= cap)
+            bad = 1;
+        else
+            p[k] = (uint8_t)v;
+    }
+    void out32(uint32_t k, uint32_t v)
+    {
+        if (k + 4 > cap)
+            bad = 1;
+        else
+            memcpy(p + k, &v, 4);
+    }
+};
+} // namespace
+
+// stats[0] window steps, [1] schedule steps, [2] cuts, [3] long matches,
+// [4] tokens, [5] lanes touched, [6] walk events (copies + chain misses)
+extern "C" uint32_t span_wave_compress(const uint8_t *src, uint32_t n,
+                                       uint8_t *out, uint32_t out_cap,
+                                       uint64_t *stats)
+{
+    if (n == 0 || n > 65536)
+        return 0x80000000u;
+    Out o{out, out_cap, 0, src};
+    uint32_t d = 0;
+    for (uint32_t v = n;;) {
+        if (v < 128) {
+            o.out8(d++, v);
+            break;
+        }
+        o.out8(d++, (v & 127) | 128);
+        v >>= 7;
+    }
+    if (n < 17) {
+        d = tiny_put_literal(o, d, 0, n);
+        return o.bad ? 0x80000001u : d;
+    }
+    uint32_t shift = 24;
+    for (uint32_t size = 256; size < 16384 && size < n; size *= 2)
+        shift--;
+    static thread_local uint16_t table[16384];
+    memset(table, 0, sizeof table);
+    const uint32_t s_limit = n - 15;
+    SpanState st{1, 0, 0, 0};
+    Sink sink;
+    Lanes ln;
+    uint32_t run0 = 1;
+    bool done = false;
+    while (!done) {
+        if (!st.chain && st.q >= kSpanRun) {
+            // the schedule-ordered step (k_compress_blocks' batch, q > 0):
+            // lane l = probe q + l of the run that began at run0
+            stats[1]++;
+            uint32_t p[64], h[64], cand[64], m[64];
+            bool valid[64];
+            bool any_invalid = false;
+            int kh = -1;
+            for (uint32_t l = 0; l < 64; l++) {
+                p[l] = run0 + kDelta.d[st.q + l];
+                const uint32_t nextp = run0 + kDelta.d[st.q + l + 1];
+                valid[l] = nextp <= s_limit;
+                any_invalid |= !valid[l];
+                cand[l] = 0;
+                m[l] = 0;
+                if (valid[l]) {
+                    h[l] = tiny_hash(le32(src + p[l]), shift);
+                    cand[l] = table[h[l]];
+                    table[h[l]] = (uint16_t)p[l];
+                    m[l] = common(src + p[l], src + cand[l], 16);
+                    if (m[l] >= 4 && kh < 0)
+                        kh = (int)l;
+                }
+            }
+            if (kh < 0) {
+                if (any_invalid)
+                    break;
+                st.q += 64;
+                continue;
+            }
+            for (uint32_t l = kh + 1; l < 64; l++)
+                if (valid[l] && cand[l] <= p[kh])
+                    table[h[l]] = (uint16_t)cand[l];
+            uint32_t len = m[kh];
+            if (len == 16)
+                len += common(src + p[kh] + 16, src + cand[kh] + 16,
+                              n - p[kh] - 16);
+            sink.token(p[kh] - st.next_emit, len, p[kh] - cand[kh]);
+            st.s = p[kh] + len;
+            st.next_emit = st.s;
+            st.chain = 1;
+            st.q = 0;
+            if (st.s >= s_limit)
+                break;
+            continue;
+        }
+        // the window step
+        stats[0]++;
+        const uint32_t base = st.s, lo = st.s - st.chain;
+        bool act[64];
+        uint32_t h[64];
+        uint64_t hits = 0, cbits = 0;
+        for (uint32_t l = 0; l < 64; l++) {
+            const uint32_t P = base - 1 + l;
+            act[l] = l ? P + 16 <= n : st.chain != 0;
+            ln.mv[l] = 0;
+            ln.ov[l] = 0;
+            if (!act[l])
+                continue;
+            h[l] = tiny_hash(le32(src + P), shift);
+            ln.ov[l] = table[h[l]];
+            table[h[l]] = (uint16_t)P;
+            ln.mv[l] = common(src + P, src + ln.ov[l], 16);
+            if (l && ln.mv[l] >= 4)
+                hits |= 1ull << l;
+            if (ln.ov[l] >= lo)
+                cbits |= 1ull << l;
+        }
+        uint64_t T = 0;
+        uint32_t at = 0;
+        const size_t tok0 = sink.t.size();
+        const uint32_t q0 = st.q, chain0 = st.chain;
+        const uint32_t rc = span_walk(st, hits, cbits, s_limit, ln, sink, T, at);
+        (void)q0;
+        (void)chain0;
+        stats[5] += (uint64_t)__builtin_popcountll(T);
+        stats[6] += sink.t.size() - tok0;
+        for (uint32_t l = 0; l < 64; l++) {
+            if (!act[l])
+                continue;
+            const bool t = (T >> l) & 1, c = (cbits >> l) & 1;
+            if (t)
+                table[h[l]] = (uint16_t)(base - 1 + l);
+            else if (!c)
+                table[h[l]] = (uint16_t)ln.ov[l];
+        }
+        if (rc == kSpanLong) {
+            stats[3]++;
+            const uint32_t P = st.s, cand = ln.ov[at];
+            const uint32_t len =
+                16 + common(src + P + 16, src + cand + 16, n - P - 16);
+            sink.token(P - st.next_emit, len, P - cand);
+            st.s = P + len;
+            st.next_emit = st.s;
+            st.chain = 1;
+            st.q = 0;
+            if (st.s >= s_limit)
+                done = true;
+        } else if (rc == kSpanDone) {
+            done = true;
+        } else if (!st.chain && st.q >= kSpanRun) {
+            run0 = st.s - st.q;
+        } else if (base - 1 + 64 > st.s && !(st.chain && 0)) {
+            // (a step that ended inside its window: cut or deferred insert)
+            if (st.s < base - 1 + 60)
+                stats[2]++;
+        }
+    }
+    stats[4] += sink.t.size();
+    uint32_t atpos = 0;
+    for (const Token &t : sink.t) {
+        if (t.lit) {
+            d = tiny_put_literal(o, d, atpos, t.lit);
+            atpos += t.lit;
+        }
+        d = tiny_put_copy(o, d, t.off, t.len);
+        atpos += t.len;
+    }
+    if (st.next_emit < n)
+        d = tiny_put_literal(o, d, st.next_emit, n - st.next_emit);
+    return o.bad ? 0x80000001u : d;
+}
