@@ -279,6 +279,9 @@ int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value)
         ctx->lane_speculate = (int)value;
     else if (strcmp(name, "span_kernel") == 0 && value >= 0 && value <= 1)
         ctx->span_kernel = (int)value;
+    else if (strcmp(name, "both_wave_cus") == 0 && value >= 0 &&
+             value <= 4096)
+        ctx->both_wave_cus = (uint32_t)value;
     else if (strcmp(name, "tiny_stream_kernel") == 0 && value >= 0 &&
              value <= 1)
         ctx->tiny_stream_kernel = (int)value;
@@ -838,8 +841,13 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
             } else {
                 const uint64_t want =
                     (blocks + kCompressWaves - 1) / kCompressWaves;
-                const uint32_t wgs = (uint32_t)(
-                    want < (uint64_t)ctx->num_cus ? want : ctx->num_cus);
+                // (beside the lane kernel it takes a share of the CUs only:
+                // a persistent workgroup owns its CU's whole LDS)
+                const uint64_t cus =
+                    lanes_mode ? (ctx->both_wave_cus ? ctx->both_wave_cus
+                                                     : ctx->num_cus / 2)
+                               : (uint64_t)ctx->num_cus;
+                const uint32_t wgs = (uint32_t)(want < cus ? want : cus);
                 hipLaunchKernelGGL(ctx->span_kernel ? k_compress_spans
                                                     : k_compress_blocks,
                                    dim3(wgs), dim3(kCompressWaves * 64), 0, ws,

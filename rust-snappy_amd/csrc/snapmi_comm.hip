@@ -203,7 +203,11 @@ int snapmi_gatherv(snapmi_ctx *ctx, snapmi_comm *c, int root,
     hipStream_t s = ctx->stream;
     const int W = c->world;
     // 1. sizes (and the root's capacity): two u64 per rank, everywhere
-    const uint64_t mine[2] = {send_bytes, recv_cap};
+    // (a root without a receive buffer advertises capacity 0: then "the
+    // root's buffer is too small" is every rank's error below, and no rank
+    // enters the exchange to wait for a receive that is never posted)
+    const uint64_t mine[2] = {send_bytes,
+                              c->rank == root && !d_recv ? 0 : recv_cap};
     uint64_t *d_mine = c->d_sizes + 2 * (size_t)W;
     HIP_TRY(ctx, hipMemcpyAsync(d_mine, mine, sizeof mine,
                                 hipMemcpyHostToDevice, s));
@@ -232,8 +236,6 @@ int snapmi_gatherv(snapmi_ctx *ctx, snapmi_comm *c, int root,
                                 "buffer holds %llu",
                                 (unsigned long long)sum,
                                 (unsigned long long)cap);
-    if (c->rank == root && sum && !d_recv)
-        return SNAPMI_E_ARGUMENT;
     // 2. one group of point-to-point operations
     NCCL_TRY(ctx, r.GroupStart());
     ncclResult_t bad = 0;

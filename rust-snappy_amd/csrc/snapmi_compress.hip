@@ -211,6 +211,19 @@ struct TokenSink {
             flush();
     }
 
+    // the same without the flush: for a caller that makes room itself
+    // (k_compress_spans: at most 17 tokens per step, one flush site)
+    __device__ __forceinline__ void record_nf(uint32_t lit_start,
+                                              uint32_t lit_len,
+                                              uint32_t offset,
+                                              uint32_t copy_len)
+    {
+        const bool me = lane == t;
+        a = me ? ((lit_len & 0xFFFFu) | (offset << 16)) : a;
+        b = me ? (copy_len | (lit_start << 16)) : b;
+        t++;
+    }
+
     // Encode the pending tokens: reference emit_literal (src/compress.rs:
     // 433-474) and emit_copy / emit_copy2 (:323-369), one token per lane.
     __device__ __forceinline__ void flush()
@@ -950,7 +963,7 @@ struct SpanSink {
     __device__ __forceinline__ void token(uint32_t lit, uint32_t len,
                                           uint32_t off)
     {
-        out->record(emit, lit, off, len);
+        out->record_nf(emit, lit, off, len);
         emit += lit + len;
     }
 };
@@ -1067,6 +1080,10 @@ __device__ __forceinline__ void compress_one_block_span(
         n_batches++;
 #endif
         TICK(0);
+        // room for a step's tokens (at most 16 copies of a window + a long
+        // match): the one place where tokens are encoded
+        if (out.t + 17 > kWave)
+            out.flush();
         if (!st.chain && st.q >= kSpanRun) {
             // ---- schedule step (k_compress_blocks' batch for q > 0): lane l
             // is probe q + l of the run that began at run0
@@ -1146,10 +1163,60 @@ __device__ __forceinline__ void compress_one_block_span(
             const uint64_t hits = __ballot(active && lane && ln.mv >= 4);
             const uint64_t cbits = __ballot(cbit);
             uint64_t touched = 0;
-            uint32_t at = 0;
+            uint32_t at = 0, rc = kSpanCont;
             st.next_emit = sink.emit;
-            const uint32_t rc =
-                span_walk(st, hits, cbits, s_limit, ln, sink, touched, at);
+            // the fast walk (snapmi_span.hpp): the scalar unit follows the
+            // chain of copies, the lanes derive everything else at once
+            bool fast = span_fast_ok(st, hits, n);
+            if (fast) {
+                const uint64_t longs =
+                    __ballot(active && lane && ln.mv >= 16);
+                SpanFast f;
+                span_fast_walk(hits, longs, ln, f);
+                uint64_t vh;
+                span_fast_masks(f, hits, st.chain, 64, vh, touched);
+                // an inserted lane with a C bit needs the lane it collided
+                // with inserted too: the step ends in front of the lowest
+                // lane where that fails (span_walk's cut)
+                uint32_t cut = 64;
+                if (cbits & touched) {
+                    const uint32_t pred = old - (base - 1);
+                    const bool mine = (touched >> lane) & 1;
+                    const uint64_t bad = __ballot(
+                        mine && cbit && !((touched >> (pred & 63)) & 1));
+                    if (bad) {
+                        cut = (uint32_t)__builtin_ctzll(bad);
+                        span_fast_masks(f, hits, st.chain, cut, vh, touched);
+                    }
+                }
+                const uint32_t cnt = (uint32_t)__builtin_popcountll(vh);
+                if (cnt) {
+                    uint32_t lit, rank;
+                    span_fast_token(lane, base, sink.emit, f.inside, vh, lit,
+                                    rank);
+                    const bool is_vh = (vh >> lane) & 1;
+                    // token of lane X goes to sink lane t + rank: a push
+                    // (ds_permute); the other lanes push to a lane outside
+                    // [t, t + cnt) whose value is not taken
+                    const uint32_t to =
+                        is_vh ? out.t + rank : (out.t + cnt) & 63u;
+                    const uint32_t ta = (lit & 0xFFFFu) | ((P - old) << 16);
+                    const uint32_t tb = ln.mv | ((P - lit) << 16);
+                    const uint32_t ra = (uint32_t)__builtin_amdgcn_ds_permute(
+                        (int)(to << 2), (int)ta);
+                    const uint32_t rb = (uint32_t)__builtin_amdgcn_ds_permute(
+                        (int)(to << 2), (int)tb);
+                    const bool got = lane - out.t < cnt;
+                    out.a = got ? ra : out.a;
+                    out.b = got ? rb : out.b;
+                    out.t += cnt;
+                }
+                rc = span_fast_state(st, f, cut, sink.emit);
+                at = f.at;
+            }
+            if (!fast)
+                rc = span_walk(st, hits, cbits, s_limit, ln, sink, touched,
+                               at);
             TICK(4);
             // the table as the reference leaves it: one lane-ordered store
             {
@@ -1202,7 +1269,7 @@ __device__ __forceinline__ void compress_one_block_span(
         TICK(7);
     }
     if (sink.emit < n) // done(): src/compress.rs:417-426
-        out.record(sink.emit, n - sink.emit, 0, 0);
+        out.record_nf(sink.emit, n - sink.emit, 0, 0);
     if (out.t)
         out.flush();
     if (lane == 0)

@@ -68,6 +68,10 @@ struct snapmi_ctx {
     // 0 = one copy per step (k_compress_blocks / k_compress_block_lds, the
     // kernels of rounds 1-3: kept as the cross-check)
     int span_kernel = 1;
+    // compress_mode 2 ("both"): CUs the wavefront kernel's persistent
+    // workgroups take (each owns a CU's whole LDS, so the lane kernel's
+    // wavefronts run on the others); 0 = half of the CUs
+    uint32_t both_wave_cus = 0;
     // 1 (default): a lane-kernel launch of at most lane_speculate_max_blocks
     // blocks (and no more blocks than lanes) runs k_match_blocks_spec (a
     // probe's round also fetches the entry of the probe that follows a

@@ -1206,14 +1206,27 @@ __global__ __launch_bounds__(256) void k_to_host(uint8_t *host,
 }
 
 // is [p, p + n) host memory a kernel may write (pinned and mapped)?
-static bool device_visible(const void *p)
+static bool device_visible_at(const void *p)
 {
     hipPointerAttribute_t at;
     if (hipPointerGetAttributes(&at, p) != hipSuccess) {
         (void)hipGetLastError(); // plain malloc memory: not an error here
         return false;
     }
-    return at.type == hipMemoryTypeHost && at.devicePointer != nullptr;
+    // (the copy kernel stores through the HOST address: memory that is
+    // mapped at another device address - hipHostRegister without unified
+    // addressing - goes home by hipMemcpyAsync instead)
+    return at.type == hipMemoryTypeHost && at.devicePointer == p;
+}
+// k_to_host may store to [p, p + n): both ends pinned and mapped at their
+// host address (a buffer that starts in a pinned region and leaves it - a
+// caller's offset into a smaller registration - must not reach the kernel)
+static bool device_visible(const void *p, size_t n)
+{
+    if (!p || !n)
+        return false;
+    return device_visible_at(p) &&
+           device_visible_at((const uint8_t *)p + (n - 1));
 }
 
 static int copy_home(snapmi_ctx *ctx, hipStream_t st, uint8_t *h_dst,
@@ -1565,6 +1578,27 @@ static int host_pipe(snapmi_ctx *ctx, snapmi_host_pipe **out)
     return SNAPMI_OK;
 }
 
+// Every exit of a host-buffer call that comes after its first asynchronous
+// operation goes through this: an early return (a failed allocation, a
+// capacity check, an error of the codec call) must not hand the caller's
+// buffers back while copies of earlier slices still read or write them, and
+// the next call relies on "the previous call ended with its streams idle".
+namespace {
+struct PipeDrain {
+    snapmi_ctx *ctx;
+    snapmi_host_pipe *pipe;
+    bool armed = true;
+    ~PipeDrain()
+    {
+        if (!armed)
+            return;
+        (void)hipStreamSynchronize(pipe->s_in);
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamSynchronize(pipe->s_out);
+    }
+};
+} // namespace
+
 static int slot_offsets(snapmi_ctx *ctx, PipeSlot &sl, size_t n)
 {
     if (n <= sl.h_off_cap)
@@ -1628,6 +1662,7 @@ int snapmi_frame_encode_host(snapmi_ctx *ctx, const uint8_t *h_in,
     if (rc)
         return rc;
     hipStream_t sK = ctx->stream;
+    PipeDrain drain{ctx, P};
     // Slices: the match finder wants large launches (its latency floor is
     // ~35 ms whatever the size: DESIGN 4.1), the pipeline wants several
     // slices; by default a batch of 1 GiB or more is cut in two to three.
@@ -1658,7 +1693,7 @@ int snapmi_frame_encode_host(snapmi_ctx *ctx, const uint8_t *h_in,
     const size_t ns = sl.size();
     uint64_t out_off = 0;
     const bool out_by_kernel =
-        (ctx->host_copy_kernel & 2) && device_visible(h_out);
+        (ctx->host_copy_kernel & 2) && device_visible(h_out, out_cap);
     // step t: copy slice t in, start the kernels of slice t-1, send the
     // result of slice t-2 home
     for (size_t t = 0; t < ns + 2; t++) {
@@ -1719,6 +1754,7 @@ int snapmi_frame_encode_host(snapmi_ctx *ctx, const uint8_t *h_in,
         }
     }
     HIP_TRY(ctx, hipStreamSynchronize(P->s_out));
+    drain.armed = false; // (every copy in and every kernel lies in front)
     *written = (size_t)out_off;
     return SNAPMI_OK;
 }
@@ -1744,6 +1780,7 @@ int snapmi_frame_decode_host(snapmi_ctx *ctx, const uint8_t *h_in,
     if (rc)
         return rc;
     hipStream_t sK = ctx->stream;
+    PipeDrain drain{ctx, P};
     const bool final = (flags & SNAPMI_FRAME_FINAL) != 0;
     uint32_t cflag = flags & SNAPMI_FRAME_CONTINUATION;
     uint8_t stale[10] = {0}; // the reader's src[0..10) in front of `pos`
@@ -1751,7 +1788,7 @@ int snapmi_frame_decode_host(snapmi_ctx *ctx, const uint8_t *h_in,
         memcpy(stale, stale10, 10);
     const uint64_t slice_chunks = ctx->host_decode_slice_chunks;
     const bool out_by_kernel =
-        (ctx->host_copy_kernel & 1) && out_cap && device_visible(h_out);
+        (ctx->host_copy_kernel & 1) && device_visible(h_out, out_cap);
 
     static const bool trace = getenv("SNAPMI_PIPE_TRACE") != nullptr;
     static hipEvent_t ev_base = nullptr;
@@ -1931,6 +1968,7 @@ int snapmi_frame_decode_host(snapmi_ctx *ctx, const uint8_t *h_in,
         if ((rc = retire(k)))
             return rc;
     HIP_TRY(ctx, hipStreamSynchronize(P->s_out));
+    drain.armed = false; // all slices retired, their copies home are done
     if (trace) {
         for (int k = 0; k < kSlots; k++) {
             float a = 0;

@@ -84,6 +84,9 @@ SNAPMI_LANE_FN uint32_t span_walk(SpanState &st, const uint64_t hits,
     bool chain = st.chain != 0;
     const uint64_t stop = hits | cbits;
     uint32_t rc = kSpanCont;
+    // (the state is written once, behind the loop, from these: stores into
+    // `st` from a dozen branches keep the struct in scratch memory)
+    uint32_t ns = base, nq = st.q, nchain = st.chain, nemit = st.next_emit;
     for (;;) {
         uint32_t P = base - 1 + L;
         if (!chain) {
@@ -108,9 +111,9 @@ SNAPMI_LANE_FN uint32_t span_walk(SpanState &st, const uint64_t hits,
                 P += k;
             }
             if (k == room) { // a limit, whatever lane L holds
-                st.s = P;
-                st.q = q;
-                st.chain = 0;
+                ns = P;
+                nq = q;
+                nchain = 0;
                 rc = P + 1 > s_limit ? kSpanDone : kSpanCont;
                 break;
             }
@@ -120,9 +123,9 @@ SNAPMI_LANE_FN uint32_t span_walk(SpanState &st, const uint64_t hits,
         if (cbits & bit) {
             const uint32_t pred = ln.old(L) - (base - 1);
             if (!((T >> pred) & 1)) { // cut: the next step starts here
-                st.s = P;
-                st.q = q;
-                st.chain = chain ? 1 : 0;
+                ns = P;
+                nq = q;
+                nchain = chain ? 1 : 0;
                 break;
             }
         }
@@ -131,16 +134,16 @@ SNAPMI_LANE_FN uint32_t span_walk(SpanState &st, const uint64_t hits,
             const uint32_t m = ln.m(L);
             if (m >= 16) {
                 at = L;
-                st.s = P;
+                ns = P;
                 rc = kSpanLong;
                 break;
             }
-            sink.token(P - st.next_emit, m, P - ln.old(L));
+            sink.token(P - nemit, m, P - ln.old(L));
             const uint32_t e = P + m;
-            st.next_emit = e;
-            st.s = e;
-            st.q = 0;
-            st.chain = 1;
+            nemit = e;
+            ns = e;
+            nq = 0;
+            nchain = 1;
             if (e >= s_limit) {
                 rc = kSpanDone;
                 break;
@@ -166,8 +169,176 @@ SNAPMI_LANE_FN uint32_t span_walk(SpanState &st, const uint64_t hits,
             L++;
         }
     }
+    st.s = ns;
+    st.q = nq;
+    st.chain = nchain;
+    st.next_emit = nemit;
     touched = T;
     return rc;
+}
+
+// ---------------------------------------------------------------------
+// The fast walk.  span_walk above costs the scalar unit ~70 instructions and
+// ten branches per copy (measured: 5 700 of a step's 10 000 cycles on text,
+// nine copies per step).  But where the parse GOES depends on nothing but the
+// hit mask and the match lengths: from a lookup at lane L the next hit X is a
+// find-first-set, the lookup after a copy of m bytes is lane X + m.  So the
+// scalar unit only follows the chain of copies and collects the lanes INSIDE
+// them (X+1 .. X+m-1: never looked up) - a dozen instructions per copy - and
+// everything else is derived for all lanes at once: the lanes looked up are
+// the ones outside copies, the lanes inserted are those plus the last lane
+// inside every copy (src/compress.rs:290-297: insert e - 1), a hit lane's
+// literal starts behind the last inside lane below it, its place among the
+// wave's tokens is a population count.  Conditions the derivation does not
+// cover send the step to span_walk instead, which is exact everywhere:
+//   * the window reaches the block's limit region (s_limit checks, done());
+//   * 32 lanes in a row without a hit (the run-length rule, kSpanRun).
+// span_walk's cut (an inserted lane with a C bit whose lower lane is not
+// inserted) is a mask operation here: the step ends in front of the lowest
+// such lane.
+// ---------------------------------------------------------------------
+enum : uint32_t {
+    kFastRun = 0,     // no hit from lane `at` (a chain check) to the window's end
+    kFastCopyOut = 1, // the copy at lane `at` ends at lane `end` >= 64
+    kFastLong = 2,    // lane `at` hits with >= 16 equal bytes
+};
+struct SpanFast {
+    uint64_t inside; // lanes inside copies
+    uint32_t kind, at, end;
+};
+
+// may this step take the fast walk?  n = block length, st.s = window base
+// (written without branches, like the functions below: at five wavefronts
+// per CU a taken scalar branch costs as much as a dozen ALU instructions)
+SNAPMI_LANE_FN bool span_fast_ok(const SpanState &st, const uint64_t hits,
+                                 const uint32_t n)
+{
+    // lanes 1..63 without a hit, as 63 bits: 32 in a row anywhere?
+    const uint64_t z = (~hits) >> 1;
+    uint64_t r = z & (z >> 1);
+    r &= r >> 2;
+    r &= r >> 4;
+    r &= r >> 8;
+    r &= r >> 16;
+    // ... and the run the window may start in (bit 63 of ~z is set)
+    const uint32_t lead = (uint32_t)__builtin_ctzll(~z);
+    const bool run_ok = (st.chain != 0) | (st.q + lead < kSpanRun);
+    // st.s + 93 <= n: every lane active, no limit check can fail, no copy
+    // of fewer than 16 bytes can end the block
+    return (st.s + 93 <= n) & (r == 0) & run_ok;
+}
+
+// hits: lanes (1..63) whose lookup would hit; longs: those of them with 16
+// equal bytes or more.  LN::m(lane) = the match length there.
+template <class LN>
+SNAPMI_LANE_FN void span_fast_walk(const uint64_t hits, const uint64_t longs,
+                                   const LN &ln, SpanFast &f)
+{
+    uint64_t inside = 0, ahead;
+    uint32_t L = 1, X = 0, e = 0;
+    for (;;) {
+        ahead = hits >> L; // L <= 63
+        if (!ahead)
+            break; // no hit from the chain check at L on
+        X = L + (uint32_t)__builtin_ctzll(ahead);
+        e = X + ln.m(X);
+        // a long match, or a copy whose last byte is lane 63 or beyond (the
+        // insert of e - 1 and the check at e are the next step's)
+        if (((longs >> X) & 1) | (e >= 64))
+            break;
+        inside |= ((1ull << (e - X - 1)) - 1) << (X + 1); // X+1 .. e-1
+        L = e;
+    }
+    const bool run = !ahead;
+    const bool lng = !run & (((longs >> X) & 1) != 0);
+    const bool out = !run & !lng;
+    f.inside = inside | (out ? (~0ull << X) << 1 : 0);
+    f.kind = run ? kFastRun : (lng ? kFastLong : kFastCopyOut);
+    f.at = run ? L : X;
+    f.end = out ? e : 0;
+}
+
+// What the lanes are, as masks: vh = lanes whose copy becomes a token of this
+// step, touched = lanes the reference inserts (bit 0: the insert of s - 1).
+// cut < 64: the step ends in front of lane `cut` (an inserted lane with a C
+// bit whose lower lane is not inserted: span_walk's cut; cut >= 1) - what
+// lies below stands as it is.
+SNAPMI_LANE_FN void span_fast_masks(const SpanFast &f, const uint64_t hits,
+                                    const uint32_t chain0, const uint32_t cut,
+                                    uint64_t &vh, uint64_t &touched)
+{
+    // lanes 1 .. stop-1 were walked: a long match ends the walk at its lane
+    // (which is looked up, hence inserted), a cut in front of its lane
+    const uint32_t lstop = f.kind == kFastLong ? f.at + 1 : 64;
+    const uint32_t stop = cut < lstop ? cut : lstop; // 1 .. 64
+    const uint64_t range = (~0ull >> (64 - stop)) & ~1ull;
+    const uint64_t visited = range & ~f.inside;
+    const uint64_t lbit = f.kind == kFastLong ? 1ull << f.at : 0;
+    vh = visited & hits & ~lbit;
+    // the last lane inside every copy is inserted; lane 63 never is (a copy
+    // that reaches it leaves the window: kFastCopyOut)
+    const uint64_t ins =
+        f.inside & ~(f.inside >> 1) & ~(1ull << 63) & range;
+    touched = visited | ins | (chain0 ? 1ull : 0ull);
+}
+
+// lane l's token if it is in vh: literal length and start; its rank among the
+// step's tokens.  emit0 = first byte not covered when the step began.
+SNAPMI_LANE_FN void span_fast_token(const uint32_t l, const uint32_t base,
+                                    const uint32_t emit0, const uint64_t inside,
+                                    const uint64_t vh, uint32_t &lit,
+                                    uint32_t &rank)
+{
+    const uint64_t below = (1ull << l) - 1; // l <= 63
+    const uint64_t in_b = inside & below;
+    const uint32_t P = base - 1 + l;
+    // the literal starts behind the last lane inside a copy below l
+    lit = in_b ? l - 1 - (63u - (uint32_t)__builtin_clzll(in_b)) : P - emit0;
+    rank = (uint32_t)__builtin_popcountll(vh & below);
+}
+
+// the state behind a fast step (returns kSpanLong with st.s = the hit's
+// position when the caller has a long match to finish, kSpanCont otherwise);
+// emit = the new "first byte not covered"
+SNAPMI_LANE_FN uint32_t span_fast_state(SpanState &st, const SpanFast &f,
+                                        const uint32_t cut, uint32_t &emit)
+{
+    const uint32_t base = st.s;
+    const bool is_cut = cut < 64;
+    const bool is_long = !is_cut & (f.kind == kFastLong);
+    const bool is_out = !is_cut & (f.kind == kFastCopyOut);
+    const bool is_run = !is_cut & (f.kind == kFastRun);
+    // the inside lanes that count: below the cut, below a long match's lane
+    const uint32_t lim = is_cut ? cut : (is_long ? f.at : 64); // 1 .. 64
+    const uint64_t in_b = f.inside & (~0ull >> (64 - lim));
+    const uint32_t hb = 63u - (uint32_t)__builtin_clzll(in_b | 1);
+    // a cut: in front of the insert behind a copy (the copy stands, insert
+    // and check are the next step's), of a chain check, or of a probe
+    const bool cut_ins = is_cut & (((f.inside >> (cut & 63)) & 1) != 0);
+    const bool cut_chk =
+        is_cut & !cut_ins &
+        (cut == 1 ? st.chain != 0
+                  : ((f.inside >> ((cut - 1) & 63)) & 1) != 0);
+    const bool cut_run = is_cut & !cut_ins & !cut_chk;
+    const uint32_t q_cut =
+        in_b ? cut - (hb + 2) : (st.chain ? cut - 2 : st.q + cut - 1);
+    uint32_t nemit = in_b ? base + hb : emit;
+    nemit = cut_ins ? base + cut : nemit;
+    nemit = is_out ? base - 1 + f.end : nemit;
+    const uint32_t ns = (cut_ins | is_out)
+                            ? nemit
+                            : (is_run ? base + 63
+                                      : base - 1 + (is_cut ? cut : f.at));
+    const uint32_t nchain =
+        (cut_ins | cut_chk | is_out) ? 1 : (is_long ? st.chain : 0);
+    const uint32_t nq =
+        cut_run ? q_cut : (is_run ? 63 - f.at : (is_long ? st.q : 0));
+    st.s = ns;
+    st.q = nq;
+    st.chain = nchain;
+    st.next_emit = nemit;
+    emit = nemit;
+    return is_long ? kSpanLong : kSpanCont;
 }
 
 } // namespace snapmi

@@ -86,8 +86,10 @@ struct Out {
 };
 } // namespace
 
-// stats[0] window steps, [1] schedule steps, [2] cuts, [3] long matches,
-// [4] tokens, [5] lanes touched, [6] walk events (copies + chain misses)
+// stats[0] window steps, [1] schedule steps, [2] cuts of fast steps, [3] long
+// matches,
+// [4] tokens, [5] lanes touched, [6] tokens of window steps, [7] window
+// steps that took the fast walk
 extern "C" uint32_t span_wave_compress(const uint8_t *src, uint32_t n,
                                        uint8_t *out, uint32_t out_cap,
                                        uint64_t *stats)
@@ -189,12 +191,51 @@ extern "C" uint32_t span_wave_compress(const uint8_t *src, uint32_t n,
                 cbits |= 1ull << l;
         }
         uint64_t T = 0;
-        uint32_t at = 0;
+        uint32_t at = 0, rc = kSpanCont;
         const size_t tok0 = sink.t.size();
-        const uint32_t q0 = st.q, chain0 = st.chain;
-        const uint32_t rc = span_walk(st, hits, cbits, s_limit, ln, sink, T, at);
-        (void)q0;
-        (void)chain0;
+        // the kernel's order: the fast walk where its conditions hold, the
+        // exact walk otherwise
+        bool fast = span_fast_ok(st, hits, n);
+        if (fast) {
+            uint64_t longs = 0;
+            for (uint32_t l = 1; l < 64; l++)
+                if (act[l] && ln.mv[l] >= 16)
+                    longs |= 1ull << l;
+            SpanFast f;
+            span_fast_walk(hits, longs, ln, f);
+            uint64_t vh;
+            span_fast_masks(f, hits, st.chain, 64, vh, T);
+            uint32_t cut = 64;
+            for (uint32_t l = 0; l < 64; l++) {
+                const uint32_t pred = ln.ov[l] - (base - 1);
+                if (((T >> l) & 1) && ((cbits >> l) & 1) &&
+                    !((T >> (pred & 63)) & 1)) {
+                    cut = l;
+                    break;
+                }
+            }
+            if (cut < 64) {
+                stats[2]++;
+                span_fast_masks(f, hits, st.chain, cut, vh, T);
+            }
+            stats[7]++;
+            for (uint32_t l = 1; l < 64; l++) {
+                if (!((vh >> l) & 1))
+                    continue;
+                uint32_t lit, rank;
+                span_fast_token(l, base, st.next_emit, f.inside, vh, lit,
+                                rank);
+                if (rank != sink.t.size() - tok0)
+                    return 0x80000002u;
+                const uint32_t P = base - 1 + l;
+                sink.token(lit, ln.mv[l], P - ln.ov[l]);
+            }
+            uint32_t emit = st.next_emit;
+            rc = span_fast_state(st, f, cut, emit);
+            at = f.at;
+        }
+        if (!fast)
+            rc = span_walk(st, hits, cbits, s_limit, ln, sink, T, at);
         stats[5] += (uint64_t)__builtin_popcountll(T);
         stats[6] += sink.t.size() - tok0;
         for (uint32_t l = 0; l < 64; l++) {
@@ -222,10 +263,6 @@ extern "C" uint32_t span_wave_compress(const uint8_t *src, uint32_t n,
             done = true;
         } else if (!st.chain && st.q >= kSpanRun) {
             run0 = st.s - st.q;
-        } else if (base - 1 + 64 > st.s && !(st.chain && 0)) {
-            // (a step that ended inside its window: cut or deferred insert)
-            if (st.s < base - 1 + 60)
-                stats[2]++;
         }
     }
     stats[4] += sink.t.size();
