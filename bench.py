@@ -240,12 +240,12 @@ def run_extras(args, local_rank, dev, rank, world):
     if world == 1:
         g3 = args.extras_gib or 64.0
         g5 = args.extras_gib or 32.0
-        plan = (f"cfg3:{g3:g},cfg5:{g5:g},files:2,stream:2,cfg4:8,pcie:4,"
-                "adapters:4,tiny:1")
+        plan = (f"sweep:4,cfg3:{g3:g},cfg5:{g5:g},files:2,stream:2,cfg4:8,"
+                "pcie:4,adapters:4,tiny:1,budget:8")
         cmd = [sys.executable, str(ROOT / "bench_configs.py"), "--plan", plan]
         try:
             p = subprocess.run(cmd, capture_output=True, text=True,
-                               timeout=420)
+                               timeout=540)
             for ln in p.stdout.splitlines():
                 if ln.startswith("{"):
                     rec = json.loads(ln)
@@ -254,7 +254,7 @@ def run_extras(args, local_rank, dev, rank, world):
                 out["error"] = (f"bench_configs.py exit {p.returncode}: "
                                 + p.stderr.strip()[-300:])
         except subprocess.TimeoutExpired:
-            out["error"] = "bench_configs.py --plan timed out (420 s)"
+            out["error"] = "bench_configs.py --plan timed out (540 s)"
         return out
     # N > 1: every rank starts one child (bench_configs.py --plan cfg4) and
     # the children form a process group of their own on a fresh port.  The
@@ -262,13 +262,41 @@ def run_extras(args, local_rank, dev, rank, world):
     # own runs; in a child with a time limit, whatever goes wrong there is a
     # recorded error and not a lost headline line.
     over = os.environ.get("SNAPMI_OVERSUBSCRIBE") == "1"
-    res = rank_children([sys.executable, str(ROOT / "bench_configs.py"),
-                         "--plan", f"cfg4:{(1 if over else 8) * world}"]
-                        + (["--period-mib", "64"] if over else []),
-                        rank, local_rank, world, 300)
+    res = with_deadline(
+        lambda: rank_children(
+            [sys.executable, str(ROOT / "bench_configs.py"), "--plan",
+             f"cfg4:{(1 if over else 8) * world}"]
+            + (["--period-mib", "64"] if over else []),
+            rank, local_rank, world, 300), 420,
+        {"error": f"rank {rank}: cfg4 children: no answer within 420 s "
+                  "(the rendezvous of the child group, or a rank that is "
+                  "gone)"})
     if res is not None:
         out["cfg4"] = res
     return out if rank == 0 else None
+
+
+def with_deadline(fn, seconds, on_timeout):
+    """fn() on a helper thread; its result, or `on_timeout` when it has not
+    come back in time (a collective that waits for a rank that is gone must
+    not take the headline line with it: the thread is left behind, the
+    process exits through os._exit at the end of main in that case)."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            box["v"] = fn()
+        except Exception as e:  # noqa: BLE001 - recorded, not hidden
+            box["v"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    th.join(seconds)
+    if th.is_alive():
+        box["hung"] = True
+        return dict(on_timeout, hung=True)
+    return box.get("v")
 
 
 def rank_children(cmd, rank, local_rank, world, limit_s):
@@ -445,12 +473,37 @@ def main():
     dev = torch.device("cuda", local_rank)
     cdev = torch.device("cpu") if over else dev  # where collectives run
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if over:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+        try:
+            if over:
+                dist.init_process_group(
+                    "gloo", timeout=datetime.timedelta(seconds=600))
+            else:
+                dist.init_process_group(
+                    "nccl", device_id=dev,
+                    timeout=datetime.timedelta(seconds=600))
+                # the first collective is where RCCL really comes up
+                # (communicator, xGMI rings): fail here, with a record,
+                # rather than in the middle of the timed region
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                assert int(probe.item()) == world, probe
+        except Exception as e:  # noqa: BLE001 - recorded, not hidden
+            # no process group: every rank says why (rank 0 on stdout, as the
+            # one JSON line the driver reads) and leaves with an error code
+            msg = f"rank {rank}: process group: {type(e).__name__}: {e}"[:400]
+            log("[bench] " + msg)
+            if rank == 0:
+                print(json.dumps({
+                    "metric": "GiB/s uncompressed (compress + decompress) on "
+                              "zflat/uflat corpus", "value": None,
+                    "unit": "GiB/s", "n_gpus": world, "steps": args.steps,
+                    "warmup": args.warmup, "higher_is_better": True,
+                    "scaling": "weak", "error": msg}), flush=True)
+            sys.exit(3)
 
     import __graft_entry__ as g
     g.build()
@@ -564,6 +617,29 @@ def main():
         t_dec += tc - tb
     barrier()
     elapsed = time.perf_counter() - t0
+    # ---- the same gate AFTER the timed steps: what the last step left in
+    # `comp` and `back` is still the oracle's bytes and the input
+    verified_after = False
+    if not args.no_verify:
+        cl2 = comp_lens.cpu().numpy()
+        assert (cl2 == cl).all(), "compressed lengths changed during the run"
+        assert (kinds(comp_errs) == 0).all() and (kinds(back_errs) == 0).all()
+        for j in range(12):
+            got = comp.stream_bytes(j, cl2[j])
+            assert hashlib.sha256(got).hexdigest() == shas[j][2], \
+                f"after the timed steps: stream {j} differs from the oracle's"
+        if rounds > 1:
+            perc = comp.data[:rounds * c_stride].view(rounds, c_stride)
+            for r in {rounds // 2, rounds - 1}:
+                for j in range(12):
+                    o, m = int(comp.offsets[j]), int(cl2[j])
+                    assert bool((perc[r, o:o + m] == perc[0, o:o + m]).all())
+        for r in {0, rounds // 2, rounds - 1}:
+            for j in range(12):
+                o, m = int(r_offs[j]), int(r_lens[j])
+                assert bool((per[r, o:o + m] == d_round[o:o + m]).all()), \
+                    f"after the timed steps: round trip of stream {j}"
+        verified_after = True
     if rank == 0:
         probe = R._lib.load().snapmi_table_probe_log(ctx._h).decode()
         log(f"[bench] lane-table placement probe ms per candidate: {probe}")
@@ -572,19 +648,39 @@ def main():
             + " | decompress: " + " ".join(f"{x:.1f}" for x in k_dec_ms))
     per_rank = [[float(np.mean(k_dom_ms)), float(np.mean(k_comp_ms)),
                  float(np.mean(k_dec_ms)), elapsed / args.steps * 1e3]]
+    # which physical device this rank drove (the N ranks of a real run must
+    # have N different ones)
+    props = torch.cuda.get_device_properties(dev)
+    my_dev = str(getattr(props, "uuid", None) or
+                 (getattr(props, "pci_domain_id", 0),
+                  getattr(props, "pci_bus_id", local_rank),
+                  getattr(props, "pci_device_id", 0)))
+    coll_error = None
     if world > 1:
-        t = torch.tensor([elapsed, t_comp, t_dec], dtype=torch.float64,
-                         device=cdev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed, t_comp, t_dec = t.tolist()
-        mine = torch.tensor(per_rank[0], dtype=torch.float64, device=cdev)
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        torch.distributed.all_gather(allr, mine)
-        per_rank = [x.tolist() for x in allr]
-        ranks_seen = [None] * world
-        torch.distributed.all_gather_object(ranks_seen, rank)
+        try:
+            t = torch.tensor([elapsed, t_comp, t_dec], dtype=torch.float64,
+                             device=cdev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            elapsed, t_comp, t_dec = t.tolist()
+            mine = torch.tensor(per_rank[0], dtype=torch.float64, device=cdev)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            torch.distributed.all_gather(allr, mine)
+            per_rank = [x.tolist() for x in allr]
+            seen = [None] * world
+            torch.distributed.all_gather_object(seen, (rank, my_dev))
+            ranks_seen = [r for r, _ in seen]
+            devices_seen = [d for _, d in seen]
+        except Exception as e:  # noqa: BLE001 - the line still gets printed
+            coll_error = f"collective after the timed region: " \
+                         f"{type(e).__name__}: {e}"[:300]
+            log(f"[bench] rank {rank}: {coll_error}")
+            ranks_seen, devices_seen = [rank], [my_dev]
     else:
-        ranks_seen = [0]
+        ranks_seen, devices_seen = [0], [my_dev]
+    if world > 1 and not over and coll_error is None and \
+            len(set(devices_seen)) != world:
+        coll_error = (f"{world} ranks drove {len(set(devices_seen))} distinct "
+                      f"device(s): {devices_seen}")
 
     # ---- extra configs (never part of `value`) ---------------------------
     extras = None
@@ -619,7 +715,7 @@ def main():
         ach = alg / kdom / 1e9
         ach_d = alg / kd / 1e9
         dom_name = ("k_match_blocks" if abs(kdom - kc) > 1e-9
-                    else "k_compress_blocks")
+                    else "k_compress_spans")
         dec_name = ("k_decompress_streams2" if os.environ.get(
             "SNAPMI_DECODE_KERNEL") == "2" else "k_decompress_streams3")
         # roofline.traffic: measured by this command (two PMC child runs) -
@@ -712,6 +808,10 @@ def main():
         # decompress kernel, wall per step] in ms (HIP events / host clock)
         line["per_rank_ms"] = [[round(v, 3) for v in r] for r in per_rank]
         line["ranks_seen"] = sorted(ranks_seen)
+        line["devices_seen"] = len(set(devices_seen))
+        line["verified_after_timed_steps"] = verified_after
+        if coll_error is not None:
+            line["error"] = coll_error
         if extras is not None:
             line["extras"] = extras
         if args.no_verify:
@@ -724,6 +824,12 @@ def main():
             line["cpu_baseline"] = cpu_baseline(rnd)
         print(json.dumps(line), flush=True)
     if world > 1:
+        hung = isinstance(extras, dict) and any(
+            isinstance(v, dict) and v.get("hung") for v in extras.values())
+        if hung or coll_error is not None:
+            # a collective is stuck or failed: leave without waiting for it
+            sys.stdout.flush()
+            os._exit(4 if rank == 0 else 5)
         torch.distributed.destroy_process_group()
 
 

@@ -307,6 +307,108 @@ def files(args, ctx, dev):
             "files": rows}
 
 
+def round_tiles(ctx, dev, gib, steps):
+    """The 12-stream zflat/uflat round tiled to `gib` as independent raw
+    streams (bench.py's workload at another size): compress and decompress
+    seconds per pass, round 0 compared with the oracle's bytes, the round
+    trip with the input."""
+    import oracle_lib as O
+    from rust_snappy_amd import batch, raw
+    rnd = O.corpus_round()
+    offs, pos = [], 0
+    for _, d in rnd:
+        offs.append(pos)
+        pos += (len(d) + 15) // 16 * 16
+    one = np.zeros(pos, dtype=np.uint8)
+    for (_, d), o in zip(rnd, offs):
+        one[o:o + len(d)] = np.frombuffer(d, dtype=np.uint8)
+    r_lens = np.array([len(d) for _, d in rnd], dtype=np.int64)
+    rounds = max(1, int(round(gib * GIB / int(r_lens.sum()))))
+    data = torch.from_numpy(one).to(dev).repeat(rounds)
+    o_all = (np.arange(rounds, dtype=np.int64)[:, None] * pos
+             + np.array(offs, dtype=np.int64)[None, :]).reshape(-1)
+    lens = np.tile(r_lens, rounds)
+    n = 12 * rounds
+    src = batch.StreamBatch(data, o_all, lens)
+    caps = np.array([raw.max_compress_len(int(x)) for x in r_lens],
+                    dtype=np.int64)
+    comp = batch.StreamBatch.empty(np.tile(caps, rounds), dev)
+    clens = torch.zeros(n, dtype=torch.int64, device=dev)
+    back = batch.StreamBatch.empty(lens, dev)
+    blens = torch.zeros(n, dtype=torch.int64, device=dev)
+
+    def enc():
+        raw.compress_batch(ctx, src.d_ptrs, src.d_lens, comp.d_ptrs,
+                           comp.d_lens, clens, None, host_in_lens=src.h_lens)
+
+    def dec():
+        raw.decompress_batch(ctx, comp.d_ptrs, clens, back.d_ptrs,
+                             back.d_lens, blens, None)
+
+    enc()
+    ctx.synchronize()
+    cl = clens.cpu().numpy()
+    for j, (_, d) in enumerate(rnd):
+        assert comp.stream_bytes(j, int(cl[j])) == O.compress(d), j
+        k = n - 12 + j
+        assert comp.stream_bytes(k, int(cl[k])) == O.compress(d), k
+    te = time_it(enc, steps, ctx)
+    td = time_it(dec, steps, ctx)
+    for j, (_, d) in enumerate(rnd):
+        assert back.stream_bytes(n - 12 + j) == d, j
+    ub = rounds * int(r_lens.sum())
+    return ub, int(cl.sum()), n, te, td
+
+
+def sweep(args, ctx, dev):
+    """The batch-size regime the headline hides: bench.py's workload (the
+    12-stream round as independent raw streams) at 64 MiB / 256 MiB / 1 GiB /
+    4 GiB per call - what an adapter's batch, a host slice or a frame of a
+    few hundred MiB pays."""
+    rows = {}
+    for label, gib in (("64MiB", 1 / 16), ("256MiB", 0.25), ("1GiB", 1.0),
+                       ("4GiB", 4.0)):
+        if gib > args.gib:
+            continue
+        ub, cb, n, te, td = round_tiles(ctx, dev, gib, max(args.steps, 3))
+        rows[label] = {"gib": round(ub / GIB, 4), "streams": n,
+                       "compress_gibs": round(ub / GIB / te, 2),
+                       "decompress_gibs": round(ub / GIB / td, 2),
+                       "compress_ms": round(te * 1e3, 3),
+                       "decompress_ms": round(td * 1e3, 3)}
+    return {"config": "bench.py's workload (12-stream round, independent raw "
+                      "streams, device resident) by batch size", "sizes": rows}
+
+
+def budget(args, ctx, dev):
+    """What the headline's memory setting buys: bench.py's workload at --gib
+    with the lane tables allowed 75 % (bench.py), 33 % (the library's
+    default) and 15 % of the free device memory - compress GiB/s, the bytes
+    the tables hold afterwards and the most that was held while a placement
+    was chosen (snapmi_table_probe_log)."""
+    from rust_snappy_amd import _lib, raw
+    rows = {}
+    for pct in (75, 33, 15):
+        c = raw.Context(ctx.device)
+        c.set_option("lane_table_budget_pct", pct)
+        free0 = torch.cuda.mem_get_info(dev)[0]
+        ub, cb, n, te, td = round_tiles(c, dev, args.gib, max(args.steps, 3))
+        log = _lib.load().snapmi_table_probe_log(c._h).decode()
+        held = None
+        if "held at most" in log:
+            held = int(log.split("held at most")[1].split()[0])
+        torch.cuda.empty_cache()
+        free1 = torch.cuda.mem_get_info(dev)[0]
+        rows[f"pct{pct}"] = {"compress_gibs": round(ub / GIB / te, 2),
+                             "compress_ms": round(te * 1e3, 2),
+                             "context_bytes": int(free0 - free1),
+                             "held_at_most_during_placement": held}
+        c.close()
+        torch.cuda.empty_cache()
+    return {"config": f"lane_table_budget_pct 75 / 33 / 15 at {args.gib:g} "
+                      "GiB of bench.py's workload", "budgets": rows}
+
+
 def tiny(args, ctx, dev):
     """The tiny-stream regime on its own: zflat03 (the first 200 bytes of
     fireworks.jpeg, bench/src/bench.rs:91) tiled to --gib = 10.7 M streams
@@ -427,7 +529,7 @@ def adapters(args, ctx, dev):
     enc = frame.FrameEncoder(sink, ctx)
     enc.write_all(h_in.view[:64 << 20])
     enc.flush()
-    enc.DIRECT_MAX = 4 << 30
+    enc.DIRECT_MAX = 4 << 30    # one device call for the whole write
     enc.write_all(h_in.view)                    # staging grows here
     enc.flush()
     head0 = bytes(sink.head)
@@ -451,35 +553,70 @@ def adapters(args, ctx, dev):
     enc.write_all(h_in.view[:m])
     enc.flush()
     framed = sink.getvalue()
+    # read_to_end: everything into one bytearray (the reference's Vec<u8>).
+    # Its ceiling is the host's, not the device's: every byte of the result
+    # is written once into memory the process has never touched - timed here
+    # as a plain copy of the same size into a fresh bytearray
     t0 = time.perf_counter()
-    back = frame.FrameDecoder(io.BytesIO(framed), ctx).read_to_end()
-    td = time.perf_counter() - t0
-    assert back == bytes(h_in.view[:m]), "adapter round trip"
-    del back
-    # io::Read::read as the reference has it - into the caller's buffer
-    # (pinned, with room for a batch: the bytes come straight from the call)
+    fresh = bytearray(h_in.view[:m])
+    t_fresh = time.perf_counter() - t0
+    del fresh
+    td = None
+    for _ in range(2):
+        dec = frame.FrameDecoder(io.BytesIO(framed), ctx)
+        t0 = time.perf_counter()
+        back = dec.read_to_end()
+        t = time.perf_counter() - t0
+        td = t if td is None or t < td else td
+        assert len(back) == m and back[:1 << 20] == h_in.view[:1 << 20] and \
+            back[m - (1 << 20):] == h_in.view[m - (1 << 20):m], \
+            "adapter round trip"
+        del back
+        dec.close()
+
+    def readinto_all(reader):
+        """io::Read::read as the reference has it - into the caller's
+        buffer (pinned, with room for a batch: the bytes come straight from
+        the device call)"""
+        dec = frame.FrameDecoder(reader, ctx)
+        t0 = time.perf_counter()
+        pos = 0
+        while True:
+            k = dec.readinto(h_back.view[pos:])
+            if k == 0:
+                break
+            pos += k
+        t = time.perf_counter() - t0
+        assert pos == m and bytes(h_back.view[:1 << 20]) == bytes(
+            h_in.view[:1 << 20]) and bytes(
+            h_back.view[m - (1 << 20):m]) == bytes(
+            h_in.view[m - (1 << 20):m]), "readinto round trip"
+        dec.close()
+        return t
+
     h_back = frame.HostBuffer(m + (256 << 20))
-    dec = frame.FrameDecoder(io.BytesIO(framed), ctx)
-    t0 = time.perf_counter()
-    pos = 0
-    while True:
-        k = dec.readinto(h_back.view[pos:])
-        if k == 0:
-            break
-        pos += k
-    ti = time.perf_counter() - t0
-    assert pos == m and bytes(h_back.view[:1 << 20]) == bytes(
-        h_in.view[:1 << 20]) and bytes(h_back.view[m - (1 << 20):m]) == bytes(
-        h_in.view[m - (1 << 20):m]), "readinto round trip"
+    # ... from Python bytes (io.BytesIO lends its buffer: no host copy, but
+    # the copy to the device reads pageable memory) and from pinned memory
+    # (HostReader: both ends pinned - what the device call itself does)
+    ti = min(readinto_all(io.BytesIO(framed)) for _ in range(2))
+    h_fr = frame.HostBuffer(len(framed))
+    h_fr.view[:] = framed
+    tp = min(readinto_all(frame.HostReader(h_fr.view)) for _ in range(2))
+    h_fr.close()
     h_back.close()
     h_in.close()
     return {"config": "Python streaming adapters over the host-buffer calls: "
                       "FrameEncoder.write_all of one pinned buffer (no copy "
-                      "on the Python side), FrameDecoder.read_to_end",
+                      "on the Python side), FrameDecoder.read_to_end (one "
+                      "bytearray), FrameDecoder.readinto a pinned buffer "
+                      "from io.BytesIO and from a pinned HostReader",
             "gib": round(n / GIB, 3), "framed_bytes": sink_n(sink, framed),
             "frame_encoder_write_all_gibs": round(n / GIB / best, 2),
             "frame_decoder_read_to_end_gibs": round(m / GIB / td, 2),
+            "fresh_bytearray_copy_gibs": round(m / GIB / t_fresh, 2),
             "frame_decoder_readinto_pinned_gibs": round(m / GIB / ti, 2),
+            "frame_decoder_readinto_pinned_from_pinned_gibs": round(
+                m / GIB / tp, 2),
             "decoder_gib": round(m / GIB, 3)}
 
 
@@ -661,7 +798,7 @@ def main():
         ctx.set_option(name, int(value))
     table = {"cfg3": cfg3, "cfg5": cfg5, "files": files, "pcie": pcie,
              "adapters": adapters, "stream": stream, "cfg4": cfg4,
-             "tiny": tiny}
+             "tiny": tiny, "sweep": sweep, "budget": budget}
     if args.plan:
         for item in args.plan.split(","):
             name, gib = item.split(":")

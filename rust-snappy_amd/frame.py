@@ -248,14 +248,32 @@ def decode_host(ctx, data, out, continuation, final, stale):
     written, consumed = C.c_size_t(0), C.c_size_t(0)
     err = _lib.SnapmiError()
     flags = (1 if continuation else 0) | (2 if final else 0)
+    addr, n_in, keep = _address(data)      # bytes, memoryview, pinned view
     rc = L.snapmi_frame_decode_host(
-        ctx._h, data, len(data), flags, (C.c_uint8 * 10).from_buffer(stale),
+        ctx._h, C.c_void_p(addr), n_in, flags,
+        (C.c_uint8 * 10).from_buffer(stale),
         (C.c_char * len(out)).from_buffer(out), len(out), C.byref(written),
         C.byref(consumed), C.byref(err))
+    del keep
     if rc >= 100:
         raw._raise(ctx, rc)
     e = Error(err.kind, err.a, err.b, err.c) if rc else None
     return written.value, consumed.value, e
+
+
+def count_chunks_host(data, continuation):
+    """snapmi_frame_scan_host (host code, no GPU) without a copy of `data`:
+    (data chunks, bytes) of the complete, well-formed chunks at its start."""
+    L = _lib.load()
+    addr, n, keep = _address(data)
+    nd, used = C.c_uint64(0), C.c_uint64(0)
+    rc = L.snapmi_frame_scan_host(C.c_void_p(addr), n,
+                                  1 if continuation else 0, None, None, 0,
+                                  C.byref(nd), C.byref(used))
+    del keep
+    if rc > 3:
+        raise Error(rc, message="snapmi_frame_scan_host")
+    return nd.value, used.value
 
 
 def index_host(data):
@@ -329,9 +347,10 @@ class FrameEncoder:
 
     # a write of at least this many bytes that arrives with an empty block
     # buffer is compressed where it lies (no queue, no copy), at most
-    # DIRECT_MAX bytes per device call
+    # DIRECT_MAX bytes per device call (which bounds the pinned staging of
+    # the framed bytes: 1.2 GiB)
     DIRECT_MIN = 4 << 20
-    DIRECT_MAX = 4 << 30
+    DIRECT_MAX = 1 << 30
 
     def __init__(self, wtr, ctx=None, batch_bytes=BATCH_BYTES):
         self.w = wtr
@@ -366,7 +385,24 @@ class FrameEncoder:
             k = encode_host_into(self.ctx, part, lens, self._stage,
                                  ident=not self._wrote_ident)
             self._wrote_ident = True
-            self.w.write(self._stage.view[:k])
+            self._write_all(self._stage.view[:k])
+
+    def _write_all(self, buf):
+        """io::Write::write_all on the inner writer: a writer may take fewer
+        bytes than it is given (raw files, sockets).  `buf` is BORROWED, as a
+        &[u8] is in the reference: it is only valid during the call (the
+        direct path lends a view of pinned staging memory that the next
+        write overwrites) - a writer that keeps bytes must copy them, which
+        io.BytesIO, files and sockets do."""
+        mv = memoryview(buf).cast("B")
+        while len(mv):
+            k = self.w.write(mv)
+            if k is None or k >= len(mv):   # (None: everything, io.RawIOBase
+                break                        # aside, which says so with 0)
+            if k <= 0:
+                raise OSError("FrameEncoder: the inner writer accepts no "
+                              "more bytes (write returned 0)")
+            mv = mv[k:]
 
     # reference Inner::write (src/write.rs:171-190): cut `buf` into chunks
     def _inner_write(self, buf):
@@ -391,7 +427,7 @@ class FrameEncoder:
         framed = encode_host(self.ctx, host, lens,
                              ident=not self._wrote_ident)
         self._wrote_ident = True   # identifier only once (:167-170)
-        self.w.write(framed)
+        self._write_all(framed)
 
     def write(self, buf):
         try:
@@ -435,8 +471,16 @@ class FrameEncoder:
             raise IntoInnerError(self, e) from e
         return self.w
 
+    def _release(self):
+        if self._stage is not None:   # the pinned staging of direct writes
+            self._stage.close()
+            self._stage = None
+
     def close(self):
-        self.flush()
+        try:
+            self.flush()
+        finally:
+            self._release()
 
     def __enter__(self):
         return self
@@ -447,25 +491,90 @@ class FrameEncoder:
         except Exception:
             if a[0] is None:
                 raise
+        finally:
+            self._release()
+
+
+class _ReaderFailed(Exception):
+    """The INNER reader raised (not the device): the caller may retry, what
+    was read before stays staged."""
+
+    def __init__(self, err):
+        super().__init__(str(err))
+        self.err = err
+
+
+class HostReader:
+    """A reader over pinned host memory (a HostBuffer's view, or any buffer)
+    that LENDS its bytes - getbuffer() / tell() / seek(), like io.BytesIO -
+    instead of copying them out: FrameDecoder then hands the device call the
+    reader's own memory (BufRead::fill_buf / consume in the reference's
+    language).  With a pinned buffer that is the whole host-to-device leg
+    without a copy on the host."""
+
+    def __init__(self, buf):
+        self._v = memoryview(buf).cast("B")
+        self._p = 0
+
+    def getbuffer(self):
+        return self._v
+
+    def tell(self):
+        return self._p
+
+    def seek(self, pos, whence=0):
+        self._p = max(0, min(len(self._v), pos if whence == 0 else
+                             (self._p + pos if whence == 1
+                              else len(self._v) + pos)))
+        return self._p
+
+    def read(self, n=-1):
+        end = len(self._v) if n is None or n < 0 else min(len(self._v),
+                                                           self._p + n)
+        b = bytes(self._v[self._p:end])
+        self._p = end
+        return b
+
+    def readinto(self, b):
+        mv = memoryview(b).cast("B")
+        k = min(len(mv), len(self._v) - self._p)
+        mv[:k] = self._v[self._p:self._p + k]
+        self._p += k
+        return k
 
 
 class FrameDecoder:
     """snap::read::FrameDecoder<R> (reference src/read.rs:47-239): `read`,
-    `get_ref`, `get_mut`, `into_inner`.
+    `readinto`, `read_to_end`, `get_ref`, `get_mut`, `into_inner`.
 
-    Pulls at most `batch_bytes` from the reader at a time, cuts the batch at
-    its last complete chunk (host scan of the chunk headers, which also serves
-    as the side index) and decodes those chunks in one device call.  Bytes of
-    the chunks in front of a bad chunk are returned first; the error is raised
-    by the read that reaches it (src/read.rs:111-118)."""
+    Takes at most `batch_bytes` from the reader at a time, cuts the batch at
+    its last complete chunk (host scan of the chunk headers, which also sizes
+    the output and serves as the side index) and decodes those chunks in one
+    device call.  Bytes of the chunks in front of a bad chunk are returned
+    first; the error is raised by the read that reaches it
+    (src/read.rs:111-118).
+
+    Where the bytes live: a reader that lends its buffer (io.BytesIO,
+    HostReader: getbuffer / tell / seek) is decoded where it lies, nothing is
+    copied on the host; any other reader fills pinned staging memory -
+    through readinto / readinto1 when it has one (one copy, no allocation),
+    through read otherwise.  Decoded bytes land in pinned room kept from
+    batch to batch and are handed out from there (`read` copies what it
+    returns once; `readinto` with room for a batch gets the bytes straight
+    from the device call; `read_to_end` appends batch by batch to one
+    bytearray)."""
 
     def __init__(self, rdr, ctx=None, batch_bytes=BATCH_BYTES):
         self.r = rdr
         self.ctx = ctx or raw.default_context()
         self.batch_bytes = max(int(batch_bytes), 1 << 17)
-        self._carry = b""        # bytes read but not decoded (a cut chunk)
+        self._lends = all(callable(getattr(rdr, a, None))
+                          for a in ("getbuffer", "tell", "seek"))
+        self._no_into = False
+        self._in = None          # pinned staging of the input (grow-only)
+        self._have = 0           # _in[:_have]: read, not decoded yet
         self._outbuf = None      # pinned room for a batch's output
-        self._out = b""
+        self._out = memoryview(b"")
         self._pos = 0
         self._err = None
         self._io_err = None      # the inner reader's error (retryable)
@@ -481,40 +590,61 @@ class FrameDecoder:
     def into_inner(self):
         return self.r
 
+    def close(self):
+        """Release the pinned buffers (they are also released when the
+        decoder is collected)."""
+        self._out = memoryview(b"")
+        for b in (self._in, self._outbuf):
+            if b is not None:
+                b.close()
+        self._in = self._outbuf = None
+
+    def _stage(self, want):
+        """Pinned input staging of at least `want` bytes, what is staged
+        kept."""
+        if self._in is None or self._in.nbytes < want:
+            new = HostBuffer(want + want // 8)
+            if self._have:
+                new.view[:self._have] = self._in.view[:self._have]
+            if self._in is not None:
+                self._in.close()
+            self._in = new
+        return self._in.view
+
     def _pull(self, want):
-        """Bytes for one batch: the carry plus what the reader has NOW.  The
-        reference reads one chunk per call (src/read.rs:105-172); batching
-        must not turn into waiting: one inner read at least, more only while
-        the reader keeps filling what it is offered (a short read means it
-        has no more at the moment - a pipe, a socket, a request/response
-        peer that waits for our answer before it sends on)."""
-        rd = getattr(self.r, "read1", None) or self.r.read
-        pieces = [self._carry] if self._carry else []
-        have = len(self._carry)
-
-        def joined():
-            # (one piece - the usual batch from a file or a buffer - is
-            # handed on as it is, without a copy)
-            if len(pieces) == 1 and isinstance(pieces[0], bytes):
-                return pieces[0]
-            return b"".join(pieces)
-
+        """Bytes for one batch: what is staged plus what the reader has NOW.
+        The reference reads one chunk per call (src/read.rs:105-172);
+        batching must not turn into waiting: one inner read at least, more
+        only while the reader keeps filling what it is offered (a short read
+        means it has no more at the moment - a pipe, a socket, a
+        request/response peer that waits for our answer before it sends
+        on).  A reader's exception leaves what was read before it staged."""
+        view = self._stage(want)
+        into = getattr(self.r, "readinto1", None) or getattr(
+            self.r, "readinto", None)
+        rd = getattr(self.r, "read1", None) or getattr(self.r, "read", None)
         try:
-            while have < want and not self._eof:
-                ask = want - have
-                b = rd(ask)
-                if not b:
+            while self._have < want and not self._eof:
+                ask = want - self._have
+                k = None
+                if into is not None and not self._no_into:
+                    try:
+                        k = into(view[self._have:want]) or 0
+                    except (NotImplementedError, io.UnsupportedOperation):
+                        self._no_into = True   # declared, not implemented
+                if k is None:
+                    b = rd(ask)
+                    k = len(b) if b else 0
+                    view[self._have:self._have + k] = b[:k] if k else b""
+                if not k:
                     self._eof = True
                     break
-                pieces.append(b)
-                have += len(b)
-                if len(b) < ask:
+                self._have += k
+                if k < ask:
                     break
-        except BaseException:
-            self._carry = joined()   # what was read before the error is kept
-            raise
-        self._carry = b""
-        return joined()
+        except Exception as e:  # noqa: BLE001 - the reader's, re-raised
+            raise _ReaderFailed(e) from e
+        return view[:self._have]
 
     def _room(self, nbytes):
         """Pinned memory for one batch's output, kept from batch to batch:
@@ -522,47 +652,85 @@ class FrameDecoder:
         cost a page fault per 4 KiB and a pageable copy)."""
         if self._outbuf is None or self._outbuf.nbytes < nbytes:
             if self._outbuf is not None:
+                self._out = memoryview(b"")
                 self._outbuf.close()
-            self._outbuf = HostBuffer(nbytes)
+            self._outbuf = HostBuffer(nbytes + nbytes // 8)
         return self._outbuf.view[:nbytes]
 
     def _fill(self, direct=None):
         """Decode the next batch.  Into `direct` (a writable memoryview of
-        the caller's, readinto) when that has room for whatever the batch can
-        hold - the bytes are then the caller's without another copy and their
-        number is returned; into the decoder's own pinned room otherwise
-        (returns 0, the bytes wait in _out)."""
-        want = self.batch_bytes
-        while True:
-            data = self._pull(want)
-            if not data:
+        the caller's, readinto) when that has room for every chunk of the
+        batch - the bytes are then the caller's without another copy and
+        their number is returned; into the decoder's own pinned room
+        otherwise (returns 0, the bytes wait in _out)."""
+        # (a lending reader costs no staging memory: four times the batch,
+        # fewer device calls - each has a latency floor of a millisecond or
+        # two - when the output goes straight to the caller)
+        want = self.batch_bytes * (4 if self._lends and direct is not None
+                                   else 1)
+        lent = None
+        try:
+            while True:
+                if self._lends:
+                    # the reader's own memory: nothing is copied or staged
+                    lent = self.r.getbuffer()
+                    at = self.r.tell()
+                    data = memoryview(lent)[at:at + want]
+                    self._eof = at + want >= len(lent)
+                else:
+                    data = self._pull(want)
+                if not len(data):
+                    return 0
+                # room for every data chunk of the batch (the scan counts
+                # them): a chunk yields at most 65536 bytes
+                nd, _ = count_chunks_host(data, self._seen_ident)
+                room = max(nd, 1) * MAX_BLOCK_SIZE
+                mine = direct is None or len(direct) < room
+                out = self._room(room) if mine else direct[:room]
+                try:
+                    n, used, err = decode_host(self.ctx, data, out,
+                                               self._seen_ident, self._eof,
+                                               self._stale)
+                except Error:
+                    raise
+                except Exception as e:  # noqa: BLE001 - a device failure is
+                    self._err = Error(   # final: a retry would skip input
+                        101, message=f"frame_decode_host: {e}")
+                    raise self._err from e
+                if err is None and used == 0:   # not one whole chunk yet
+                    want = len(data) + self.batch_bytes
+                    if self._eof:
+                        raise Error(101, message="frame_decode_host made no "
+                                                 "progress at end of input")
+                    if lent is not None:
+                        data.release()
+                        lent = None
+                    continue
+                break
+            if self._lends:
+                self.r.seek(at + (used if err is None else len(data)))
+            else:
+                rest = self._have - used if err is None else 0
+                if rest and used:
+                    self._in.view[:rest] = self._in.view[used:self._have]
+                self._have = rest
+            self._seen_ident = self._seen_ident or used > 0
+            self._err = err
+            if mine:
+                self._out, self._pos = out[:n], 0
                 return 0
-            # room for every chunk the batch can hold: a chunk is at least 8
-            # bytes of header and yields at most 65536 bytes, but a batch of
-            # 64 KiB chunks needs about its own size; decode_host consumes
-            # only as many chunks as fit and is called again for the rest
-            room = (max(2 * len(data), 1 << 20) // MAX_BLOCK_SIZE
-                    * MAX_BLOCK_SIZE)
-            mine = direct is None or len(direct) < room
-            out = self._room(room) if mine else direct[:room]
-            n, used, err = decode_host(self.ctx, data, out, self._seen_ident,
-                                       self._eof, self._stale)
-            if err is None and used == 0:   # not one whole chunk yet
-                self._carry = data
-                want = len(data) + self.batch_bytes
-                if self._eof:
-                    raise Error(101, message="frame_decode_host made no "
-                                             "progress at end of input")
-                continue
-            break
-        self._carry = data[used:] if err is None else b""
-        self._seen_ident = self._seen_ident or used > 0
-        self._err = err
-        if mine:
-            self._out, self._pos = bytes(out[:n]), 0
-            return 0
-        self._out, self._pos = b"", 0
-        return n
+            self._out, self._pos = memoryview(b""), 0
+            return n
+        finally:
+            if lent is not None:
+                try:
+                    data.release()
+                except Exception:  # noqa: BLE001
+                    pass
+
+    def _drained(self):
+        return self._eof and not self._have and (
+            not self._lends or self.r.tell() >= len(self.r.getbuffer()))
 
     def readinto(self, b):
         """io::Read::read (reference src/read.rs:104-239): up to len(b)
@@ -583,60 +751,69 @@ class FrameDecoder:
             if self._io_err is not None:
                 e, self._io_err = self._io_err, None
                 raise e
-            if self._eof and not self._carry:
+            if self._drained():
                 return 0
-            n = self._fill(mv)   # (the reader's error: nothing is lost,
-            if n:                # what it read before stays in _carry)
+            try:
+                n = self._fill(mv)
+            except _ReaderFailed as e:   # nothing is lost: what the reader
+                raise e.err from None    # gave before stays staged
+            if n:
                 return n
-            if not self._out and self._err is None and self._eof \
-                    and not self._carry:
+            if not len(self._out) and self._err is None and self._drained():
                 return 0
 
-    def read(self, size=-1):
-        """Up to `size` bytes (all remaining for size < 0).  An error is
-        raised once the bytes in front of it have been returned."""
-        parts, need = [], (None if size is None or size < 0 else size)
+    def _gather(self, size, acc):
+        """Up to `size` bytes (all that remain for None) appended to the
+        bytearray `acc`; an error is raised once the bytes in front of it
+        have been handed out."""
+        need, got = size, 0
         while need is None or need > 0:
             if self._pos < len(self._out):
                 end = len(self._out) if need is None else min(
                     len(self._out), self._pos + need)
-                parts.append(self._out[self._pos:end])
+                acc += self._out[self._pos:end]
+                got += end - self._pos
                 if need is not None:
                     need -= end - self._pos
                 self._pos = end
                 continue
             if self._err is not None:
-                if parts:
+                if got:
                     break          # hand out the good bytes first
                 raise self._err
             if self._io_err is not None:
-                if parts:
+                if got:
                     break
                 e, self._io_err = self._io_err, None
                 raise e            # a caller may retry: nothing was lost
-            if self._eof and not self._carry:
+            if self._drained():
                 break
             try:
                 self._fill()
-            except Error:
-                raise
-            except Exception as e:  # noqa: BLE001 - the reader's error
-                self._io_err = e    # behind the bytes gathered so far
+            except _ReaderFailed as e:
+                self._io_err = e.err   # behind the bytes gathered so far
                 continue
-            if not self._out and self._err is None and self._eof \
-                    and not self._carry:
-                break
-        return b"".join(parts)
+        return got
 
-    def read_to_end(self):
-        """io::Read::read_to_end: all bytes, or the stream's error (with the
-        bytes decoded in front of it in `.partial`)."""
-        data = self.read(-1)
+    def read(self, size=-1):
+        """Up to `size` bytes (all remaining for size < 0), as bytes.  An
+        error is raised once the bytes in front of it have been returned."""
+        acc = bytearray()
+        self._gather(None if size is None or size < 0 else size, acc)
+        return bytes(acc)
+
+    def read_to_end(self, buf=None):
+        """io::Read::read_to_end (the reference appends to a Vec<u8>): all
+        remaining bytes appended to the bytearray `buf` (a new one by
+        default), which is returned - or the stream's error, with the bytes
+        decoded in front of it in `.partial`."""
+        acc = bytearray() if buf is None else buf
+        self._gather(None, acc)
         if self._err is not None:
             e = self._err
-            e.partial = data
+            e.partial = acc
             raise e
-        return data
+        return acc
 
 
 class ReadFrameEncoder:

@@ -49,6 +49,12 @@ extern "C" {
         ctx: *mut SnapmiCtx, input: *const u8, input_len: usize, output: *mut u8,
         output_cap: usize, written: *mut usize, err: *mut SnapmiError,
     ) -> c_int;
+    pub fn snapmi_host_alloc(bytes: usize) -> *mut c_void;
+    pub fn snapmi_host_free(p: *mut c_void);
+    pub fn snapmi_frame_scan_host(
+        h_in: *const c_void, in_len: u64, flags: u32, stale10: *mut u8, h_offsets: *mut u64,
+        cap: u64, n_chunks: *mut u64, consumed: *mut u64,
+    ) -> c_int;
     pub fn snapmi_frame_encode_bound(total_bytes: usize, n_chunks: usize) -> usize;
     pub fn snapmi_frame_encode_host(
         ctx: *mut SnapmiCtx, h_in: *const u8, h_chunk_lens: *const u32, n: usize, flags: u32,
@@ -59,6 +65,102 @@ extern "C" {
         h_out: *mut u8, out_cap: usize, written: *mut usize, consumed: *mut usize,
         err: *mut SnapmiError,
     ) -> c_int;
+}
+
+/// Page-locked, device-mapped host memory (`snapmi_host_alloc`), used like a
+/// `Vec<u8>`.  The host-buffer calls (`snapmi_frame_encode_host`,
+/// `snapmi_frame_decode_host`) copy asynchronously - slice i+1 on its way to
+/// the device, the kernels of slice i, the result of slice i-1 on its way
+/// home - only from and to memory like this; from a pageable `Vec` the three
+/// legs run one after the other.  The adapters
+/// stage their batches here, as rust-snappy_amd/frame.py does (`HostBuffer`).
+pub struct PinnedBuf {
+    ptr: *mut u8,
+    cap: usize,
+    len: usize,
+}
+
+unsafe impl Send for PinnedBuf {}
+
+impl PinnedBuf {
+    pub fn new() -> PinnedBuf {
+        PinnedBuf { ptr: ptr::null_mut(), cap: 0, len: 0 }
+    }
+
+    pub fn with_len(len: usize) -> PinnedBuf {
+        let mut b = PinnedBuf::new();
+        b.resize(len);
+        b
+    }
+
+    /// Room for at least `cap` bytes; what is in `[..len]` is kept.  Grows by
+    /// an eighth beyond the request, like the library's own scratch.
+    pub fn reserve(&mut self, cap: usize) {
+        if cap <= self.cap {
+            return;
+        }
+        let want = cap + cap / 8;
+        let p = unsafe { snapmi_host_alloc(want) } as *mut u8;
+        if p.is_null() {
+            panic!("snap (MI355X): snapmi_host_alloc({}) failed", want);
+        }
+        if self.len > 0 {
+            unsafe { ptr::copy_nonoverlapping(self.ptr, p, self.len) };
+        }
+        if !self.ptr.is_null() {
+            unsafe { snapmi_host_free(self.ptr as *mut c_void) };
+        }
+        self.ptr = p;
+        self.cap = want;
+    }
+
+    /// `Vec::resize(len, 0)`.
+    pub fn resize(&mut self, len: usize) {
+        self.reserve(len);
+        if len > self.len {
+            unsafe { ptr::write_bytes(self.ptr.add(self.len), 0, len - self.len) };
+        }
+        self.len = len;
+    }
+
+    pub fn clear(&mut self) {
+        self.len = 0;
+    }
+
+    pub fn extend_from_slice(&mut self, s: &[u8]) {
+        self.reserve(self.len + s.len());
+        unsafe { ptr::copy_nonoverlapping(s.as_ptr(), self.ptr.add(self.len), s.len()) };
+        self.len += s.len();
+    }
+}
+
+impl std::ops::Deref for PinnedBuf {
+    type Target = [u8];
+    fn deref(&self) -> &[u8] {
+        if self.ptr.is_null() {
+            &[]
+        } else {
+            unsafe { std::slice::from_raw_parts(self.ptr, self.len) }
+        }
+    }
+}
+
+impl std::ops::DerefMut for PinnedBuf {
+    fn deref_mut(&mut self) -> &mut [u8] {
+        if self.ptr.is_null() {
+            &mut []
+        } else {
+            unsafe { std::slice::from_raw_parts_mut(self.ptr, self.len) }
+        }
+    }
+}
+
+impl Drop for PinnedBuf {
+    fn drop(&mut self) {
+        if !self.ptr.is_null() {
+            unsafe { snapmi_host_free(self.ptr as *mut c_void) };
+        }
+    }
 }
 
 /// Owner of a `snapmi_ctx`.

@@ -7,11 +7,19 @@
 //! call (header checks, raw decode, CRC, all in the reference's order) and
 //! keeps the cut-off tail for the next round.  Bytes of the chunks in front of
 //! a bad chunk are returned before the error (reference :111-118).
+//!
+//! Memory, as in rust-snappy_amd/frame.py (the tested mirror of this file):
+//! input and output of a batch are staged in page-locked memory
+//! (`gpu::PinnedBuf`) so that the copies of the device call are asynchronous;
+//! the output room is sized by a host scan of the chunk headers
+//! (`snapmi_frame_scan_host`: 65536 bytes per data chunk of the batch), and a
+//! caller's buffer that has that much room gets the decoded bytes straight
+//! from the device call.
 use std::cmp;
 use std::fmt;
 use std::io::{self, Read};
 
-use crate::gpu::{self, Context, Failure, SnapmiError};
+use crate::gpu::{self, Context, Failure, PinnedBuf, SnapmiError};
 use crate::MAX_BLOCK_SIZE;
 
 /// Most that one device call is handed.  Buffers start small and grow towards
@@ -23,11 +31,11 @@ const FIRST: usize = 1 << 20;
 pub struct FrameDecoder<R: io::Read> {
     r: R,
     ctx: Context,
-    /// Compressed bytes read but not decoded yet (src[..srce]).
-    src: Vec<u8>,
+    /// Compressed bytes read but not decoded yet (src[..srce]), pinned.
+    src: PinnedBuf,
     srce: usize,
-    /// Decoded bytes not yet handed out: dst[dsts..dste].
-    dst: Vec<u8>,
+    /// Decoded bytes not yet handed out: dst[dsts..dste], pinned.
+    dst: PinnedBuf,
     dsts: usize,
     dste: usize,
     /// An error that follows the bytes in `dst`.
@@ -45,9 +53,9 @@ impl<R: io::Read> FrameDecoder<R> {
         FrameDecoder {
             r: rdr,
             ctx: Context::new(),
-            src: vec![0; FIRST],
+            src: PinnedBuf::with_len(FIRST),
             srce: 0,
-            dst: vec![0; 2 * FIRST],
+            dst: PinnedBuf::new(),
             dsts: 0,
             dste: 0,
             pending: None,
@@ -80,7 +88,11 @@ impl<R: io::Read> FrameDecoder<R> {
     /// (a pipe, a socket, a peer that waits for our answer before it sends
     /// on).  A read error leaves `src[..srce]` as it is: nothing is lost, the
     /// next call carries on.
-    fn fill(&mut self) -> io::Result<()> {
+    ///
+    /// `direct`: the caller's buffer.  When it has room for every data chunk
+    /// of the batch the bytes are decoded straight into it and their number
+    /// is returned; otherwise they wait in `dst` (returns 0).
+    fn fill(&mut self, direct: &mut [u8]) -> io::Result<usize> {
         loop {
             let mut full = true;
             while self.srce < self.src.len() && !self.eof {
@@ -102,11 +114,10 @@ impl<R: io::Read> FrameDecoder<R> {
             if full && !self.eof && self.src.len() < BATCH {
                 // the reader keeps up: a larger batch next time
                 let len = cmp::min(2 * self.src.len(), BATCH);
-                self.src.resize(len, 0);
-                self.dst.resize(2 * len, 0);
+                self.src.resize(len);
             }
             if self.srce == 0 {
-                return Ok(()); // clean end of the stream
+                return Ok(0); // clean end of the stream
             }
             let mut flags = 0;
             if self.read_stream_ident {
@@ -115,17 +126,38 @@ impl<R: io::Read> FrameDecoder<R> {
             if self.eof {
                 flags |= gpu::SNAPMI_FRAME_FINAL;
             }
+            // room for every data chunk of the batch: the host scan counts
+            // them (a chunk yields at most 65536 bytes)
+            let (mut nd, mut scanned) = (0u64, 0u64);
+            unsafe {
+                gpu::snapmi_frame_scan_host(
+                    self.src.as_ptr() as *const _, self.srce as u64,
+                    flags & gpu::SNAPMI_FRAME_CONTINUATION, std::ptr::null_mut(),
+                    std::ptr::null_mut(), 0, &mut nd, &mut scanned,
+                );
+            }
+            let room = cmp::max(nd as usize, 1) * MAX_BLOCK_SIZE;
+            let mine = direct.len() < room;
+            if mine {
+                self.dst.resize(room);
+            }
+            let (out, out_cap) = if mine {
+                (self.dst.as_mut_ptr(), room)
+            } else {
+                (direct.as_mut_ptr(), room)
+            };
             let (mut written, mut consumed) = (0usize, 0usize);
             let mut e = SnapmiError::default();
             let rc = unsafe {
                 gpu::snapmi_frame_decode_host(
                     self.ctx.as_ptr(), self.src.as_ptr(), self.srce, flags,
-                    self.stale.as_mut_ptr(), self.dst.as_mut_ptr(), self.dst.len(),
+                    self.stale.as_mut_ptr(), out, out_cap,
                     &mut written, &mut consumed, &mut e,
                 )
             };
             self.dsts = 0;
-            self.dste = written;
+            self.dste = if mine { written } else { 0 };
+            let handed = if mine { 0 } else { written };
             if rc != 0 {
                 // the good bytes first, the error by the read that reaches it
                 self.pending = Some(match gpu::to_failure(rc, &e, Some(&self.ctx)) {
@@ -134,7 +166,7 @@ impl<R: io::Read> FrameDecoder<R> {
                     Failure::Device(msg) => io::Error::new(io::ErrorKind::Other, msg),
                 });
                 self.srce = 0;
-                return Ok(());
+                return Ok(handed);
             }
             if consumed == 0 {
                 // not one whole chunk in the buffer (a chunk is < 76 KiB, so
@@ -143,14 +175,15 @@ impl<R: io::Read> FrameDecoder<R> {
                     return Err(io::Error::new(io::ErrorKind::Other, "snapmi: no progress"));
                 }
                 if self.srce == self.src.len() {
-                    self.src.resize(2 * self.src.len(), 0);
+                    let len = 2 * self.src.len();
+                    self.src.resize(len);
                 }
                 continue;
             }
             self.read_stream_ident = true;
             self.src.copy_within(consumed..self.srce, 0);
             self.srce -= consumed;
-            return Ok(());
+            return Ok(handed);
         }
     }
 }
@@ -170,7 +203,10 @@ impl<R: io::Read> io::Read for FrameDecoder<R> {
             if self.eof && self.srce == 0 {
                 return Ok(0);
             }
-            self.fill()?;
+            let n = self.fill(buf)?;
+            if n > 0 {
+                return Ok(n); // decoded straight into `buf`
+            }
             if self.dsts == self.dste && self.pending.is_none() && self.eof && self.srce == 0 {
                 return Ok(0);
             }
@@ -198,9 +234,9 @@ impl<R: fmt::Debug + io::Read> fmt::Debug for FrameDecoder<R> {
 pub struct FrameEncoder<R: io::Read> {
     r: R,
     ctx: Context,
-    src: Vec<u8>,
+    src: PinnedBuf,
     lens: Vec<u32>,
-    dst: Vec<u8>,
+    dst: PinnedBuf,
     dsts: usize,
     dste: usize,
     eof: bool,
@@ -215,9 +251,9 @@ impl<R: io::Read> FrameEncoder<R> {
         FrameEncoder {
             r: rdr,
             ctx: Context::new(),
-            src: Vec::new(),
+            src: PinnedBuf::new(),
             lens: Vec::new(),
-            dst: Vec::new(),
+            dst: PinnedBuf::new(),
             dsts: 0,
             dste: 0,
             eof: false,
@@ -246,15 +282,15 @@ impl<R: io::Read> FrameEncoder<R> {
         self.lens.clear();
         while self.src.len() < BATCH {
             let at = self.src.len();
-            self.src.resize(at + MAX_BLOCK_SIZE, 0);
+            self.src.resize(at + MAX_BLOCK_SIZE);
             let n = match self.r.read(&mut self.src[at..]) {
                 Ok(n) => n,
                 Err(ref e) if e.kind() == io::ErrorKind::Interrupted => {
-                    self.src.truncate(at);
+                    self.src.resize(at);
                     continue;
                 }
                 Err(e) => {
-                    self.src.truncate(at);
+                    self.src.resize(at);
                     if self.lens.is_empty() {
                         return Err(e);
                     }
@@ -262,7 +298,7 @@ impl<R: io::Read> FrameEncoder<R> {
                     break;
                 }
             };
-            self.src.truncate(at + n);
+            self.src.resize(at + n);
             if n == 0 {
                 self.eof = true;
                 break;
@@ -278,7 +314,7 @@ impl<R: io::Read> FrameEncoder<R> {
             return Ok(());
         }
         let cap = unsafe { gpu::snapmi_frame_encode_bound(self.src.len(), self.lens.len()) };
-        self.dst.resize(cap, 0);
+        self.dst.resize(cap);
         let flags = if self.wrote_stream_ident { gpu::SNAPMI_FRAME_NO_IDENT } else { 0 };
         let mut written = 0usize;
         let rc = unsafe {

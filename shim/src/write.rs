@@ -6,15 +6,29 @@
 //! handed to the GPU `BATCH` bytes at a time (`snapmi_frame_encode_host`:
 //! CRC32C, raw compression and framing of all queued chunks in one launch
 //! sequence).  `flush()` compresses what is queued.
+//!
+//! Memory, as in rust-snappy_amd/frame.py (the tested mirror of this file):
+//! the queue and the framed output live in page-locked memory
+//! (`gpu::PinnedBuf`), so that copy-in, kernels and copy-out of a batch's
+//! slices overlap; a write of `DIRECT_MIN` bytes or more that arrives with an
+//! empty block buffer is not queued at all - its chunks (cut exactly as the
+//! queue would cut them, partial tail included) are compressed where the
+//! caller's bytes lie, at most `DIRECT_MAX` per device call.
 use std::fmt;
 use std::io::{self, Write};
 
 pub use crate::error::IntoInnerError;
-use crate::gpu::{self, Context, Failure, SnapmiError};
+use crate::gpu::{self, Context, Failure, PinnedBuf, SnapmiError};
 use crate::MAX_BLOCK_SIZE;
 
 /// Bytes queued before the device is called (bounded memory).
 const BATCH: usize = 64 << 20;
+/// A write of at least this many bytes with an empty block buffer goes to the
+/// device from where it lies ...
+const DIRECT_MIN: usize = 4 << 20;
+/// ... at most this many bytes per device call (bounds the pinned staging of
+/// the framed bytes).
+const DIRECT_MAX: usize = 1 << 30;
 
 /// Compresses what is written to it into the Snappy frame format and writes
 /// that to `W` (reference src/write.rs:19-50).  Flushed on drop, errors of
@@ -28,11 +42,12 @@ pub struct FrameEncoder<W: io::Write> {
 struct Inner<W> {
     w: W,
     ctx: Context,
-    /// Chunks cut but not yet compressed, back to back, and their lengths.
-    queue: Vec<u8>,
+    /// Chunks cut but not yet compressed, back to back (pinned), and their
+    /// lengths.
+    queue: PinnedBuf,
     lens: Vec<u32>,
-    /// Framed output of one batch.
-    dst: Vec<u8>,
+    /// Framed output of one batch or one direct part (pinned).
+    dst: PinnedBuf,
     wrote_stream_ident: bool,
 }
 
@@ -43,9 +58,9 @@ impl<W: io::Write> FrameEncoder<W> {
             inner: Some(Inner {
                 w: wtr,
                 ctx: Context::new(),
-                queue: Vec::new(),
+                queue: PinnedBuf::new(),
                 lens: Vec::new(),
-                dst: Vec::new(),
+                dst: PinnedBuf::new(),
                 wrote_stream_ident: false,
             }),
             src: Vec::with_capacity(MAX_BLOCK_SIZE),
@@ -124,6 +139,11 @@ impl<W: io::Write> Inner<W> {
     /// reference `Inner::write` (:171-190): `buf` becomes chunks of at most
     /// 65536 bytes; they are compressed when a batch is full.
     fn cut(&mut self, buf: &[u8]) -> io::Result<usize> {
+        if buf.len() >= DIRECT_MIN {
+            self.emit()?; // what is queued goes first
+            self.emit_direct(buf)?;
+            return Ok(buf.len());
+        }
         for c in buf.chunks(MAX_BLOCK_SIZE) {
             self.queue.extend_from_slice(c);
             self.lens.push(c.len() as u32);
@@ -134,22 +154,42 @@ impl<W: io::Write> Inner<W> {
         Ok(buf.len())
     }
 
+    /// The chunks of `buf`, cut as `cut` cuts them, straight from the
+    /// caller's memory (no queue, no copy on the host).
+    fn emit_direct(&mut self, buf: &[u8]) -> io::Result<()> {
+        for part in buf.chunks(DIRECT_MAX) {
+            let mut lens: Vec<u32> = part.chunks(MAX_BLOCK_SIZE).map(|c| c.len() as u32).collect();
+            std::mem::swap(&mut lens, &mut self.lens);
+            let r = self.encode(part.as_ptr(), part.len());
+            std::mem::swap(&mut lens, &mut self.lens);
+            self.lens.clear();
+            r?;
+        }
+        Ok(())
+    }
+
     fn emit(&mut self) -> io::Result<()> {
         if self.lens.is_empty() {
             return Ok(());
         }
-        let cap = unsafe { gpu::snapmi_frame_encode_bound(self.queue.len(), self.lens.len()) };
-        self.dst.resize(cap, 0);
+        let r = self.encode(self.queue.as_ptr(), self.queue.len());
+        self.queue.clear();
+        self.lens.clear();
+        r
+    }
+
+    /// One device call: `self.lens` chunks from `total` bytes at `input`.
+    fn encode(&mut self, input: *const u8, total: usize) -> io::Result<()> {
+        let cap = unsafe { gpu::snapmi_frame_encode_bound(total, self.lens.len()) };
+        self.dst.resize(cap);
         let flags = if self.wrote_stream_ident { gpu::SNAPMI_FRAME_NO_IDENT } else { 0 };
         let mut written = 0usize;
         let rc = unsafe {
             gpu::snapmi_frame_encode_host(
-                self.ctx.as_ptr(), self.queue.as_ptr(), self.lens.as_ptr(), self.lens.len(),
+                self.ctx.as_ptr(), input, self.lens.as_ptr(), self.lens.len(),
                 flags, self.dst.as_mut_ptr(), cap, &mut written,
             )
         };
-        self.queue.clear();
-        self.lens.clear();
         if rc != 0 {
             let e = SnapmiError::default();
             return Err(match gpu::to_failure(rc, &e, Some(&self.ctx)) {

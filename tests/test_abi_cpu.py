@@ -232,6 +232,27 @@ def test_rust_shim_binds_only_exported_symbols(built):
                     "Checksum"):
         assert f"Error::{variant}" in gpu, variant
         assert variant in (ROOT / "shim" / "src" / "error.rs").read_text()
+    # the adapters stage their batches the way the tested Python mirror does
+    # (rust-snappy_amd/frame.py): pinned memory, the same batch size, the same
+    # direct path for large writes, output room sized by the host scan
+    from rust_snappy_amd import frame
+    w_rs = (ROOT / "shim" / "src" / "write.rs").read_text()
+    r_rs = (ROOT / "shim" / "src" / "read.rs").read_text()
+
+    def const(text, name):
+        m = re.search(r"const %s: usize = (\d+) << (\d+);" % name, text)
+        assert m, name
+        return int(m.group(1)) << int(m.group(2))
+    assert const(w_rs, "BATCH") == const(r_rs, "BATCH") == frame.BATCH_BYTES
+    assert const(w_rs, "DIRECT_MIN") == frame.FrameEncoder.DIRECT_MIN
+    assert const(w_rs, "DIRECT_MAX") == frame.FrameEncoder.DIRECT_MAX
+    assert "queue: PinnedBuf" in w_rs and "dst: PinnedBuf" in w_rs
+    assert "src: PinnedBuf," in r_rs and "dst: PinnedBuf," in r_rs and \
+        "Vec<u8>" not in r_rs
+    assert "fn emit_direct" in w_rs and "snapmi_frame_scan_host" in r_rs
+    for sym in ("snapmi_host_alloc", "snapmi_host_free",
+                "snapmi_frame_scan_host"):
+        assert sym in [d[0] for d in decls], sym
     # the public surface of the reference
     for f, items in (("raw.rs", ["pub fn max_compress_len",
                                  "pub fn decompress_len", "pub struct Encoder",
