@@ -11,7 +11,13 @@ from pathlib import Path
 PKG_DIR = Path(__file__).resolve().parent
 # SNAPMI_LIB selects another build of the same ABI (ablation / experiment
 # builds made by `make -C rust-snappy_amd/csrc ablate`); never a CPU codec.
-LIB_PATH = Path(os.environ.get("SNAPMI_LIB", PKG_DIR / "libsnapmi.so"))
+# A process that says SNAPMI_TESTING=1 (the test suite: tests/conftest.py; the
+# experiment drivers under tests/hw/) gets libsnapmi_test.so - the same
+# sources with the test knobs and the cross-check kernels compiled in
+# (include/snapmi_test.h), which the product library does not carry.
+_DEFAULT = "libsnapmi_test.so" if os.environ.get("SNAPMI_TESTING") \
+    else "libsnapmi.so"
+LIB_PATH = Path(os.environ.get("SNAPMI_LIB", PKG_DIR / _DEFAULT))
 
 
 class SnapmiError(C.Structure):
@@ -92,6 +98,9 @@ SYMBOLS = [
       C.POINTER(C.c_uint64)]),
 ]
 
+# include/snapmi_test.h: exported by libsnapmi_test.so only
+TEST_ONLY = {"snapmi_ctx_set_test_option"}
+
 _lib = None
 
 
@@ -115,6 +124,8 @@ def load():
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
     L = C.CDLL(str(LIB_PATH), mode=getattr(os, "RTLD_LOCAL", 0))
     for name, res, args in SYMBOLS:
+        if name in TEST_ONLY and not hasattr(L, name):
+            continue          # the product build: no test knobs
         f = getattr(L, name)  # AttributeError if the ABI lost a symbol
         f.restype = res
         f.argtypes = args

@@ -96,6 +96,7 @@ int snapmi_ctx_create(int device, void *hip_stream, snapmi_ctx **out)
     // experiment knobs from the environment (tests/hw drivers): only for a
     // process that says SNAPMI_TESTING=1 - a production host sets what it
     // needs through snapmi_ctx_set_option
+#ifdef SNAPMI_TESTING // (the test build, libsnapmi_test.so: Makefile)
     if (getenv("SNAPMI_TESTING")) {
         if (const char *e = getenv("SNAPMI_LANE_WAVES")) {
             const int v = atoi(e);
@@ -135,6 +136,7 @@ int snapmi_ctx_create(int device, void *hip_stream, snapmi_ctx **out)
                                      ? 0
                                      : (strcmp(m, "lanes") == 0 ? 1 : 2);
     }
+#endif
     if (hip_stream) {
         ctx->stream = (hipStream_t)hip_stream;
     } else {
@@ -256,7 +258,18 @@ int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value)
 {
     if (!ctx || !name)
         return SNAPMI_E_ARGUMENT;
-    if (strcmp(name, "compress_mode") == 0 && value >= 0 && value <= 2)
+#ifdef SNAPMI_TESTING
+    // cross-checks of the test build: both compressors at once on one
+    // ticket (compress_mode 2), the one-copy-per-step wavefront kernels of
+    // rounds 1-3 (span_kernel 0), the second-generation decoder alone
+    // (decode_kernel 2)
+    constexpr int64_t kModeMax = 2, kSpanMin = 0;
+    constexpr bool kDec2 = true;
+#else
+    constexpr int64_t kModeMax = 1, kSpanMin = 1;
+    constexpr bool kDec2 = false;
+#endif
+    if (strcmp(name, "compress_mode") == 0 && value >= 0 && value <= kModeMax)
         ctx->compress_mode = (int)value;
     else if (strcmp(name, "lane_min_blocks") == 0 && value >= 1)
         ctx->lane_min_blocks = (uint32_t)value;
@@ -277,7 +290,8 @@ int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value)
         ctx->small_batch_kernel = (int)value;
     else if (strcmp(name, "lane_speculate") == 0 && value >= 0 && value <= 1)
         ctx->lane_speculate = (int)value;
-    else if (strcmp(name, "span_kernel") == 0 && value >= 0 && value <= 1)
+    else if (strcmp(name, "span_kernel") == 0 && value >= kSpanMin &&
+             value <= 1)
         ctx->span_kernel = (int)value;
     else if (strcmp(name, "both_wave_cus") == 0 && value >= 0 &&
              value <= 4096)
@@ -297,14 +311,16 @@ int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value)
     else if (strcmp(name, "host_decode_slice_chunks") == 0 && value >= 1)
         ctx->host_decode_slice_chunks = (uint64_t)value;
     else if (strcmp(name, "decode_kernel") == 0 &&
-             (value == 0 || value == 2 || value == 3))
+             (value == 0 || (value == 2 && kDec2) || value == 3))
         ctx->decode_kernel = ctx->lds_store_order_ok ? (int)value : 0;
     else
         return fail_ctx(ctx, SNAPMI_E_ARGUMENT, "unknown option %s", name);
     return SNAPMI_OK;
 }
 
+#ifdef SNAPMI_TESTING
 // include/snapmi_test.h: knobs of the test suite and the experiment drivers
+// (libsnapmi_test.so only: the product library does not export it)
 int snapmi_ctx_set_test_option(snapmi_ctx *ctx, const char *name,
                                int64_t value)
 {
@@ -355,6 +371,7 @@ int snapmi_ctx_set_test_option(snapmi_ctx *ctx, const char *name,
                         name);
     return SNAPMI_OK;
 }
+#endif // SNAPMI_TESTING
 
 void *snapmi_host_alloc(size_t bytes)
 {
@@ -835,9 +852,14 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
             if (lds_input) {
                 const uint32_t wgs = (uint32_t)(
                     blocks < (uint64_t)ctx->num_cus ? blocks : ctx->num_cus);
+#ifdef SNAPMI_TESTING
                 hipLaunchKernelGGL(ctx->span_kernel ? k_compress_span_lds
                                                     : k_compress_block_lds,
                                    dim3(wgs), dim3(64), 0, ws, a);
+#else
+                hipLaunchKernelGGL(k_compress_span_lds, dim3(wgs), dim3(64),
+                                   0, ws, a);
+#endif
             } else {
                 const uint64_t want =
                     (blocks + kCompressWaves - 1) / kCompressWaves;
@@ -848,10 +870,15 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                                                      : ctx->num_cus / 2)
                                : (uint64_t)ctx->num_cus;
                 const uint32_t wgs = (uint32_t)(want < cus ? want : cus);
+#ifdef SNAPMI_TESTING
                 hipLaunchKernelGGL(ctx->span_kernel ? k_compress_spans
                                                     : k_compress_blocks,
                                    dim3(wgs), dim3(kCompressWaves * 64), 0, ws,
                                    a);
+#else
+                hipLaunchKernelGGL(k_compress_spans, dim3(wgs),
+                                   dim3(kCompressWaves * 64), 0, ws, a);
+#endif
             }
         }
         if (lanes_mode) {
@@ -1000,9 +1027,11 @@ int launch_decompress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     if (ctx->decode_kernel == 0)
         hipLaunchKernelGGL(k_decompress_sequential, dim3((uint32_t)n),
                            dim3(64), 0, s, a);
+#ifdef SNAPMI_TESTING
     else if (ctx->decode_kernel == 2)
         hipLaunchKernelGGL(k_decompress_streams2, dim3((uint32_t)n), dim3(64),
                            0, s, a);
+#endif
     else {
         if (n > ctx->decode_many_min)
             hipLaunchKernelGGL(

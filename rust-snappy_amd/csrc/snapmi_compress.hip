@@ -821,6 +821,8 @@ __global__ __launch_bounds__(64) void k_probe_tables(unsigned long long *tables,
         t[0] = (u32x4){state, 0, 0, 0};
 }
 
+#ifdef SNAPMI_TESTING // the one-copy-per-step kernels of rounds 1-3: the
+                      // test build's cross-check (option span_kernel 0)
 // ---------------------------------------------------------------------
 // K1: persistent workgroups of five wavefronts, one 32 KiB table each.
 // ---------------------------------------------------------------------
@@ -907,6 +909,8 @@ __global__ __launch_bounds__(64) void k_compress_block_lds(CompressArgs a)
         b = uni(next_ticket(a.ticket, lane, nblocks));
     }
 }
+
+#endif // SNAPMI_TESTING
 
 // ---------------------------------------------------------------------
 // K1s: wavefront per block, a WINDOW of 63 consecutive positions per step.

@@ -506,7 +506,10 @@ __global__ __launch_bounds__(1024) void k_plan_decompress_c(DecompressArgs a)
 // used here).
 // ---------------------------------------------------------------------
 namespace {
-constexpr uint32_t kRing2 = 4096;
+#ifndef SNAPMI_RING
+#define SNAPMI_RING 4096 // experiment builds: 8192 / 16384 (make ring_variants)
+#endif
+constexpr uint32_t kRing2 = SNAPMI_RING;
 constexpr uint32_t kWinMax = 2048;
 typedef __attribute__((address_space(3))) uint8_t l_u8;
 typedef __attribute__((address_space(3))) uint16_t l_u16x;
@@ -1640,6 +1643,7 @@ __global__ __launch_bounds__(64) void k_decompress_streams3_many(
     }
 }
 
+#ifdef SNAPMI_TESTING // (libsnapmi_test.so only)
 // The second generation alone (option decode_kernel = 2): kept as the
 // cross-check every decoder parity test also runs through.
 __attribute__((amdgpu_waves_per_eu(SNAPMI_DEC2_WAVES, SNAPMI_DEC2_WAVES)))
@@ -1655,6 +1659,7 @@ __global__ __launch_bounds__(64) void k_decompress_streams2(DecompressArgs a)
     const bool irregular = x.too_big() || decode_windows2(x, lane);
     close_stream(a, lane, x, irregular);
 }
+#endif
 
 // The reference's loop alone, one element at a time (option decode_kernel =
 // 0): what a context falls back to when the self-check of the LDS store

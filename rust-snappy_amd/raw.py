@@ -72,8 +72,13 @@ class Context:
     def set_test_option(self, name, value):
         """snapmi_ctx_set_test_option (include/snapmi_test.h): knobs of the
         test suite and the experiment drivers."""
-        rc = _lib.load().snapmi_ctx_set_test_option(self._h, name.encode(),
-                                                    int(value))
+        L = _lib.load()
+        if not hasattr(L, "snapmi_ctx_set_test_option"):
+            raise RuntimeError(
+                "set_test_option: this is the product library; the test "
+                "knobs live in libsnapmi_test.so (SNAPMI_TESTING=1)")
+        rc = L.snapmi_ctx_set_test_option(self._h, name.encode(),
+                                          int(value))
         if rc:
             _raise(self, rc)
 

@@ -3,6 +3,15 @@ from pathlib import Path
 
 import pytest
 
+import os
+
+# the suite runs on the TEST build of the library (libsnapmi_test.so: the same
+# sources with the knobs of include/snapmi_test.h and the cross-check kernels
+# compiled in); rust-snappy_amd/_lib.py picks it when SNAPMI_TESTING is set.
+# The product library (libsnapmi.so) is what smoke(), bench.py and the tools
+# load, and tests/test_abi_cpu.py checks what it exports.
+os.environ.setdefault("SNAPMI_TESTING", "1")
+
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))

@@ -31,8 +31,38 @@ def test_library_exports_every_declared_symbol(built):
 def test_library_carries_gfx950_code_objects(built):
     blob = (ROOT / "rust-snappy_amd" / "libsnapmi.so").read_bytes()
     assert b"gfx950" in blob
-    for k in (b"k_compress_blocks", b"k_decompress_streams", b"k_compact"):
+    for k in (b"k_compress_spans", b"k_match_blocks", b"k_decompress_streams3",
+              b"k_encode_tokens"):
         assert k in blob
+
+
+def test_product_library_carries_no_test_knobs(built):
+    """The shipped library (libsnapmi.so) is built without SNAPMI_TESTING: it
+    exports every symbol of include/snapmi.h and nothing of
+    include/snapmi_test.h, and the cross-check kernels (one copy per step,
+    second-generation decoder alone) are not in it.  The suite itself runs on
+    libsnapmi_test.so, which has them."""
+    prod = C.CDLL(str(ROOT / "rust-snappy_amd" / "libsnapmi.so"),
+                  mode=getattr(__import__("os"), "RTLD_LOCAL", 0))
+    header = (ROOT / "include" / "snapmi.h").read_text()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    names = sorted(set(re.findall(r"\b(snap(?:py|mi)_[a-z_0-9]+)\s*\(",
+                                  header)))
+    assert len(names) >= 19
+    for name in names:
+        assert hasattr(prod, name), f"libsnapmi.so does not export {name}"
+    assert not hasattr(prod, "snapmi_ctx_set_test_option")
+    blob = (ROOT / "rust-snappy_amd" / "libsnapmi.so").read_bytes()
+    for k in (b"k_compress_blocks", b"k_compress_block_lds",
+              b"k_decompress_streams2E", b"snapmi_ctx_set_test_option"):
+        assert k not in blob, k
+    tblob = (ROOT / "rust-snappy_amd" / "libsnapmi_test.so").read_bytes()
+    for k in (b"k_compress_blocks", b"k_decompress_streams2",
+              b"snapmi_ctx_set_test_option"):
+        assert k in tblob, k
+    # the options that select them are refused by the product library: no
+    # GPU is needed to see that (a null context is E_ARGUMENT either way),
+    # so this is checked on the GPU tier (tests/test_gpu_parity.py)
 
 
 def test_host_helpers(built):

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 import kats
+from conftest import ROOT
 import oracle_lib as O
 
 pytestmark = pytest.mark.gpu
@@ -996,3 +997,48 @@ def test_tiny_compressed_streams_with_large_output(ctx, count):
         else:
             assert errs[i][0] == 0, (i, errs[i])
             assert got[i] == x, i
+
+
+@pytest.mark.gpu
+def test_product_library_refuses_the_cross_check_options(built):
+    """libsnapmi.so (built without SNAPMI_TESTING) beside the test build this
+    suite runs on: it compresses and decompresses like it, and the options
+    that select the cross-check kernels are arguments it does not know."""
+    import ctypes as C
+    from rust_snappy_amd import _lib
+    P = C.CDLL(str(ROOT / "rust-snappy_amd" / "libsnapmi.so"),
+               mode=getattr(__import__("os"), "RTLD_LOCAL", 0))
+    assert not hasattr(P, "snapmi_ctx_set_test_option")
+    P.snapmi_ctx_create.argtypes = [C.c_int, C.c_void_p,
+                                    C.POINTER(C.c_void_p)]
+    P.snapmi_ctx_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    P.snapmi_ctx_destroy.argtypes = [C.c_void_p]
+    P.snapmi_raw_compress.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t,
+                                      C.c_void_p, C.c_size_t,
+                                      C.POINTER(C.c_size_t),
+                                      C.POINTER(_lib.SnapmiError)]
+    P.snapmi_raw_decompress.argtypes = P.snapmi_raw_compress.argtypes
+    h = C.c_void_p()
+    assert P.snapmi_ctx_create(0, None, C.byref(h)) == 0
+    try:
+        E_ARG = 101
+        for name, bad, good in ((b"compress_mode", 2, 1),
+                                (b"span_kernel", 0, 1),
+                                (b"decode_kernel", 2, 3)):
+            assert P.snapmi_ctx_set_option(h, name, bad) == E_ARG, name
+            assert P.snapmi_ctx_set_option(h, name, good) == 0, name
+        data = (O.CORPUS / "alice29.txt").read_bytes()
+        cap = len(data) + len(data) // 6 + 64
+        out = C.create_string_buffer(cap)
+        n = C.c_size_t(0)
+        err = _lib.SnapmiError()
+        assert P.snapmi_raw_compress(h, data, len(data), out, cap,
+                                     C.byref(n), C.byref(err)) == 0
+        comp = out.raw[:n.value]
+        assert comp == O.compress(data)
+        back = C.create_string_buffer(len(data))
+        assert P.snapmi_raw_decompress(h, comp, len(comp), back, len(data),
+                                       C.byref(n), C.byref(err)) == 0
+        assert back.raw[:n.value] == data
+    finally:
+        P.snapmi_ctx_destroy(h)
