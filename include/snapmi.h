@@ -125,8 +125,11 @@ void *snapmi_ctx_stream(const snapmi_ctx *ctx);
 const char *snapmi_version(void);
 /*
  * Options (results never depend on them, only speed and memory):
- *   "compress_mode"        0 wavefront-per-block kernel only, 1 lane-per-block
- *                          kernel on large batches (default), 2 both at once
+ *   "compress_mode"        0 wavefront-per-block kernel only (k_compress_spans:
+ *                          no scratch beyond the caller's buffers), 1
+ *                          lane-per-block kernel on large batches (default)
+ *                          [2, both at once, is a cross-check of the test
+ *                          build: snapmi_test.h]
  *   "small_batch_kernel"   1 (default): batches of at most two blocks per
  *                          CU run one block per CU with table AND input block
  *                          in LDS; 0 never; 2 whenever the wavefront kernel
@@ -162,11 +165,19 @@ const char *snapmi_version(void);
  *                          tables then spread further (bench.py: 75)
  *   "lane_table_tries"     placements of the lane tables that are timed
  *                          (k_probe_tables, 3 ms each) before the fastest is
- *                          kept (default 10; DESIGN 4.1: where the tables lie
- *                          decides 10-25 % of the match finder's speed).  1:
- *                          no probing, one region of the whole budget
- *   "decode_kernel"        3 (default) k_decompress_streams3; 2 the second
- *                          generation (cross-check); 0 one element at a time
+ *                          kept - at most this many (default 10), fewer when
+ *                          three of them probe within 2 % of each other
+ *                          (where the tables lie decides 10-25 %
+ *                          of the match finder's speed).  1: no probing, one
+ *                          region of the whole budget
+ *   "release_scratch"      1: the compressor's per-batch scratch (token
+ *                          arrays of the lane kernel: 128 KiB per block of a
+ *                          launch, up to 34 GB) is freed by
+ *                          snapmi_ctx_synchronize instead of being kept for
+ *                          the next batch (default 0)
+ *   "decode_kernel"        3 (default) k_decompress_streams3; 0 one element
+ *                          at a time [2, the second generation alone, is a
+ *                          cross-check of the test build]
  *   "frame_parallel_walk_min"  framed streams of at least this many bytes
  *                          decoded without a side index get their chunk
  *                          headers found in parallel (default 4 MiB)

@@ -3,6 +3,15 @@
  * (tests/, tests/hw/).  Not part of the production ABI of snapmi.h: results
  * never depend on them, and a production host has no use for them.
  *
+ * These exist in the TEST build of the library only (libsnapmi_test.so:
+ * the same sources compiled with -DSNAPMI_TESTING; rust-snappy_amd/csrc/
+ * Makefile).  The product library, libsnapmi.so, does not export
+ * snapmi_ctx_set_test_option, ignores the environment, and does not contain
+ * the cross-check kernels that only these options reach: snapmi_ctx_set_option
+ * values "compress_mode" 2 (both compressors on one ticket), "span_kernel" 0
+ * (k_compress_blocks / k_compress_block_lds, one copy per step) and
+ * "decode_kernel" 2 (k_decompress_streams2 alone) are SNAPMI_E_ARGUMENT there.
+ *
  * Environment: a process that sets SNAPMI_TESTING=1 may also steer a new
  * context with SNAPMI_LANE_WAVES, SNAPMI_LANE_SEGMENT_BLOCKS,
  * SNAPMI_LANE_TABLE_SPREAD, SNAPMI_LANE_MIN_BLOCKS, SNAPMI_FRAME_CRC_SIDE,

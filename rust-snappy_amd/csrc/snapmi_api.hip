@@ -224,6 +224,8 @@ void snapmi_ctx_destroy(snapmi_ctx *ctx)
             (void)hipHostFree(p);
     if (ctx->h_mail)
         (void)hipHostFree((void *)ctx->h_mail);
+    if (ctx->h_ratio)
+        (void)hipHostFree((void *)ctx->h_ratio);
     for (DevBuf *b : {&ctx->blk_first, &ctx->slot_first, &ctx->blk_size,
                       &ctx->blk_off, &ctx->slots, &ctx->plan_part,
                       &ctx->st_in, &ctx->st_out,
@@ -293,6 +295,13 @@ int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value)
     else if (strcmp(name, "span_kernel") == 0 && value >= kSpanMin &&
              value <= 1)
         ctx->span_kernel = (int)value;
+    else if (strcmp(name, "match_kernel") == 0 && value >= 0 && value <= 2)
+        ctx->match_kernel = (int)value;
+    else if (strcmp(name, "match_spans_ratio_pct") == 0 && value >= 1 &&
+             value <= 200)
+        ctx->match_spans_ratio_pct = (uint32_t)value;
+    else if (strcmp(name, "release_scratch") == 0 && value >= 0 && value <= 1)
+        ctx->release_scratch = (int)value;
     else if (strcmp(name, "both_wave_cus") == 0 && value >= 0 &&
              value <= 4096)
         ctx->both_wave_cus = (uint32_t)value;
@@ -410,6 +419,16 @@ int snapmi_ctx_synchronize(snapmi_ctx *ctx)
         return SNAPMI_E_ARGUMENT;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->release_scratch) {
+        // (option release_scratch: nothing of the batch is in flight now)
+        for (snapmi::DevBuf *b : {&ctx->tokens, &ctx->slots}) {
+            if (b->p) {
+                HIP_TRY(ctx, hipFree(b->p));
+                b->p = nullptr;
+                b->cap = 0;
+            }
+        }
+    }
     return SNAPMI_OK;
 }
 
@@ -612,7 +631,32 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     a.scratch = (uint8_t *)ctx->slots.p;
     a.blk_lo = 0;
     a.blk_hi = (uint32_t)blocks;
-    if (lanes_mode) {
+    // The token path's match finder: the lane kernel, or - option
+    // match_kernel - the window kernel (k_match_spans: table in LDS, no
+    // tables in HBM).  By default the context's last batch decides: data that
+    // does not compress costs a lane three HBM transactions per probe for
+    // nothing (cfg5: 12 ms of lane kernel for 32 GiB against ~4 of windows).
+    bool span_match = false;
+    if (lanes_mode && !waves_mode && ctx->lds_order_ok) {
+        if (ctx->match_kernel == 1) {
+            span_match = true;
+        } else if (ctx->match_kernel == 2 && ctx->h_ratio &&
+                   ctx->h_ratio[4] != 0) {
+            const uint64_t c =
+                ((uint64_t)ctx->h_ratio[1] << 32) | ctx->h_ratio[0];
+            const uint64_t u =
+                ((uint64_t)ctx->h_ratio[3] << 32) | ctx->h_ratio[2];
+            span_match = u && c * 100 >= u * ctx->match_spans_ratio_pct;
+        }
+    }
+    if (lanes_mode && span_match) {
+        if ((rc = reserve(ctx, ctx->tokens, (size_t)seg_blocks * kMaxTokens *
+                                                sizeof(uint64_t))) ||
+            (rc = reserve(ctx, ctx->ntok, (size_t)blocks * sizeof(uint32_t))))
+            return rc;
+        a.tokens = (unsigned long long *)ctx->tokens.p;
+        a.ntok = (uint32_t *)ctx->ntok.p;
+    } else if (lanes_mode) {
         // waves of the lane-per-block match finder: a few per CU saturate
         // the random-access rate of HBM; never more lanes than blocks
         uint64_t waves = (uint64_t)ctx->num_cus * ctx->lane_waves_per_cu;
@@ -685,6 +729,8 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                 }
             } rg;
             float best_ms = 0;
+            float probe_ms[16];
+            uint32_t n_probed = 0;
             ctx->probe_log.clear();
             size_t held_peak = 0;
             for (uint32_t t = 0; t < tries; t++) {
@@ -740,6 +786,18 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                     loser = cand;
                 }
                 cand = nullptr;
+                // enough: two more candidates within 2 % of the best one seen
+                // means the fast kind of placement has been found (the slow
+                // ones are 10-25 % off); every further candidate is a hipMalloc
+                // of the whole region and a third of the budget held
+                if (tries > 1) {
+                    probe_ms[n_probed++] = ms;
+                    uint32_t near = 0;
+                    for (uint32_t k = 0; k < n_probed; k++)
+                        near += probe_ms[k] <= best_ms * 1.02f;
+                    if (near >= 3)
+                        break;
+                }
             }
             {
                 char buf[96];
@@ -916,6 +974,15 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                 const bool spec = ctx->lane_speculate &&
                                   hi - lo <= a.n_lanes &&
                                   hi - lo <= ctx->lane_speculate_max_blocks;
+                if (span_match) {
+                    const uint64_t want =
+                        (mid - lo + kCompressWaves - 1) / kCompressWaves;
+                    hipLaunchKernelGGL(
+                        k_match_spans,
+                        dim3((uint32_t)(want < (uint64_t)ctx->num_cus
+                                            ? want : ctx->num_cus)),
+                        dim3(kCompressWaves * 64), 0, s, a);
+                } else
                 hipLaunchKernelGGL(spec ? k_match_blocks_spec : k_match_blocks,
                                    dim3(a.n_lanes / 64), dim3(64), 0, s, a);
                 if (mid < hi) {
@@ -929,6 +996,15 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                     a.blk_lo = (uint32_t)mid;
                     a.blk_hi = (uint32_t)hi;
                     HIP_TRY(ctx, hipMemsetAsync(ctx->ticket.p, 0, 64, s));
+                    if (span_match) {
+                        const uint64_t want =
+                            (hi - mid + kCompressWaves - 1) / kCompressWaves;
+                        hipLaunchKernelGGL(
+                            k_match_spans,
+                            dim3((uint32_t)(want < (uint64_t)ctx->num_cus
+                                                ? want : ctx->num_cus)),
+                            dim3(kCompressWaves * 64), 0, s, a);
+                    } else
                     hipLaunchKernelGGL(
                         spec ? k_match_blocks_spec : k_match_blocks,
                         dim3(a.n_lanes / 64), dim3(64), 0, s, a);
@@ -956,6 +1032,19 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     if (blocks && direct) {
         hipLaunchKernelGGL(k_stream_lens, dim3((uint32_t)((n + 255) / 256)),
                            dim3(256), 0, s, a);
+        // what this batch compressed to, for the next batch's choice of
+        // match finder (read without waiting: a hint)
+        if (ctx->match_kernel == 2 && blocks >= 2 * ctx->lane_min_blocks) {
+            if (!ctx->h_ratio) {
+                HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_ratio, 64,
+                                           hipHostMallocDefault));
+                memset((void *)ctx->h_ratio, 0, 64);
+            }
+            hipLaunchKernelGGL(k_post_ratio, dim3(1), dim3(1024), 0, s,
+                               (uint32_t *)ctx->h_ratio, a.blk_off,
+                               (uint32_t)blocks, a.in_lens, a.n_streams,
+                               ++ctx->ratio_seq);
+        }
     } else if (blocks) {
         launch_scan_sizes(a, s);
         hipLaunchKernelGGL(k_compact, dim3((uint32_t)blocks), dim3(256), 0,

@@ -680,6 +680,16 @@ __device__ __noinline__ uint32_t next_ticket(uint32_t *ticket, uint32_t lane,
     return uni(blk);
 }
 
+// the same for a kernel that takes blocks from the front only
+__device__ __noinline__ uint32_t next_front_ticket(uint32_t *ticket,
+                                                   uint32_t lane)
+{
+    uint32_t t = 0;
+    if (lane == 0)
+        t = atomicAdd(ticket, 1u);
+    return uni(t);
+}
+
 // ---------------------------------------------------------------------
 // Self-check run once per context (snapmi_ctx_create): k_compress_blocks
 // needs one wave64 ds_mskor_rtn_b32 to apply lanes that hit the same address
@@ -950,6 +960,60 @@ __device__ __forceinline__ void lds_mskor(uint32_t byte_addr, uint32_t mask,
 }
 
 namespace {
+// The window kernel as a MATCH FINDER for the lane kernel's encoder
+// (k_match_spans): the same record / flush interface as TokenSink, but a
+// flush stores the wave's pending tokens in k_encode_tokens' format (literal
+// length | copy length << 17 | offset << 33), 64 of them coalesced, and adds
+// up what they will encode to (token_bytes) - so that, as behind
+// k_match_blocks, every block's size is known before a byte of it is written
+// and k_encode_tokens can put it at its final position (no scratch slots, no
+// k_compact).
+struct TokenWriter {
+    typedef __attribute__((address_space(1))) unsigned long long g_u64;
+    g_u64 *tok;    // this block's token array
+    uint32_t ntok; // tokens stored so far (uniform)
+    uint32_t d;    // encoded bytes of the tokens stored so far (uniform)
+    uint32_t a, b; // this lane's pending token (TokenSink's packing)
+    uint32_t t;    // tokens pending (uniform)
+    uint32_t lane;
+
+    __device__ __forceinline__ void init(g_u64 *tokens, uint32_t l)
+    {
+        tok = tokens;
+        ntok = 0;
+        d = 0;
+        a = b = 0;
+        t = 0;
+        lane = l;
+    }
+    __device__ __forceinline__ void record_nf(uint32_t lit_start,
+                                              uint32_t lit_len,
+                                              uint32_t offset,
+                                              uint32_t copy_len)
+    {
+        const bool me = lane == t;
+        a = me ? ((lit_len & 0xFFFFu) | (offset << 16)) : a;
+        b = me ? (copy_len | (lit_start << 16)) : b;
+        t++;
+    }
+    __device__ __forceinline__ void flush()
+    {
+        const bool act = lane < t;
+        const uint32_t C = act ? (b & 0xFFFFu) : 0;
+        uint32_t L = act ? (a & 0xFFFFu) : 0;
+        if (act && L == 0 && C == 0)
+            L = kMaxBlock; // (TokenSink: the one length that needs 17 bits)
+        const uint32_t O = a >> 16;
+        if (act)
+            tok[ntok + lane] = (unsigned long long)L |
+                               ((unsigned long long)C << 17) |
+                               ((unsigned long long)O << 33);
+        const uint32_t size = act ? token_bytes(L, C, O) : 0;
+        d += rdlane(wave_inclusive_scan(size), kWave - 1);
+        ntok += t;
+        t = 0;
+    }
+};
 struct SpanLanes {
     uint32_t mv, ov; // this lane's match length and exchanged table entry
     __device__ __forceinline__ uint32_t m(uint32_t l) const
@@ -961,8 +1025,8 @@ struct SpanLanes {
         return rdlane(ov, l);
     }
 };
-struct SpanSink {
-    TokenSink *out;
+template <class OUT> struct SpanSink {
+    OUT *out;
     uint32_t emit; // where the pending literal starts
     __device__ __forceinline__ void token(uint32_t lit, uint32_t len,
                                           uint32_t off)
@@ -973,7 +1037,7 @@ struct SpanSink {
 };
 } // namespace
 
-template <bool kLds>
+template <bool kLds, bool kTok = false>
 __device__ __forceinline__ void compress_one_block_span(
     const CompressArgs &a, const uint32_t b, const uint32_t lane,
     const lptr16 table, const uint32_t tbase,
@@ -996,32 +1060,43 @@ __device__ __forceinline__ void compress_one_block_span(
     const uint64_t avail = total - boff;
     const uint32_t n = avail < kMaxBlock ? (uint32_t)avail : kMaxBlock;
 
-    gptr dst;
-    if (k == 0) {
-        dst = (gptr)a.out_ptrs[st_i];
-        if (lane == 0) { // varint(total): src/compress.rs:128
-            uint64_t v = total;
-            uint32_t i = 0;
-            while (v >= 0x80) {
-                dst[i++] = (uint8_t)v | 0x80;
-                v >>= 7;
-            }
-            dst[i] = (uint8_t)v;
-        }
-        dst += varint_len(total);
+    typename std::conditional<kTok, TokenWriter, TokenSink>::type out;
+    if constexpr (kTok) {
+        // match finder only: tokens for k_encode_tokens (which also writes
+        // the varint of block 0)
+        out.init((TokenWriter::g_u64 *)a.tokens +
+                     (uint64_t)(b - a.tok_base) * kMaxTokens,
+                 lane);
     } else {
-        const uint32_t slot = a.slot_first[st_i] + k - 1;
-        if (slot >= a.host_slots)
-            return; // stream rejected by k_plan_compress (E_ARGUMENT)
-        dst = (gptr)a.scratch + (uint64_t)slot * kSlotBytes;
+        gptr dst;
+        if (k == 0) {
+            dst = (gptr)a.out_ptrs[st_i];
+            if (lane == 0) { // varint(total): src/compress.rs:128
+                uint64_t v = total;
+                uint32_t i = 0;
+                while (v >= 0x80) {
+                    dst[i++] = (uint8_t)v | 0x80;
+                    v >>= 7;
+                }
+                dst[i] = (uint8_t)v;
+            }
+            dst += varint_len(total);
+        } else {
+            const uint32_t slot = a.slot_first[st_i] + k - 1;
+            if (slot >= a.host_slots)
+                return; // stream rejected by k_plan_compress (E_ARGUMENT)
+            dst = (gptr)a.scratch + (uint64_t)slot * kSlotBytes;
+        }
+        out.init(src, n, dst, lane);
     }
-    TokenSink out;
-    out.init(src, n, dst, lane);
     if (n < kMinNonLiteral) { // src/compress.rs:140-146
-        out.record(0, n, 0, 0);
+        out.record_nf(0, n, 0, 0);
         out.flush();
-        if (lane == 0)
+        if (lane == 0) {
             a.blk_size[b] = out.d;
+            if constexpr (kTok)
+                a.ntok[b] = out.ntok;
+        }
         return;
     }
     typename std::conditional<kLds, lcptr, gcptr>::type msrc;
@@ -1071,7 +1146,7 @@ __device__ __forceinline__ void compress_one_block_span(
         wv3 = ld32u(msrc + (lane + 192 < n4 ? lane + 192 : n4));
         wv4 = ld32u(msrc + (lane + 256 < n4 ? lane + 256 : n4));
     }
-    SpanSink sink;
+    SpanSink<decltype(out)> sink;
     sink.out = &out;
     sink.emit = 0;
 #ifdef SNAPMI_PROFILE
@@ -1276,8 +1351,11 @@ __device__ __forceinline__ void compress_one_block_span(
         out.record_nf(sink.emit, n - sink.emit, 0, 0);
     if (out.t)
         out.flush();
-    if (lane == 0)
+    if (lane == 0) {
         a.blk_size[b] = out.d;
+        if constexpr (kTok)
+            a.ntok[b] = out.ntok;
+    }
 #ifdef SNAPMI_PROFILE
     TICK(8);
     if (lane == 0 && a.prof) {
@@ -1288,6 +1366,64 @@ __device__ __forceinline__ void compress_one_block_span(
         atomicAdd(&a.prof[12], 1ull);
     }
 #endif
+}
+
+// The window kernel as the match finder of the token path (k_scan_sizes +
+// k_encode_tokens behind it, every block at its final position): what
+// launch_compress runs instead of k_match_blocks where the lane kernel's
+// tables buy nothing - batches that do not compress (every probe of a lane is
+// an HBM transaction, here it is an LDS access: cfg5), and whenever the
+// option says so.  Blocks [blk_lo, blk_hi) from the front of the ticket.
+__global__ __launch_bounds__(kCompressWaves * 64) void k_match_spans(
+    CompressArgs a)
+{
+    __shared__ __attribute__((aligned(16)))
+    uint16_t tables[kCompressWaves][kMaxTable];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    const lptr16 table = (lptr16)&tables[wave][0];
+    const uint32_t tbase = (uint32_t)(uintptr_t)table;
+    uint32_t nblocks = a.blk_first[a.n_streams];
+    if (nblocks > a.host_blocks)
+        nblocks = a.host_blocks;
+    if (nblocks > a.blk_hi)
+        nblocks = a.blk_hi;
+    // (the ticket through a helper that is not inlined: DESIGN section 5)
+    uint32_t b = a.blk_lo + uni(next_front_ticket(a.ticket, lane));
+    while (b < nblocks) {
+        compress_one_block_span<false, true>(a, b, lane, table, tbase);
+        b = a.blk_lo + uni(next_front_ticket(a.ticket, lane));
+    }
+}
+
+// What the batch compressed to, posted into pinned host memory for the NEXT
+// batch's choice of match finder (launch_compress: a context whose data does
+// not compress is better off with LDS tables).  words 0..1 = compressed bytes
+// of the blocks, 2..3 = input bytes of the batch, 4 = the batch's number.
+__global__ __launch_bounds__(1024) void k_post_ratio(
+    uint32_t *host_mapped, const uint64_t *blk_off, uint32_t blocks,
+    const uint64_t *in_lens, uint32_t n_streams, uint32_t seq)
+{
+    __shared__ unsigned long long part[1024];
+    unsigned long long sum = 0;
+    for (uint32_t i = threadIdx.x; i < n_streams; i += 1024)
+        sum += in_lens[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t w = 512; w; w >>= 1) {
+        if (threadIdx.x < w)
+            part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const uint64_t total = blk_off[blocks];
+        host_mapped[0] = (uint32_t)total;
+        host_mapped[1] = (uint32_t)(total >> 32);
+        host_mapped[2] = (uint32_t)part[0];
+        host_mapped[3] = (uint32_t)(part[0] >> 32);
+        __threadfence_system();
+        host_mapped[4] = seq;
+    }
 }
 
 __global__ __launch_bounds__(kCompressWaves * 64) void k_compress_spans(

@@ -72,6 +72,27 @@ struct snapmi_ctx {
     // workgroups take (each owns a CU's whole LDS, so the lane kernel's
     // wavefronts run on the others); 0 = half of the CUs
     uint32_t both_wave_cus = 0;
+    // 1: the per-batch scratch of the compressor (token arrays: 128 KiB per
+    // block of a lane-kernel segment, up to 34 GB; block slots of the
+    // wavefront kernels) is given back when the batch's results are waited
+    // for (snapmi_ctx_synchronize, snapmi_last_timing, the scalar and host
+    // entry points) instead of being kept for the next batch.  For a host
+    // that compresses now and then and shares the GPU; costs a hipFree /
+    // hipMalloc pair per batch.  The lane tables are not scratch: they are
+    // bounded by lane_table_budget_pct.
+    int release_scratch = 0;
+    // the match finder of the token path (large batches, compress_mode 1):
+    // 0 = k_match_blocks (a lane per block, hash tables in HBM), 1 =
+    // k_match_spans (a wavefront per block, table in LDS, no tables in HBM
+    // at all), 2 (default) = by what this context's last batch compressed
+    // to: data that does not compress (ratio >= match_spans_ratio_pct) costs
+    // a lane three HBM transactions per probe for nothing
+    int match_kernel = 2;
+    uint32_t match_spans_ratio_pct = 90;
+    // the hint: pinned words the last token-path batch posted (compressed
+    // bytes, input bytes, its number)
+    volatile uint32_t *h_ratio = nullptr;
+    uint32_t ratio_seq = 0; // batches posted so far
     // 1 (default): a lane-kernel launch of at most lane_speculate_max_blocks
     // blocks (and no more blocks than lanes) runs k_match_blocks_spec (a
     // probe's round also fetches the entry of the probe that follows a

@@ -94,6 +94,10 @@ __global__ void k_scan_sizes_c(CompressArgs a);
 __global__ void k_compress_blocks(CompressArgs a);
 __global__ void k_compress_block_lds(CompressArgs a);
 __global__ void k_compress_spans(CompressArgs a);    // window steps, 5 tables/CU
+__global__ void k_match_spans(CompressArgs a); // ... as the token path's match finder
+__global__ void k_post_ratio(uint32_t *host_mapped, const uint64_t *blk_off,
+                             uint32_t blocks, const uint64_t *in_lens,
+                             uint32_t n_streams, uint32_t seq);
 __global__ void k_compress_span_lds(CompressArgs a); // ... one block per CU
 __global__ void k_compress_tiny(CompressArgs a);
 __global__ void k_compress_small512(CompressArgs a); // [256, 512) bytes

@@ -46,7 +46,8 @@ def ctx(request, built):
 
 @pytest.fixture(scope="session",
                 params=["spans", "spans_lds", "waves", "waves_lds", "lanes",
-                        "lanes_segmented", "lanes_overlap", "both"])
+                        "lanes_segmented", "lanes_overlap", "both",
+                        "spans_match"])
 def cctx(request, built):
     """A context per compressor kernel: the wavefront-per-block kernels (window
     steps and, as the cross-check, one copy per step; five tables per CU and
@@ -64,8 +65,12 @@ def cctx(request, built):
     c.set_option("compress_mode", {"spans": 0, "spans_lds": 0, "waves": 0,
                                    "waves_lds": 0, "lanes": 1,
                                    "lanes_segmented": 1, "lanes_overlap": 1,
-                                   "both": 2}[
+                                   "both": 2, "spans_match": 1}[
         request.param])
+    # the token path's match finder: the lane kernel in the "lanes*"
+    # configurations whatever the last batch compressed to (the default picks
+    # by that), the window kernel (k_match_spans) in "spans_match"
+    c.set_option("match_kernel", 1 if request.param == "spans_match" else 0)
     # spans / waves: five tables per CU, input from L2; *_lds: one block per
     # CU, table and input block in LDS (the kernel of the smallest batches).
     # spans*: a window of 63 positions per step (k_compress_spans, the
