@@ -1133,6 +1133,7 @@ __device__ __forceinline__ void compress_one_block_span(
     st.chain = 0;
     st.next_emit = 0;
     uint32_t run0 = 1; // schedule steps: where the run began
+    uint32_t dq = ~0u, d0 = 0, d1 = 0; // kDelta.d[dq + lane], [dq + lane + 1]
     // Register window of the input for the hashes (global input only): lane l
     // of wv[j] holds the dword at block offset wbase + 64 j + l; five
     // registers, so that a step may move s by up to 128 positions and the
@@ -1166,8 +1167,21 @@ __device__ __forceinline__ void compress_one_block_span(
         if (!st.chain && st.q >= kSpanRun) {
             // ---- schedule step (k_compress_blocks' batch for q > 0): lane l
             // is probe q + l of the run that began at run0
-            const uint32_t p = run0 + kDelta.d[st.q + lane];
-            const uint32_t nextp = run0 + kDelta.d[st.q + lane + 1];
+            // (this lane's two schedule entries were requested one step
+            // ahead: a run of misses goes on with q + 64, and a load from the
+            // table costs a step of incompressible data a fifth of its time)
+            if (dq != st.q) {
+                d0 = kDelta.d[st.q + lane];
+                d1 = kDelta.d[st.q + lane + 1];
+            }
+            const uint32_t p = run0 + d0;
+            const uint32_t nextp = run0 + d1;
+            {
+                const uint32_t qn = st.q + kWave + lane;
+                d0 = kDelta.d[qn < 446 ? qn : 446];
+                d1 = kDelta.d[qn < 446 ? qn + 1 : 447];
+                dq = st.q + kWave;
+            }
             const bool valid = nextp <= s_limit; // src/compress.rs:212-214
             const B16 x = ld128u(msrc + (p < n16 ? p : n16));
             const uint32_t h = hash32(x.w[0], shift);
