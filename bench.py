@@ -466,9 +466,22 @@ def main():
     if over:
         os.environ["SNAPMI_OVERSUBSCRIBE"] = "1"
         local_rank = 0
-    if torch.cuda.device_count() <= local_rank:
-        sys.exit(f"bench.py: rank {rank} wants cuda:{local_rank} but only "
-                 f"{torch.cuda.device_count()} devices are visible")
+    if torch.cuda.device_count() <= local_rank or (
+            not over and torch.cuda.device_count() < world):
+        # EVERY rank sees this (the same count on one node) and leaves at
+        # once: no rank is left waiting in a rendezvous for one that is gone
+        msg = (f"--gpus {world}: {torch.cuda.device_count()} device(s) "
+               f"visible to rank {rank} (wants cuda:{local_rank}; one device "
+               f"per rank, no oversubscription)")
+        log("[bench] " + msg)
+        if rank == 0:
+            print(json.dumps({
+                "metric": "GiB/s uncompressed (compress + decompress) on "
+                          "zflat/uflat corpus", "value": None,
+                "unit": "GiB/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "higher_is_better": True,
+                "scaling": "weak", "error": msg}), flush=True)
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cdev = torch.device("cpu") if over else dev  # where collectives run
@@ -521,10 +534,10 @@ def main():
             f"{ubytes / GIB:.3f} GiB uncompressed per GPU, world={world}")
 
     # ---- inputs resident in HBM, tiled on the device --------------------
+    # (the library's defaults throughout: the lane tables within a third of
+    # the free memory.  Rounds 2-3 quoted the headline at 75 %; measured in
+    # round 4 - extras.budget - 75, 33 and 15 % give the same rate)
     ctx = raw.Context(local_rank)
-    # the benchmark owns its GPU: the lane tables may spread over three
-    # quarters of the free memory (a library user's default is a third)
-    ctx.set_option("lane_table_budget_pct", 75)
     d_round = torch.from_numpy(host_round).to(dev)
     data = d_round.repeat(rounds)
     offs = (np.arange(rounds, dtype=np.int64)[:, None] * round_stride
@@ -771,7 +784,7 @@ def main():
                              f"GPU ({n} independent raw streams), compress "
                              f"then decompress, HBM-resident"),
                 "streams_per_gpu": n, "ratio": round(ratio, 4),
-                "lane_table_budget_pct": 75,
+                "lane_table_budget_pct": 33,
                 "parallelism": f"shard-by-stream x{world}"},
             "compress_gibs": round(comp_gibs, 3),
             "decompress_gibs": round(dec_gibs, 3),

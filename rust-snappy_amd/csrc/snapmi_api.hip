@@ -1408,10 +1408,18 @@ struct OneDesc {
 constexpr size_t kPinStage = 8u << 20;
 
 // compressed bytes from which the scalar decompress entry points use
-// snapmi_decompress_stream (SNAPMI_LONG_STREAM overrides)
+// snapmi_decompress_stream (one stream on many wavefronts).  The ten small
+// launches of the hierarchical scan cost ~0.5 ms; a single wavefront decodes
+// 100-250 MB/s: measured per bench input at 16 KiB and at 256 KiB
+// (profiles/r4_scalar_latency.txt: the test build reads SNAPMI_LONG_STREAM),
+// the scan pays from ~150 KB of compressed input on (lcet10.txt 3.6 -> 2.2
+// ms) and costs below (html 0.62 -> 1.07 ms)
 static const size_t kLongStream = [] {
-    const char *e = getenv("SNAPMI_LONG_STREAM");
-    return e ? (size_t)atoll(e) : (size_t)(256 << 10);
+#ifdef SNAPMI_TESTING
+    if (const char *e = getenv("SNAPMI_LONG_STREAM"))
+        return (size_t)atoll(e);
+#endif
+    return (size_t)(128 << 10);
 }();
 
 // pinned host staging of a context (grow-only): pageable copies go through

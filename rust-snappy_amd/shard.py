@@ -99,6 +99,22 @@ class Comm:
             raw._raise(ctx, rc)
         self._h = h
 
+    @classmethod
+    def wrap(cls, ctx, nccl_comm, rank, world):
+        """snapmi_comm_wrap: around an ncclComm_t the host already has (its
+        address as an int); the communicator stays the host's."""
+        from . import _lib, raw
+        self = cls.__new__(cls)
+        self._L, self._raw, self.ctx = _lib.load(), raw, ctx
+        self.rank, self.world = rank, world
+        h = C.c_void_p()
+        rc = self._L.snapmi_comm_wrap(ctx._h, C.c_void_p(nccl_comm), rank,
+                                      world, C.byref(h))
+        if rc:
+            raw._raise(ctx, rc)
+        self._h = h
+        return self
+
     @staticmethod
     def unique_id():
         from . import _lib
