@@ -230,17 +230,12 @@ SNAPMI_LANE_FN bool span_fast_ok(const SpanState &st, const uint64_t hits,
 
 // hits: lanes (1..63) whose lookup would hit; longs: those of them with 16
 // equal bytes or more.  LN::m(lane) = the match length there.
-// L0 = the first lane that is a lookup (1 in a step's first slot: lane 0 is the
-// insert of s - 1; in the second slot, below, any lane 0 .. 14), seed = lanes
-// below L0 that lie inside a copy which began in the slot in front.
 template <class LN>
 SNAPMI_LANE_FN void span_fast_walk(const uint64_t hits, const uint64_t longs,
-                                   const LN &ln, SpanFast &f,
-                                   const uint32_t L0 = 1,
-                                   const uint64_t seed = 0)
+                                   const LN &ln, SpanFast &f)
 {
-    uint64_t inside = seed, ahead;
-    uint32_t L = L0, X = 0, e = 0;
+    uint64_t inside = 0, ahead;
+    uint32_t L = 1, X = 0, e = 0;
     for (;;) {
         ahead = hits >> L; // L <= 63
         if (!ahead)
@@ -270,42 +265,21 @@ SNAPMI_LANE_FN void span_fast_walk(const uint64_t hits, const uint64_t longs,
 // lies below stands as it is.
 SNAPMI_LANE_FN void span_fast_masks(const SpanFast &f, const uint64_t hits,
                                     const uint32_t chain0, const uint32_t cut,
-                                    uint64_t &vh, uint64_t &touched,
-                                    const uint32_t L0 = 1)
+                                    uint64_t &vh, uint64_t &touched)
 {
-    // lanes L0 .. stop-1 were walked: a long match ends the walk at its lane
+    // lanes 1 .. stop-1 were walked: a long match ends the walk at its lane
     // (which is looked up, hence inserted), a cut in front of its lane
     const uint32_t lstop = f.kind == kFastLong ? f.at + 1 : 64;
-    const uint32_t stop = cut < lstop ? cut : lstop; // L0 .. 64
-    const uint64_t below = stop ? ~0ull >> (64 - stop) : 0;
-    const uint64_t range = below & (~0ull << L0);
+    const uint32_t stop = cut < lstop ? cut : lstop; // 1 .. 64
+    const uint64_t range = (~0ull >> (64 - stop)) & ~1ull;
     const uint64_t visited = range & ~f.inside;
     const uint64_t lbit = f.kind == kFastLong ? 1ull << f.at : 0;
     vh = visited & hits & ~lbit;
-    // the last lane inside every copy is inserted (that of a copy from the
-    // slot in front - the seed - too); lane 63 never is (a copy that reaches
-    // it leaves the window: kFastCopyOut)
+    // the last lane inside every copy is inserted; lane 63 never is (a copy
+    // that reaches it leaves the window: kFastCopyOut)
     const uint64_t ins =
-        f.inside & ~(f.inside >> 1) & ~(1ull << 63) & below;
+        f.inside & ~(f.inside >> 1) & ~(1ull << 63) & range;
     touched = visited | ins | (chain0 ? 1ull : 0ull);
-}
-
-// the second slot of a step (lanes 0 .. 63 = the 64 positions behind the
-// first slot's): may the fast walk go on there?  L0 = its first lookup lane,
-// a chain check (chain) or probe q of a run
-SNAPMI_LANE_FN bool span_fast_ok2(const uint64_t hits, const uint32_t L0,
-                                  const uint32_t chain, const uint32_t q)
-{
-    const uint64_t z = ~hits;
-    uint64_t r = z & (z >> 1);
-    r &= r >> 2;
-    r &= r >> 4;
-    r &= r >> 8;
-    r &= r >> 16;
-    const uint64_t ahead = hits >> L0; // L0 <= 63
-    const uint32_t lead = ahead ? (uint32_t)__builtin_ctzll(ahead) : 64;
-    const bool run_ok = (chain != 0) | (q + lead < kSpanRun);
-    return (r == 0) & run_ok;
 }
 
 // lane l's token if it is in vh: literal length and start; its rank among the
@@ -327,8 +301,7 @@ SNAPMI_LANE_FN void span_fast_token(const uint32_t l, const uint32_t base,
 // position when the caller has a long match to finish, kSpanCont otherwise);
 // emit = the new "first byte not covered"
 SNAPMI_LANE_FN uint32_t span_fast_state(SpanState &st, const SpanFast &f,
-                                        const uint32_t cut, uint32_t &emit,
-                                        const uint32_t L0 = 1)
+                                        const uint32_t cut, uint32_t &emit)
 {
     const uint32_t base = st.s;
     const bool is_cut = cut < 64;
@@ -336,20 +309,19 @@ SNAPMI_LANE_FN uint32_t span_fast_state(SpanState &st, const SpanFast &f,
     const bool is_out = !is_cut & (f.kind == kFastCopyOut);
     const bool is_run = !is_cut & (f.kind == kFastRun);
     // the inside lanes that count: below the cut, below a long match's lane
-    const uint32_t lim = is_cut ? cut : (is_long ? f.at : 64); // 0 .. 64
-    const uint64_t in_b = lim ? f.inside & (~0ull >> (64 - lim)) : 0;
+    const uint32_t lim = is_cut ? cut : (is_long ? f.at : 64); // 1 .. 64
+    const uint64_t in_b = f.inside & (~0ull >> (64 - lim));
     const uint32_t hb = 63u - (uint32_t)__builtin_clzll(in_b | 1);
     // a cut: in front of the insert behind a copy (the copy stands, insert
     // and check are the next step's), of a chain check, or of a probe
     const bool cut_ins = is_cut & (((f.inside >> (cut & 63)) & 1) != 0);
     const bool cut_chk =
         is_cut & !cut_ins &
-        (cut == L0 ? (st.chain != 0) | (in_b != 0)
-                   : ((f.inside >> ((cut - 1) & 63)) & 1) != 0);
+        (cut == 1 ? st.chain != 0
+                  : ((f.inside >> ((cut - 1) & 63)) & 1) != 0);
     const bool cut_run = is_cut & !cut_ins & !cut_chk;
     const uint32_t q_cut =
-        in_b ? cut - (hb + 2)
-             : (st.chain ? cut - L0 - 1 : st.q + cut - L0);
+        in_b ? cut - (hb + 2) : (st.chain ? cut - 2 : st.q + cut - 1);
     uint32_t nemit = in_b ? base + hb : emit;
     nemit = cut_ins ? base + cut : nemit;
     nemit = is_out ? base - 1 + f.end : nemit;

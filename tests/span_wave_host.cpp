@@ -89,7 +89,7 @@ struct Out {
 // stats[0] window steps, [1] schedule steps, [2] cuts of fast steps, [3] long
 // matches,
 // [4] tokens, [5] lanes touched, [6] tokens of window steps, [7] window
-// steps that took the fast walk, [8] steps whose walk went on into slot B
+// steps that took the fast walk
 extern "C" uint32_t span_wave_compress(const uint8_t *src, uint32_t n,
                                        uint8_t *out, uint32_t out_cap,
                                        uint64_t *stats)
@@ -168,17 +168,12 @@ extern "C" uint32_t span_wave_compress(const uint8_t *src, uint32_t n,
                 break;
             continue;
         }
-        // the window step: slot A = lanes 0..63 at positions base - 1 + l
-        // (lane 0: the insert of s - 1), and - while the block has room -
-        // slot B = the 64 positions behind them, exchanged and compared in
-        // the same step; the walk goes on into B when it left A at its end
+        // the window step
         stats[0]++;
         const uint32_t base = st.s, lo = st.s - st.chain;
-        const bool two = base + 64 + 93 <= n;
-        bool act[64], actB[64];
-        uint32_t h[64], hB[64];
-        Lanes lnB;
-        uint64_t hits = 0, cbits = 0, hitsB = 0, cbitsB = 0, longsB = 0;
+        bool act[64];
+        uint32_t h[64];
+        uint64_t hits = 0, cbits = 0;
         for (uint32_t l = 0; l < 64; l++) {
             const uint32_t P = base - 1 + l;
             act[l] = l ? P + 16 <= n : st.chain != 0;
@@ -195,26 +190,8 @@ extern "C" uint32_t span_wave_compress(const uint8_t *src, uint32_t n,
             if (ln.ov[l] >= lo)
                 cbits |= 1ull << l;
         }
-        for (uint32_t l = 0; l < 64; l++) {
-            actB[l] = two;
-            lnB.mv[l] = lnB.ov[l] = 0;
-            if (!two)
-                continue;
-            const uint32_t P = base + 63 + l;
-            hB[l] = tiny_hash(le32(src + P), shift);
-            lnB.ov[l] = table[hB[l]];
-            table[hB[l]] = (uint16_t)P;
-            lnB.mv[l] = common(src + P, src + lnB.ov[l], 16);
-            if (lnB.mv[l] >= 4)
-                hitsB |= 1ull << l;
-            if (lnB.mv[l] >= 16)
-                longsB |= 1ull << l;
-            if (lnB.ov[l] >= lo)
-                cbitsB |= 1ull << l;
-        }
-        uint64_t T = 0, TB = 0;
+        uint64_t T = 0;
         uint32_t at = 0, rc = kSpanCont;
-        bool atB = false; // a long match found in slot B
         const size_t tok0 = sink.t.size();
         // the kernel's order: the fast walk where its conditions hold, the
         // exact walk otherwise
@@ -256,65 +233,6 @@ extern "C" uint32_t span_wave_compress(const uint8_t *src, uint32_t n,
             uint32_t emit = st.next_emit;
             rc = span_fast_state(st, f, cut, emit);
             at = f.at;
-            // ---- slot B: the walk left A at its end (a run of misses, or a
-            // copy that ends behind lane 63) and goes on
-            bool goB = two && cut == 64 &&
-                       (f.kind == kFastRun || f.kind == kFastCopyOut);
-            uint32_t L0 = 0;
-            if (goB && f.kind == kFastCopyOut) {
-                L0 = f.end - 64;
-                if (f.end == 64) {
-                    // the insert of e - 1 is A's lane 63
-                    const uint32_t pred = ln.ov[63] - (base - 1);
-                    if (((cbits >> 63) & 1) && !((T >> (pred & 63)) & 1))
-                        goB = false;
-                    else
-                        T |= 1ull << 63;
-                }
-            }
-            if (goB && !span_fast_ok2(hitsB, L0, st.chain, st.q))
-                goB = false;
-            if (goB && f.kind == kFastCopyOut && f.end == 64)
-                st.chain = 1; // (unchanged: lane 0 of B is the chain check)
-            if (goB) {
-                stats[8]++;
-                const uint64_t seed =
-                    st.chain && L0 ? (1ull << L0) - 1 : 0;
-                SpanFast fB;
-                span_fast_walk(hitsB, longsB, lnB, fB, L0, seed);
-                uint64_t vhB;
-                span_fast_masks(fB, hitsB, 0, 64, vhB, TB, L0);
-                uint32_t cutB = 64;
-                for (uint32_t l = 0; l < 64; l++) {
-                    const uint32_t g = lnB.ov[l] - (base - 1); // 0 .. 127
-                    const bool pt = g < 64 ? (T >> g) & 1
-                                           : (TB >> ((g - 64) & 63)) & 1;
-                    if (((TB >> l) & 1) && ((cbitsB >> l) & 1) && !pt) {
-                        cutB = l;
-                        break;
-                    }
-                }
-                if (cutB < 64)
-                    span_fast_masks(fB, hitsB, 0, cutB, vhB, TB, L0);
-                const size_t tokA = sink.t.size() - tok0;
-                for (uint32_t l = 0; l < 64; l++) {
-                    if (!((vhB >> l) & 1))
-                        continue;
-                    uint32_t lit, rank;
-                    span_fast_token(l, base + 64, st.next_emit, fB.inside,
-                                    vhB, lit, rank);
-                    if (rank + tokA != sink.t.size() - tok0)
-                        return 0x80000003u;
-                    const uint32_t P = base + 63 + l;
-                    sink.token(lit, lnB.mv[l], P - lnB.ov[l]);
-                }
-                SpanState sb{base + 64, st.q, st.chain, st.next_emit};
-                uint32_t emitB = st.next_emit;
-                rc = span_fast_state(sb, fB, cutB, emitB, L0);
-                st = sb;
-                at = fB.at;
-                atB = rc == kSpanLong;
-            }
         }
         if (!fast)
             rc = span_walk(st, hits, cbits, s_limit, ln, sink, T, at);
@@ -329,18 +247,9 @@ extern "C" uint32_t span_wave_compress(const uint8_t *src, uint32_t n,
             else if (!c)
                 table[h[l]] = (uint16_t)ln.ov[l];
         }
-        for (uint32_t l = 0; l < 64; l++) {
-            if (!actB[l])
-                continue;
-            const bool t = (TB >> l) & 1, c = (cbitsB >> l) & 1;
-            if (t)
-                table[hB[l]] = (uint16_t)(base + 63 + l);
-            else if (!c)
-                table[hB[l]] = (uint16_t)lnB.ov[l];
-        }
         if (rc == kSpanLong) {
             stats[3]++;
-            const uint32_t P = st.s, cand = atB ? lnB.ov[at] : ln.ov[at];
+            const uint32_t P = st.s, cand = ln.ov[at];
             const uint32_t len =
                 16 + common(src + P + 16, src + cand + 16, n - P - 16);
             sink.token(P - st.next_emit, len, P - cand);
