@@ -640,13 +640,17 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     if (lanes_mode && !waves_mode && ctx->lds_order_ok) {
         if (ctx->match_kernel == 1) {
             span_match = true;
-        } else if (ctx->match_kernel == 2 && ctx->h_ratio &&
-                   ctx->h_ratio[4] != 0) {
-            const uint64_t c =
-                ((uint64_t)ctx->h_ratio[1] << 32) | ctx->h_ratio[0];
-            const uint64_t u =
-                ((uint64_t)ctx->h_ratio[3] << 32) | ctx->h_ratio[2];
-            span_match = u && c * 100 >= u * ctx->match_spans_ratio_pct;
+        } else if (ctx->match_kernel == 2 && ctx->h_ratio) {
+            // the slot of the latest batch that has finished (a slot reads
+            // 0 in word 4 while a kernel is writing it)
+            const volatile uint32_t *r = ctx->h_ratio;
+            const uint32_t s0 = r[4], s1 = r[12];
+            const volatile uint32_t *slot = s1 > s0 ? r + 8 : r;
+            const uint32_t seq = slot[4];
+            const uint64_t c = ((uint64_t)slot[1] << 32) | slot[0];
+            const uint64_t u = ((uint64_t)slot[3] << 32) | slot[2];
+            span_match = seq && slot[4] == seq && u &&
+                         c * 100 >= u * ctx->match_spans_ratio_pct;
         }
     }
     if (lanes_mode && span_match) {

@@ -1412,8 +1412,9 @@ __global__ __launch_bounds__(kCompressWaves * 64) void k_match_spans(
 
 // What the batch compressed to, posted into pinned host memory for the NEXT
 // batch's choice of match finder (launch_compress: a context whose data does
-// not compress is better off with LDS tables).  words 0..1 = compressed bytes
-// of the blocks, 2..3 = input bytes of the batch, 4 = the batch's number.
+// not compress is better off with LDS tables).  Per slot: words 0..1 =
+// compressed bytes of the blocks, 2..3 = input bytes of the batch, 4 = the
+// batch's number (0 while the slot is being written).
 __global__ __launch_bounds__(1024) void k_post_ratio(
     uint32_t *host_mapped, const uint64_t *blk_off, uint32_t blocks,
     const uint64_t *in_lens, uint32_t n_streams, uint32_t seq)
@@ -1430,13 +1431,18 @@ __global__ __launch_bounds__(1024) void k_post_ratio(
         __syncthreads();
     }
     if (threadIdx.x == 0) {
+        // (two slots, taken in turn: the host reads the one whose number is
+        // higher while the other is being written)
+        uint32_t *slot = host_mapped + 8 * (seq & 1);
         const uint64_t total = blk_off[blocks];
-        host_mapped[0] = (uint32_t)total;
-        host_mapped[1] = (uint32_t)(total >> 32);
-        host_mapped[2] = (uint32_t)part[0];
-        host_mapped[3] = (uint32_t)(part[0] >> 32);
+        slot[4] = 0;
         __threadfence_system();
-        host_mapped[4] = seq;
+        slot[0] = (uint32_t)total;
+        slot[1] = (uint32_t)(total >> 32);
+        slot[2] = (uint32_t)part[0];
+        slot[3] = (uint32_t)(part[0] >> 32);
+        __threadfence_system();
+        slot[4] = seq;
     }
 }
 

@@ -9,6 +9,8 @@
 // tests/test_span_wave_cpu.py compares the stream with the oracle's.  Never
 // linked into the product library.
 #include <stdint.h>
+#include <stdio.h>
+#include <string>
 #include <string.h>
 
 #include <vector>
@@ -278,4 +280,141 @@ extern "C" uint32_t span_wave_compress(const uint8_t *src, uint32_t n,
     if (st.next_emit < n)
         d = tiny_put_literal(o, d, st.next_emit, n - st.next_emit);
     return o.bad ? 0x80000001u : d;
+}
+
+// Differential check of the two walks on RANDOM per-lane results (not only the
+// ones real data produces): wherever the fast walk may run, its inserted
+// lanes, its tokens and the state it leaves must be the exact walk's.  Returns
+// 0, or the number of the first case that differs.
+// seen[0..3]: windows compared, with a cut, ending in a long match, ending
+// in a run.
+extern "C" uint32_t span_walk_diff(uint32_t seed, uint32_t cases,
+                                   uint64_t *seen)
+{
+    uint64_t x = seed * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+    auto rnd = [&]() {
+        x ^= x << 13;
+        x ^= x >> 7;
+        x ^= x << 17;
+        return x;
+    };
+    for (uint32_t c = 1; c <= cases; c++) {
+        Lanes ln;
+        const uint32_t base = 1000 + (uint32_t)(rnd() % 30000);
+        const uint32_t n = 65536, s_limit = n - 15;
+        SpanState st{base, (uint32_t)(rnd() % 20), (uint32_t)(rnd() & 1), 0};
+        if (st.chain)
+            st.q = 0;
+        st.next_emit = base - (uint32_t)(rnd() % 50) - (st.chain ? 0 : st.q);
+        const uint32_t lo = base - st.chain;
+        uint64_t hits = 0, cbits = 0;
+        const uint32_t density = 1 + (uint32_t)(rnd() % 6);   // hits per 8
+        const uint32_t cdens = (uint32_t)(rnd() % 12);        // C bits per 64
+        for (uint32_t l = 0; l < 64; l++) {
+            ln.mv[l] = 0;
+            ln.ov[l] = (uint32_t)(rnd() % (lo - 1)); // a position in front
+            const bool active = l ? true : st.chain != 0;
+            if (!active)
+                continue;
+            if (l && rnd() % 8 < density) {
+                const uint32_t r = (uint32_t)(rnd() % 16);
+                ln.mv[l] = r < 11 ? 4 + r % 8 : (r < 14 ? 12 + r % 4 : 16);
+                hits |= 1ull << l;
+            } else {
+                ln.mv[l] = (uint32_t)(rnd() % 4);
+            }
+            const uint32_t first = st.chain ? 0 : 1;
+            if (l > first && rnd() % 64 < cdens) { // a pred in the window
+                const uint32_t p = first + (uint32_t)(rnd() % (l - first));
+                ln.ov[l] = base - 1 + p;
+                cbits |= 1ull << l;
+            }
+        }
+        if (!span_fast_ok(st, hits, n))
+            continue;
+        // exact walk
+        SpanState sa = st;
+        Sink ka;
+        uint64_t Ta = 0;
+        uint32_t ata = 0;
+        const uint32_t ra =
+            span_walk(sa, hits, cbits, s_limit, ln, ka, Ta, ata);
+        // fast walk, as the kernel drives it
+        SpanState sb = st;
+        Sink kb;
+        uint64_t longs = 0;
+        for (uint32_t l = 1; l < 64; l++)
+            if (((hits >> l) & 1) && ln.mv[l] >= 16)
+                longs |= 1ull << l;
+        SpanFast f;
+        span_fast_walk(hits, longs, ln, f);
+        uint64_t vh, Tb;
+        span_fast_masks(f, hits, st.chain, 64, vh, Tb);
+        uint32_t cut = 64;
+        for (uint32_t l = 0; l < 64; l++) {
+            const uint32_t pred = ln.ov[l] - (base - 1);
+            if (((Tb >> l) & 1) && ((cbits >> l) & 1) &&
+                !((Tb >> (pred & 63)) & 1)) {
+                cut = l;
+                break;
+            }
+        }
+        if (cut < 64)
+            span_fast_masks(f, hits, st.chain, cut, vh, Tb);
+        for (uint32_t l = 1; l < 64; l++) {
+            if (!((vh >> l) & 1))
+                continue;
+            uint32_t lit, rank;
+            span_fast_token(l, base, st.next_emit, f.inside, vh, lit, rank);
+            if (rank != kb.t.size())
+                return c;
+            kb.token(lit, ln.mv[l], base - 1 + l - ln.ov[l]);
+        }
+        uint32_t emit = st.next_emit;
+        const uint32_t rb = span_fast_state(sb, f, cut, emit);
+#ifdef SPAN_DIFF_DEBUG
+        if (ra != rb || Ta != Tb || ka.t.size() != kb.t.size() ||
+            sa.s != sb.s || sa.next_emit != sb.next_emit ||
+            (ra != kSpanLong && (sa.chain != sb.chain ||
+                                 (!sa.chain && sa.q != sb.q)))) {
+            fprintf(stderr,
+                    "case %u base %u st(q %u chain %u emit %u) hits %016llx "
+                    "cbits %016llx\n ra %u rb %u Ta %016llx Tb %016llx ntok "
+                    "%zu %zu cut %u kind %u at %u end %u\n sa(s %u q %u c %u "
+                    "e %u) sb(s %u q %u c %u e %u)\n",
+                    c, base, st.q, st.chain, st.next_emit,
+                    (unsigned long long)hits, (unsigned long long)cbits, ra,
+                    rb, (unsigned long long)Ta, (unsigned long long)Tb,
+                    ka.t.size(), kb.t.size(), cut, f.kind, f.at, f.end, sa.s,
+                    sa.q, sa.chain, sa.next_emit, sb.s, sb.q, sb.chain,
+                    sb.next_emit);
+            for (uint32_t l = 0; l < 64; l++)
+                fprintf(stderr, "%u:m%u%s ", l, ln.mv[l],
+                        ((cbits >> l) & 1)
+                            ? (" p" + std::to_string(ln.ov[l] - (base - 1)))
+                                  .c_str()
+                            : "");
+            fprintf(stderr, "\n");
+        }
+#endif
+        if (ra != rb || Ta != Tb || ka.t.size() != kb.t.size())
+            return c;
+        for (size_t i = 0; i < ka.t.size(); i++)
+            if (ka.t[i].lit != kb.t[i].lit || ka.t[i].len != kb.t[i].len ||
+                ka.t[i].off != kb.t[i].off)
+                return c;
+        if (ra == kSpanLong && ata != f.at)
+            return c;
+        if (sa.s != sb.s || sa.next_emit != sb.next_emit)
+            return c;
+        seen[0]++;
+        seen[1] += cut < 64;
+        seen[2] += ra == kSpanLong;
+        seen[3] += cut == 64 && f.kind == kFastRun;
+        // (q only means something while no chain check is pending)
+        if (ra != kSpanLong &&
+            (sa.chain != sb.chain || (!sa.chain && sa.q != sb.q)))
+            return c;
+    }
+    return 0;
 }

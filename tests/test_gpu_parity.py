@@ -714,7 +714,7 @@ def test_snappy_c_api_from_many_threads(ctx):
 
 def test_lane_table_placement_stays_within_its_budget(built):
     """The GPU may be shared: while the placement of the lane tables is being
-    chosen (lane_table_tries candidates, three regions alive at a time) the
+    chosen (up to lane_table_tries candidates, three regions alive at a time) the
     context never holds more than lane_table_budget_pct of the memory that
     was free (snapmi.h).  A chip-filling launch (16 384 lanes or more) with a
     10 % budget; the bytes are the oracle's as ever."""
@@ -732,7 +732,9 @@ def test_lane_table_placement_stays_within_its_budget(built):
     log = _lib.load().snapmi_table_probe_log(c._h).decode()
     m = re.search(r"((?:[0-9.]+ ?)+)\| held at most (\d+) of budget (\d+)", log)
     assert m, log
-    assert len(m.group(1).split()) == 4                   # four candidates timed
+    # at most four candidates timed; the search stops early once three of
+    # them agree within 2 % (nothing left to choose between)
+    assert 3 <= len(m.group(1).split()) <= 4, log
     held, budget = int(m.group(2)), int(m.group(3))
     assert 0 < held <= budget <= 0.10 * free1 + (1 << 20), (held, budget, free1)
     for i in (0, 39, 16499):

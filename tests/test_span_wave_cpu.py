@@ -92,3 +92,25 @@ def test_span_steps_phrases_with_noise(span):
         data = bytes(buf[:n])
         got, _ = span(data)
         assert got == O.compress(data), (n, data[:24].hex())
+
+
+def test_fast_walk_equals_the_exact_walk_on_random_windows(tmp_path):
+    """span_fast_* against span_walk on random per-lane results - hit
+    densities from sparse to every lane, match lengths of every class, C bits
+    with preds anywhere below, chain / run starts: inserted lanes, tokens and
+    the state left behind must be identical wherever the fast walk may run."""
+    so = tmp_path / "span_wave_host.so"
+    subprocess.check_call(
+        ["g++", "-O2", "-shared", "-fPIC", "-std=c++17",
+         "-I", str(ROOT / "rust-snappy_amd" / "csrc"),
+         str(ROOT / "tests" / "span_wave_host.cpp"), "-o", str(so)])
+    L = C.CDLL(str(so))
+    L.span_walk_diff.restype = C.c_uint32
+    L.span_walk_diff.argtypes = [C.c_uint32, C.c_uint32,
+                                 C.POINTER(C.c_uint64)]
+    seen = (C.c_uint64 * 4)()
+    for seed in range(1, 9):
+        assert L.span_walk_diff(seed, 200000, seen) == 0, seed
+    windows, cuts, longs, runs = list(seen)
+    assert windows > 500000 and cuts > 50000 and longs > 50000 \
+        and runs > 5000, list(seen)
