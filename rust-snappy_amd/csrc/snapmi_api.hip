@@ -1272,9 +1272,8 @@ int snapmi_decompress_stream(snapmi_ctx *ctx, const void *d_in,
 
     hipLaunchKernelGGL(k_stream_head, dim3(1), dim3(1), 0, s, a);
     STREAM_CHECK(k_stream_head);
-    hipLaunchKernelGGL(k_stream_scan,
-                       dim3((a.nseg + kWave / kEntry - 1) / (kWave / kEntry)),
-                       dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_stream_scan, dim3((a.nseg + kWave - 1) / kWave),
+                       dim3(64), 0, s, a); // 64 segments per wavefront
     STREAM_CHECK(k_stream_scan);
     hipLaunchKernelGGL(k_stream_super, dim3(a.nsuper), dim3(kEntry), 0, s, a);
     STREAM_CHECK(k_stream_super);
@@ -1289,8 +1288,8 @@ int snapmi_decompress_stream(snapmi_ctx *ctx, const void *d_in,
     hipLaunchKernelGGL(k_stream_spread2, dim3((a.nsuper + 63) / 64), dim3(64),
                        0, s, a);
     STREAM_CHECK(k_stream_spread2);
-    hipLaunchKernelGGL(k_stream_cuts, dim3((a.nseg + 63) / 64), dim3(64), 0,
-                       s, a);
+    hipLaunchKernelGGL(k_stream_cuts, dim3((a.nseg + kCutSegs - 1) / kCutSegs),
+                       dim3(64), 0, s, a);
     STREAM_CHECK(k_stream_cuts);
     hipLaunchKernelGGL(k_stream_pieces, dim3((a.kmax + 255) / 256), dim3(256),
                        0, s, a);
@@ -1416,8 +1415,8 @@ constexpr size_t kPinStage = 8u << 20;
 // launches of the hierarchical scan cost ~0.5 ms; a single wavefront decodes
 // 100-250 MB/s: measured per bench input at 16 KiB and at 256 KiB
 // (profiles/r4_scalar_latency.txt: the test build reads SNAPMI_LONG_STREAM),
-// the scan pays from ~150 KB of compressed input on (lcet10.txt 3.6 -> 2.2
-// ms) and costs below (html 0.62 -> 1.07 ms)
+// the scan pays from ~150 KB of compressed input on (lcet10.txt 3.6 -> 2.0
+// ms) and costs below (html 0.61 -> 0.89 ms, fireworks.jpeg 0.14 -> 0.50)
 static const size_t kLongStream = [] {
 #ifdef SNAPMI_TESTING
     if (const char *e = getenv("SNAPMI_LONG_STREAM"))
@@ -1457,8 +1456,8 @@ int run_one(snapmi_ctx *ctx, bool compress, const uint8_t *input,
     // Device output buffer: what the kernels may write.  For compression the
     // reference demands max_compress_len (checked on the device as well).
     size_t dev_out = output_cap;
+    size_t dl = 0; // decompress: the length the header announces
     if (!compress) {
-        size_t dl = 0;
         snapmi_error he;
         if (input_len && snapmi_decompress_len(input, input_len, &dl, &he) ==
                              SNAPMI_OK &&
@@ -1506,9 +1505,12 @@ int run_one(snapmi_ctx *ctx, bool compress, const uint8_t *input,
         rc = snapmi_compress_batch(ctx, &d->in_ptr, &d->in_len, &hl,
                                    &d->out_ptr, &d->out_cap, &d->out_len,
                                    &d->err, 1);
-    } else if (input_len >= kLongStream) {
-        // one wavefront decodes ~50 MB/s: long streams go through the
-        // parallel single-stream path
+    } else if (input_len >= kLongStream ||
+               (input_len >= kLongStream / 2 && dl >= 4 * (size_t)kStreamChunk)) {
+        // one wavefront decodes ~140 MB/s: long streams go through the
+        // parallel single-stream path - and so do half as long ones that
+        // announce four pieces of output or more (html x4: 2.20 -> 1.23 ms;
+        // profiles/r4_scalar_latency.txt)
         rc = snapmi_decompress_stream(ctx, ctx->st_in.p, input_len,
                                       ctx->st_out.p, output_cap, &d->out_len,
                                       &d->err);

@@ -2020,40 +2020,444 @@ __global__ void k_stream_head(StreamArgs a)
     a.meta[3] = (dlen + kStreamChunk - 1) / kStreamChunk;
 }
 
+// ---------------------------------------------------------------------
+// k_stream_scan: the level-1 table, (exit, produced) for the kEntry entry
+// offsets of every 4 KiB segment.
+//
+// Rounds 1-3 gave every (segment, entry) its own lane and let it hop through
+// HBM: ~45 instructions and one dependent load per element, and the eight
+// chains of a segment are ONE chain after a few elements - seven eighths of
+// the hops were duplicates (8.1 ms of the 14.2 ms of a 2 GiB stream).  Now:
+//   * the hop is two LDS reads and ~65 straight-line instructions: the tag
+//     from the lane's window of the input (a ring of kHopLines lines; up to
+//     kHopFetch lines are fetched WHILE the lanes hop through the ones that
+//     are there - the round structure of k_match_blocks), then (encoded
+//     bytes, produced bytes) from a 256-entry table of tags.  Literals with
+//     length bytes - one per 64 KiB of incompressible data - are done between
+//     the rounds;
+//   * a wavefront owns 64 segments.  Phase A walks all 8 x 64 entries for
+//     kHopMid bytes only; phase B walks ONE trunk per segment from where
+//     entry 0 stood after phase A - entries that stood at the same place are
+//     the trunk plus what they had produced - and the chains that had not
+//     joined (chains through the bytes of a long literal never meet);
+//   * a walk that leaves its segment off the landing zone goes on through
+//     the next one - but kHopMid bytes into it, it stands as a rule where
+//     that segment's own trunk started, and is that trunk from there on;
+//   * walks are handed out lane by lane from a pool, so a lane that is done
+//     takes the next walk instead of waiting for the longest.
+// Positions are 32-bit offsets from the wavefront's first segment; a chain
+// that a literal of a GiB takes out of that range finishes in the 64-bit
+// loop of the old kernel (elem_step, through HBM).
+// Measured (one 2 GiB stream, profiles/r4_stream_scan_steps.txt): 8.07 ms ->
+// 3.3 ms; a wavefront is bound by the latency of its own dependent chain
+// (~630 cycles per round of hops, alone on the chip or not), the lanes of a
+// round are busy to ~55 %.
+// ---------------------------------------------------------------------
+#ifndef SNAPMI_HOP_LINE
+#define SNAPMI_HOP_LINE 32
+#endif
+#ifndef SNAPMI_HOP_ITERS
+#define SNAPMI_HOP_ITERS 12
+#endif
+constexpr uint32_t kHopLine = SNAPMI_HOP_LINE; // bytes of a line
+constexpr uint32_t kHopLines = 4;              // lines of a lane's ring
+constexpr uint32_t kHopFetch = 2;              // lines fetched per round
+// hops per round: a lane whose elements are larger than kHopFetch * kHopLine
+// / kHopIters bytes on average runs out of window before the round is over
+constexpr uint32_t kHopIters = SNAPMI_HOP_ITERS;
+constexpr uint32_t kHopMid = 128;               // phase A walks this far
+constexpr uint32_t kHopFar = 1u << 30;
+constexpr uint32_t kHopNone = 0xFFFFFFFFu;
+
+struct HopShared {
+    l_u32 *win;  // [kHopLines * kHopLine / 4][64]: dword r of lane l at win[r * 64 + l]
+    l_u16x *lut; // [256] encoded bytes | produced << 8; 0 = length bytes follow
+    gcptr in;    // the stream
+    uint64_t in_len;
+    uint64_t wbase;  // stream offset of the wavefront's first segment
+    uint32_t mis;    // (in + wbase) mod kHopLine: the window's lines are aligned
+    uint32_t lastR;  // end of the stream from wbase, at most 2^31
+    uint64_t lastP;  // the same + mis, exact
+};
+
+// one lane's walk
+struct Hopper {
+    uint32_t L0, nl;   // lines L0 .. L0 + nl - 1 of the aligned view are in the window
+    uint32_t R;        // position from wbase
+    uint32_t out;      // produced
+    uint32_t over;     // elements hopped behind the segment's end
+    uint32_t endR;     // the segment's end (or the stream's)
+    uint32_t stopR;    // phase A pauses at the first element start here
+    uint32_t stopOut;  // k_stream_cuts: ... at the first one that has produced this
+    bool run;          // hopping
+    bool slow;         // stands in front of a literal with length bytes
+    bool fail;         // the chain cannot be followed
+    bool punt;         // left the 32-bit range: p64 / out64 are its end
+    uint64_t p64, out64;
+
+    // (the loop condition of rounds 1-3: the exit is the first element start
+    // at or behind the segment's end that lies within kEntry bytes of a
+    // segment boundary, or the end of the stream)
+    __device__ __forceinline__ bool more(const HopShared &h) const
+    {
+        return R < h.lastR && (R < endR || (R & (kSeg - 1)) >= kEntry);
+    }
+    __device__ __forceinline__ void start(const HopShared &h, uint32_t r,
+                                          uint32_t o, uint32_t e, uint32_t st,
+                                          bool valid)
+    {
+        L0 = 0; nl = 0; R = r; out = o; over = 0; endR = e; stopR = st;
+        stopOut = kHopNone;
+        slow = false; punt = false; p64 = 0; out64 = 0;
+        fail = !valid;
+        run = valid && more(h) && R < stopR;
+    }
+    // between rounds: the literal with length bytes the lane stands at
+    // (src/decompress.rs:213-232), its bytes through HBM
+    __device__ __forceinline__ void long_literal(const HopShared &h)
+    {
+        slow = false;
+        const uint64_t p = h.wbase + R;
+        const uint32_t tag = h.in[p];
+        const uint32_t nb = (tag >> 2) - 59;
+        if (p + 1 + nb > h.in_len) {
+            fail = true;
+            return;
+        }
+        uint32_t v = 0;
+        for (uint32_t k = 0; k < nb; k++)
+            v |= (uint32_t)h.in[p + 1 + k] << (8 * k);
+        const uint64_t len = (uint64_t)v + 1;
+        if (h.in_len - (p + 1 + nb) < len) {
+            fail = true;
+            return;
+        }
+        if (len + R >= kHopFar) {
+            // out of the 32-bit range: the rest of the walk right here
+            uint64_t q = p + 1 + nb + len, qo = (uint64_t)out + len;
+            const uint64_t end = h.wbase + endR;
+            bool ok = true;
+            while (ok && q < h.in_len &&
+                   (q < end || (q & (kSeg - 1)) >= kEntry)) {
+                if (q >= end && ++over > kScanOverrun) {
+                    ok = false;
+                    break;
+                }
+                ok = elem_step(h.in, h.in_len, q, qo);
+            }
+            punt = true;
+            fail = !ok;
+            p64 = q;
+            out64 = qo;
+            return;
+        }
+        R += 1 + nb + (uint32_t)len;
+        out += (uint32_t)len;
+        run = more(h) && R < stopR && out < stopOut;
+    }
+    __device__ __forceinline__ void result(const HopShared &h, uint64_t &p,
+                                           uint64_t &o) const
+    {
+        p = punt ? p64 : h.wbase + R;
+        o = punt ? out64 : (uint64_t)out;
+    }
+};
+
+// Rounds over a pool of `npool` walks: a lane without a walk takes the next
+// one (init(item, w)), hops while its window reaches, and hands the walk to
+// done(item, w) when it stands; done returns false to send it on (with a new
+// stopR).
+template <class INIT, class DONE>
+__device__ __forceinline__ void hop_pool(const HopShared &h, uint32_t npool,
+                                         INIT init, DONE done)
+{
+    typedef __attribute__((address_space(1))) u32x4 g_u32x4;
+    const uint32_t lane = threadIdx.x;
+    const l_u8 *const winb = (const l_u8 *)(h.win + lane);
+    uint32_t next = 0; // uniform: first walk not handed out
+    bool busy = false;
+    uint32_t item = 0;
+    Hopper w;
+    w.run = false;
+    w.slow = false;
+    w.nl = 0;
+    w.L0 = 0;
+    for (;;) {
+        if (busy && !w.run && !w.slow) { // this lane's walk stands
+            if (done(item, w)) // ... and is over
+                busy = false;
+        }
+        {
+            const uint64_t M = __ballot(!busy);
+            const uint32_t mine =
+                next + __builtin_amdgcn_mbcnt_hi(
+                           (uint32_t)(M >> 32),
+                           __builtin_amdgcn_mbcnt_lo((uint32_t)M, 0));
+            if (!busy && mine < npool) {
+                item = mine;
+                init(item, w);
+                busy = true;
+            }
+            next += (uint32_t)__builtin_popcountll(M);
+            if (next > npool)
+                next = npool;
+        }
+        if (__ballot(w.slow)) {
+            if (w.slow)
+                w.long_literal(h);
+        }
+        if (!__ballot(busy))
+            break;
+        // ---- one round: fetch up to kHopFetch lines behind the window ------
+        uint32_t want = 0, cnt = 0;
+        if (w.run) {
+            const uint32_t lp = (w.R + h.mis) / kHopLine;
+            if (w.nl != 0 && lp >= w.L0 && lp < w.L0 + w.nl) {
+                w.nl -= lp - w.L0; // the lines below are used up
+                w.L0 = lp;
+            } else {
+                w.L0 = lp; // nothing of use: the lane sits this round out
+                w.nl = 0;
+            }
+            want = w.L0 + w.nl;
+            cnt = kHopLines - w.nl < kHopFetch ? kHopLines - w.nl : kHopFetch;
+            // (a line that starts behind the stream's end is never fetched:
+            // the stream's last line may be the last of the allocation)
+            while (cnt && (uint64_t)(want + cnt - 1) * kHopLine >= h.lastP)
+                cnt--;
+        }
+        u32x4 f[kHopFetch * kHopLine / 16];
+#pragma unroll
+        for (uint32_t i = 0; i < kHopFetch * kHopLine / 16; i++)
+            f[i] = (u32x4){0, 0, 0, 0};
+        {
+            const g_u32x4 *g = (const g_u32x4 *)(h.in + h.wbase - h.mis +
+                                                 (uint64_t)want * kHopLine);
+#pragma unroll
+            for (uint32_t c = 0; c < kHopFetch; c++)
+                if (c < cnt) {
+#pragma unroll
+                    for (uint32_t i = 0; i < kHopLine / 16; i++)
+                        f[c * (kHopLine / 16) + i] = g[c * (kHopLine / 16) + i];
+                }
+        }
+        // ---- at most kHopIters hops through the lines that are there (LDS
+        // only: the fetch is in flight).  Straight-line code: a divergent
+        // region in this loop costs the scalar unit three instructions per
+        // flag it carries.
+        {
+            uint32_t R = w.R, out = w.out, over = w.over;
+            bool run = w.run, slow = false, fail = w.fail;
+            const uint32_t lo = w.L0 * kHopLine - h.mis, span = w.nl * kHopLine;
+            const uint32_t endR = w.endR, stopOut = w.stopOut;
+            const uint32_t capR = w.stopR < h.lastR ? w.stopR : h.lastR;
+            for (uint32_t it = 0; it < kHopIters; it++) {
+                const bool can = run && R - lo < span;
+                if (!__ballot(can))
+                    break;
+                const uint32_t x = (R + h.mis) & (kHopLines * kHopLine - 1);
+                const uint32_t tag = winb[((x & ~3u) << 6) + (x & 3)];
+                const uint32_t lv = h.lut[tag];
+                const uint32_t e = can ? lv : 0; // a lane that waits: no step
+                over += (can && R >= endR) ? 1u : 0u;
+                R += e & 0xFF;
+                out += e >> 8;
+                slow = slow || (can && lv == 0);
+                // (the element behind the limit is hopped, then the walk fails)
+                fail = fail || over > kScanOverrun || R > h.lastR;
+                run = run && !slow && !fail && R < capR && out < stopOut &&
+                      (R < endR || (R & (kSeg - kEntry)) != 0);
+            }
+            w.R = R;
+            w.out = out;
+            w.over = over;
+            w.run = run;
+            w.slow = slow;
+            w.fail = fail;
+        }
+        // ---- the fetched lines into the ring ------------------------------
+#pragma unroll
+        for (uint32_t c = 0; c < kHopFetch; c++)
+            if (c < cnt) {
+                l_u32 *dst = h.win +
+                             ((want + c) & (kHopLines - 1)) * (kHopLine / 4) * 64 +
+                             lane;
+#pragma unroll
+                for (uint32_t i = 0; i < kHopLine / 16; i++) {
+                    const u32x4 v = f[c * (kHopLine / 16) + i];
+                    dst[(4 * i + 0) * 64] = v.x;
+                    dst[(4 * i + 1) * 64] = v.y;
+                    dst[(4 * i + 2) * 64] = v.z;
+                    dst[(4 * i + 3) * 64] = v.w;
+                }
+            }
+        w.nl += cnt;
+    }
+}
+
+// the table of tags: encoded bytes | produced bytes << 8, 0 for a literal
+// with length bytes
+__device__ __forceinline__ void hop_lut(uint16_t *lutbuf)
+{
+    for (uint32_t t = threadIdx.x; t < 256; t += 64) {
+        const uint32_t type = t & 3, n6 = t >> 2;
+        uint32_t enc, prod;
+        if (type == 0) {
+            enc = n6 < 60 ? n6 + 2 : 0;
+            prod = n6 < 60 ? n6 + 1 : 0;
+        } else {
+            enc = type == 1 ? 2 : (type == 2 ? 3 : 5);
+            prod = type == 1 ? 4 + (n6 & 7) : 1 + n6;
+        }
+        lutbuf[t] = (uint16_t)(enc | (prod << 8));
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(64) void k_stream_scan(StreamArgs a)
 {
+    __shared__ uint32_t winbuf[kHopLines * (kHopLine / 4) * 64];
+    __shared__ uint16_t lutbuf[256];
+    __shared__ uint32_t midR[64 * kEntry], midO[64 * kEntry];
+    __shared__ uint16_t todo[64 * kEntry];
+    __shared__ unsigned long long trunkP[64], trunkO[64];
+    __shared__ uint32_t todoO[64 * (kEntry - 1)];
+    __shared__ uint8_t trunkL[64], todoL[64 * (kEntry - 1)];
     if (a.meta[2])
         return;
-    // kWave / kEntry segments per wavefront, kEntry entry offsets each
-    const uint64_t seg = (uint64_t)blockIdx.x * (kWave / kEntry) +
-                         threadIdx.x / kEntry;
-    const uint32_t o = threadIdx.x % kEntry;
-    if (seg >= a.nseg)
-        return;
-    uint64_t p = seg * kSeg + o, out = 0;
-    uint64_t end = (seg + 1) * kSeg;
-    if (end > a.in_len)
-        end = a.in_len;
-    bool ok = p < a.in_len;
-    // The exit is the first element start at or behind the segment's end
-    // that lies within kEntry bytes of a segment boundary (or the end of the
-    // stream): whoever follows the tables therefore always lands on a
-    // tabulated offset, also behind a long element, and never has to hop
-    // through elements itself.
-    // The walk past the segment's end is bounded (a crafted stream whose
-    // elements all end off the landing zone would otherwise make every
-    // thread walk to the end of the input): after kScanOverrun elements the
-    // entry is left as "cannot follow", and whoever needs it sets meta[2] -
-    // the sequential decoder then owns the stream.
-    uint32_t over = 0; // elements hopped behind the segment's end
-    while (ok && p < a.in_len && (p < end || (p & (kSeg - 1)) >= kEntry)) {
-        if (p >= end && ++over > kScanOverrun) {
-            ok = false;
-            break;
-        }
-        ok = elem_step((gcptr)a.in, a.in_len, p, out);
+    const uint32_t lane = threadIdx.x;
+    HopShared h;
+    h.win = (l_u32 *)winbuf;
+    h.lut = (l_u16x *)lutbuf;
+    h.in = (gcptr)a.in;
+    h.in_len = a.in_len;
+    const uint64_t seg0 = (uint64_t)blockIdx.x * 64;
+    h.wbase = seg0 * kSeg;
+    h.mis = (uint32_t)((uintptr_t)a.in + h.wbase) & (kHopLine - 1);
+    const uint64_t left = a.in_len - h.wbase; // > 0: the grid covers nseg
+    h.lastR = left < (1ull << 31) ? (uint32_t)left : 1u << 31;
+    h.lastP = left + h.mis;
+    const uint32_t nloc =
+        a.nseg - seg0 < 64 ? (uint32_t)(a.nseg - seg0) : 64u; // segments here
+    hop_lut(lutbuf);
+    su64x2 *const table = level_table<1>(a) + seg0 * kEntry;
+    const uint32_t lastR = h.lastR;
+    auto seg_end = [lastR](uint32_t sl) {
+        return (sl + 1) * kSeg < lastR ? (sl + 1) * kSeg : lastR;
+    };
+
+    // ---- phase A: every entry, kHopMid bytes far --------------------------
+    hop_pool(
+        h, nloc * kEntry,
+        [&](uint32_t it, Hopper &w) {
+            const uint32_t sl = it / kEntry, r0 = sl * kSeg + it % kEntry;
+            w.start(h, r0, 0, seg_end(sl), sl * kSeg + kHopMid, r0 < lastR);
+        },
+        [&](uint32_t it, Hopper &w) {
+            const bool paused = !w.fail && !w.punt && w.more(h);
+            midR[it] = paused ? w.R : kHopNone;
+            midO[it] = w.out;
+            if (!paused) { // the chain is over, or cannot be followed
+                uint64_t p, o;
+                w.result(h, p, o);
+                table[it] = (su64x2){w.fail ? kNone : p, o};
+            }
+            return true;
+        });
+    __syncthreads();
+
+    // ---- the chains that stand elsewhere than their segment's entry 0 -----
+    uint32_t ntodo = 0;
+    for (uint32_t o = 1; o < kEntry; o++) {
+        const uint32_t it = lane * kEntry + o;
+        const uint32_t r = lane < nloc ? midR[it] : kHopNone;
+        const bool own = r != kHopNone && r != midR[lane * kEntry];
+        const uint64_t M = __ballot(own);
+        if (own)
+            todo[ntodo + __builtin_amdgcn_mbcnt_hi(
+                             (uint32_t)(M >> 32),
+                             __builtin_amdgcn_mbcnt_lo((uint32_t)M, 0))] =
+                (uint16_t)it;
+        ntodo += (uint32_t)__builtin_popcountll(M);
     }
-    level_table<1>(a)[seg * kEntry + o] = (su64x2){ok ? p : kNone, out};
+    __syncthreads();
+
+    // ---- phase B: one trunk per segment, and those ------------------------
+    // A walk that leaves its segment off the landing zone goes on through the
+    // next one (30 % of the trunks on text, and again with the same odds: the
+    // longest of 64 walks was 4 600 hops where the average is 1 190) - but
+    // kHopMid bytes into that segment it stands, as a rule, where that
+    // segment's own trunk started: then it IS that trunk from there on, and
+    // its result is a sum.  Links go to higher segments only; they are
+    // resolved from the last segment down.
+    for (uint32_t i = lane; i < 64; i += 64)
+        trunkL[i] = 0xFF;
+    auto next_stop = [nloc](uint32_t sl) {
+        return sl + 1 < nloc ? (sl + 1) * kSeg + kHopMid : kHopNone;
+    };
+    hop_pool(
+        h, nloc + ntodo,
+        [&](uint32_t it, Hopper &w) {
+            // (the last segment's trunk first: it has nobody to join)
+            const uint32_t e =
+                it < nloc ? (nloc - 1 - it) * kEntry : todo[it - nloc];
+            const uint32_t r = midR[e];
+            // (a trunk counts from 0: its entries add what they had)
+            w.start(h, r, it < nloc ? 0 : midO[e], seg_end(e / kEntry),
+                    next_stop(e / kEntry), r != kHopNone);
+        },
+        [&](uint32_t it, Hopper &w) {
+            uint32_t link = 0xFF;
+            if (!w.fail && !w.punt && w.more(h)) { // stands at a stop
+                const uint32_t t = w.R / kSeg;
+                if (t < nloc && midR[t * kEntry] == w.R) {
+                    link = t;
+                } else {
+                    w.stopR = next_stop(t);
+                    w.run = true;
+                    return false;
+                }
+            }
+            uint64_t p, o;
+            w.result(h, p, o);
+            if (it < nloc) {
+                const uint32_t sl = nloc - 1 - it;
+                trunkP[sl] = w.fail ? kNone : p;
+                trunkO[sl] = o;
+                trunkL[sl] = (uint8_t)link;
+            } else if (link == 0xFF) {
+                table[todo[it - nloc]] = (su64x2){w.fail ? kNone : p, o};
+            } else {
+                todoO[it - nloc] = w.out;
+            }
+            if (it >= nloc)
+                todoL[it - nloc] = (uint8_t)link;
+            return true;
+        });
+    __syncthreads();
+    if (lane == 0) {
+        for (uint32_t sl = nloc; sl-- > 0;) {
+            const uint32_t t = trunkL[sl];
+            if (t != 0xFF) {
+                trunkP[sl] = trunkP[t];
+                trunkO[sl] += trunkO[t];
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = lane; i < ntodo; i += 64) {
+        const uint32_t t = todoL[i];
+        if (t != 0xFF)
+            table[todo[i]] = (su64x2){trunkP[t], todoO[i] + trunkO[t]};
+    }
+    if (lane < nloc) {
+        const uint32_t t0 = midR[lane * kEntry];
+        for (uint32_t o = 0; o < kEntry; o++) {
+            const uint32_t it = lane * kEntry + o;
+            if (t0 != kHopNone && midR[it] == t0)
+                table[it] = (su64x2){trunkP[lane], trunkO[lane] + midO[it]};
+        }
+    }
 }
 __global__ __launch_bounds__(kEntry) void k_stream_super(StreamArgs a)
 {
@@ -2089,47 +2493,109 @@ __global__ void k_stream_spread2(StreamArgs a)
     spread_level<2>(a);
 }
 
-// one lane per segment the chain enters: the element boundary at (or first
-// after) every 64 KiB of output that falls into its hop
-__global__ void k_stream_cuts(StreamArgs a)
+// The element boundary at (or first behind) every 64 KiB of output: the
+// segments whose stretch of the chain holds such a boundary are collected -
+// kCutSegs segments per wavefront, one in eight on text - and walked from
+// where the chain enters them by the pool of k_stream_scan (windows in LDS),
+// a lane per segment, standing at every boundary on the way.  (Rounds 1-3:
+// one lane per segment hopping through HBM, the wavefront as slow as its
+// slowest lane: 1.7 ms of a 2 GiB stream.)
+__global__ __launch_bounds__(64) void k_stream_cuts(StreamArgs a)
 {
+    __shared__ uint32_t winbuf[kHopLines * (kHopLine / 4) * 64];
+    __shared__ uint16_t lutbuf[256];
+    __shared__ uint16_t todo[kCutSegs];
     if (a.meta[2])
         return;
-    const uint64_t seg = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (seg == 0) {
+    const uint32_t lane = threadIdx.x;
+    const uint64_t seg0 = (uint64_t)blockIdx.x * kCutSegs;
+    if (seg0 == 0 && lane == 0) {
         const uint64_t K = a.meta[3];
         a.cuts[0] = a.meta[0];
         a.cuts[1] = 0;
         a.cuts[K * 2] = a.in_len;
         a.cuts[K * 2 + 1] = a.meta[1];
     }
-    if (seg * kSeg >= a.in_len)
-        return;
-    const su64x2 e = level_entry<1>(a)[seg];
-    if (e.x == kNone)
-        return;
-    const uint64_t p = e.x, out = e.y;
-    uint64_t np = p, nout = out;
-    if (!reach_end<1>(a, np, nout)) {
-        a.meta[2] = 1;
-        return;
-    }
-    // piece boundaries T = k * 64 KiB with out < T <= nout
-    uint64_t k = out / kStreamChunk + 1;
-    uint64_t q = p, qo = out;
-    while (k * kStreamChunk <= nout && k * kStreamChunk < a.meta[1]) {
-        while (qo < k * kStreamChunk)
-            if (!elem_step((gcptr)a.in, a.in_len, q, qo)) {
-                a.meta[2] = 1;
-                return;
+    HopShared h;
+    h.win = (l_u32 *)winbuf;
+    h.lut = (l_u16x *)lutbuf;
+    h.in = (gcptr)a.in;
+    h.in_len = a.in_len;
+    h.wbase = seg0 * kSeg;
+    h.mis = (uint32_t)((uintptr_t)a.in + h.wbase) & (kHopLine - 1);
+    const uint64_t left = a.in_len - h.wbase;
+    h.lastR = left < (1ull << 31) ? (uint32_t)left : 1u << 31;
+    h.lastP = left + h.mis;
+    hop_lut(lutbuf);
+    const uint64_t dlen = a.meta[1];
+    // ---- the segments with a boundary in their stretch --------------------
+    uint32_t ntodo = 0;
+    for (uint32_t j = 0; j < kCutSegs; j += 64) {
+        const uint64_t seg = seg0 + j + lane;
+        bool has = false;
+        if (seg * kSeg < a.in_len) {
+            const su64x2 e = level_entry<1>(a)[seg];
+            if (e.x != kNone) {
+                uint64_t np = e.x, nout = e.y;
+                if (!reach_end<1>(a, np, nout)) {
+                    a.meta[2] = 1;
+                } else {
+                    const uint64_t t = (e.y / kStreamChunk + 1) * kStreamChunk;
+                    has = t <= nout && t < dlen;
+                }
             }
-        // (a long element can cover several boundaries)
-        while (k * kStreamChunk <= qo && k * kStreamChunk < a.meta[1]) {
-            a.cuts[k * 2] = q;
-            a.cuts[k * 2 + 1] = qo;
-            k++;
         }
+        const uint64_t M = __ballot(has);
+        if (has)
+            todo[ntodo + __builtin_amdgcn_mbcnt_hi(
+                             (uint32_t)(M >> 32),
+                             __builtin_amdgcn_mbcnt_lo((uint32_t)M, 0))] =
+                (uint16_t)(j + lane);
+        ntodo += (uint32_t)__builtin_popcountll(M);
     }
+    __syncthreads();
+    // ---- walk them: a stop at every boundary ------------------------------
+    uint64_t out0 = 0, nout = 0, k = 0; // of this lane's walk
+    const uint32_t lastR = h.lastR;
+    hop_pool(
+        h, ntodo,
+        [&](uint32_t it, Hopper &w) {
+            const uint32_t sl = todo[it];
+            const su64x2 e = level_entry<1>(a)[seg0 + sl];
+            uint64_t np = e.x;
+            out0 = e.y;
+            nout = e.y;
+            reach_end<1>(a, np, nout); // (true: it was, above)
+            k = out0 / kStreamChunk + 1;
+            const uint32_t endR =
+                (sl + 1) * kSeg < lastR ? (sl + 1) * kSeg : lastR;
+            w.start(h, (uint32_t)(e.x - h.wbase), 0, endR, kHopNone, true);
+            w.stopOut = (uint32_t)(k * kStreamChunk - out0);
+            w.run = w.run && w.out < w.stopOut;
+        },
+        [&](uint32_t it, Hopper &w) {
+            const uint64_t qo = out0 + w.out;
+            if (w.fail || w.punt || qo < k * kStreamChunk) {
+                // cannot be followed here (or a literal of a GiB): the
+                // sequential decoder owns the stream
+                a.meta[2] = 1;
+                return true;
+            }
+            // (a long element can cover several boundaries)
+            while (k * kStreamChunk <= qo && k * kStreamChunk < dlen) {
+                a.cuts[k * 2] = h.wbase + w.R;
+                a.cuts[k * 2 + 1] = qo;
+                k++;
+            }
+            if (k * kStreamChunk <= nout && k * kStreamChunk < dlen) {
+                w.stopOut = (uint32_t)(k * kStreamChunk - out0);
+                w.run = w.more(h);
+                if (w.run)
+                    return false;
+                a.meta[2] = 1; // (the stretch ends before its last boundary)
+            }
+            return true;
+        });
 }
 
 __global__ void k_stream_pieces(StreamArgs a)

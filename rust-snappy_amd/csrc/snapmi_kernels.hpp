@@ -125,6 +125,7 @@ constexpr uint32_t kSeg = 4096;           // bytes of compressed input
 // the landing zone and costs one more segment of hops: rare next to the 8x.
 constexpr uint32_t kEntry = 8;
 constexpr uint32_t kSegPerSuper = 64;
+constexpr uint32_t kCutSegs = 512;       // segments per wavefront of k_stream_cuts
 constexpr uint32_t kStreamChunk = 65536;  // output bytes per piece: the
                                           // encoders' block size, so pieces
                                           // of their streams are independent
