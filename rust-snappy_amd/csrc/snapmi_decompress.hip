@@ -2028,7 +2028,7 @@ __global__ void k_stream_head(StreamArgs a)
 // HBM: ~45 instructions and one dependent load per element, and the eight
 // chains of a segment are ONE chain after a few elements - seven eighths of
 // the hops were duplicates (8.1 ms of the 14.2 ms of a 2 GiB stream).  Now:
-//   * the hop is two LDS reads and ~65 straight-line instructions: the tag
+//   * the hop is two LDS reads and ~42 straight-line instructions: the tag
 //     from the lane's window of the input (a ring of kHopLines lines; up to
 //     kHopFetch lines are fetched WHILE the lanes hop through the ones that
 //     are there - the round structure of k_match_blocks), then (encoded
@@ -2049,9 +2049,8 @@ __global__ void k_stream_head(StreamArgs a)
 // that a literal of a GiB takes out of that range finishes in the 64-bit
 // loop of the old kernel (elem_step, through HBM).
 // Measured (one 2 GiB stream, profiles/r4_stream_scan_steps.txt): 8.07 ms ->
-// 3.3 ms; a wavefront is bound by the latency of its own dependent chain
-// (~630 cycles per round of hops, alone on the chip or not), the lanes of a
-// round are busy to ~55 %.
+// 2.0 ms; a wavefront is bound by the latency of its own dependent chain
+// (alone on the chip or not), the lanes of a round are busy to ~55 %.
 // ---------------------------------------------------------------------
 #ifndef SNAPMI_HOP_LINE
 #define SNAPMI_HOP_LINE 32
@@ -2251,22 +2250,38 @@ __device__ __forceinline__ void hop_pool(const HopShared &h, uint32_t npool,
             const uint32_t lo = w.L0 * kHopLine - h.mis, span = w.nl * kHopLine;
             const uint32_t endR = w.endR, stopOut = w.stopOut;
             const uint32_t capR = w.stopR < h.lastR ? w.stopR : h.lastR;
-            for (uint32_t it = 0; it < kHopIters; it++) {
-                const bool can = run && R - lo < span;
-                if (!__ballot(can))
+#ifndef SNAPMI_HOP_UNROLL
+#define SNAPMI_HOP_UNROLL SNAPMI_HOP_ITERS
+#endif
+            for (uint32_t it = 0; it < kHopIters; it += SNAPMI_HOP_UNROLL) {
+                // (one look at "can anyone hop" per SNAPMI_HOP_UNROLL hops - by
+                // default per round: a lane that cannot, idles through them.
+                // With a test and a branch per hop the compiler keeps the
+                // loop's flags in step with three scalar instructions each,
+                // 65 instructions per hop; unrolled it is 42, and the next
+                // tag is on its way while the flags of this one are computed:
+                // 3.39 -> 2.03 ms)
+                if (!__builtin_amdgcn_ballot_w64(run && R - lo < span))
                     break;
-                const uint32_t x = (R + h.mis) & (kHopLines * kHopLine - 1);
-                const uint32_t tag = winb[((x & ~3u) << 6) + (x & 3)];
-                const uint32_t lv = h.lut[tag];
-                const uint32_t e = can ? lv : 0; // a lane that waits: no step
-                over += (can && R >= endR) ? 1u : 0u;
-                R += e & 0xFF;
-                out += e >> 8;
-                slow = slow || (can && lv == 0);
-                // (the element behind the limit is hopped, then the walk fails)
-                fail = fail || over > kScanOverrun || R > h.lastR;
-                run = run && !slow && !fail && R < capR && out < stopOut &&
-                      (R < endR || (R & (kSeg - kEntry)) != 0);
+#pragma unroll
+                for (uint32_t u = 0; u < SNAPMI_HOP_UNROLL; u++) {
+                    const bool can = run && R - lo < span;
+                    const uint32_t x =
+                        (R + h.mis) & (kHopLines * kHopLine - 1);
+                    const uint32_t tag = winb[((x & ~3u) << 6) + (x & 3)];
+                    const uint32_t lv = h.lut[tag];
+                    const uint32_t e = can ? lv : 0; // waiting: no step
+                    over += (can && R >= endR) ? 1u : 0u;
+                    R += e & 0xFF;
+                    out += e >> 8;
+                    slow = slow || (can && lv == 0);
+                    // (the element behind the limit is hopped, then the walk
+                    // fails)
+                    fail = fail || over > kScanOverrun || R > h.lastR;
+                    run = run && !slow && !fail && R < capR &&
+                          out < stopOut &&
+                          (R < endR || (R & (kSeg - kEntry)) != 0);
+                }
             }
             w.R = R;
             w.out = out;
