@@ -15,3 +15,15 @@ db=$(find $R/gpurun_out/prof_$tag -name "*.db" | head -1)
 python $R/profiles/db_stats.py $db > $R/gpurun_out/kernel_stats_$tag.md; head -8 $R/gpurun_out/kernel_stats_$tag.md
 grep "^{\"metric" $R/gpurun_out/prof_$tag.log > $R/gpurun_out/prof_${tag}_bench.json
 find $R/gpurun_out/prof_$tag -type f -size +4M -delete
+# one Encoder::compress / Decoder::decompress call per bench input: the
+# product library's rule, then the test build at four long-stream thresholds
+cd $R
+{ echo "# product library (long streams: 128 KiB of input, or 64 KiB that announce 256 KiB of output)";
+  python tests/hw/scalar_latency.py 2>/dev/null;
+  for t in 16384 65536 262144; do echo "# test build, SNAPMI_LONG_STREAM=$t";
+    SNAPMI_TESTING=1 SNAPMI_LONG_STREAM=$t python tests/hw/scalar_latency.py 2>/dev/null | cut -c1-76; done; } > $R/gpurun_out/scalar_latency_$tag.txt
+head -14 $R/gpurun_out/scalar_latency_$tag.txt
+# kernel trace of one 2 GiB raw stream
+bash tests/hw/kernel_stats.sh stream_$tag stream:2 > /dev/null 2>&1
+grep -E "k_stream|k_decompress_streams3" $R/gpurun_out/stream_${tag}_kernel_stats.md | cut -c1-150
+grep -h decompress_stream_gibs $R/gpurun_out/stream_${tag}_run.txt | cut -c1-250

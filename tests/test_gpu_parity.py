@@ -519,6 +519,57 @@ def test_long_stream_parallel_decode(ctx):
         assert (oe.kind, oe.a, oe.b, oe.c) == e
 
 
+def test_long_stream_scan_shapes(ctx):
+    """The structure k_stream_scan / k_stream_cuts work in (64 segments of
+    4 KiB per scan wavefront, 512 per cuts wavefront, walks handed out from a
+    pool, chains that join the next segment's trunk): streams whose segment
+    count sits at and around those boundaries, streams where chains run
+    through the bytes of long literals (they never join: one walk each),
+    streams of two-byte copies and of one-byte literals (the most hops a
+    round can hold), and literals with one, two and three length bytes at
+    every alignment.  All must come from the parallel path."""
+    from rust_snappy_amd import raw
+    rng = random.Random(77)
+    text = b"".join(d for n, d in O.corpus_round() if "txt" in n or "html" in n)
+
+    def with_segments(nseg):
+        # a prefix of text x k whose stream is nseg segments long (bisection)
+        src = text * (nseg * 4096 * 3 // len(text) + 2)
+        lo, hi = 1, len(src)
+        while lo < hi:
+            mid = (lo + hi) // 2
+            if (len(O.compress(src[:mid])) + 4095) // 4096 < nseg:
+                lo = mid + 1
+            else:
+                hi = mid
+        return src[:lo]
+
+    cases = [with_segments(k) for k in (1, 2, 63, 64, 65, 128, 129, 511, 512,
+                                        513, 1025)]
+    noise = lambda n: bytes(rng.randrange(256) for _ in range(n))  # noqa: E731
+    mixed = bytearray()
+    for n in (200_000, 70_000, 61, 62, 300, 65_536, 65_537, 4096, 100_000):
+        mixed += noise(n) + text[rng.randrange(100_000):][:rng.randrange(
+            5_000, 150_000)]
+    cases.append(bytes(mixed))
+    small = bytes(rng.choice(b"abcd") for _ in range(700_000))   # tiny elements
+    cases.append(small)
+    cases.append(bytes(rng.randrange(2) for _ in range(900_000)))
+    # literals of 61 .. 70 000 bytes between copies, at drifting alignment
+    lit = bytearray()
+    for k in range(400):
+        lit += noise(rng.choice((61, 62, 100, 255, 256, 257, 1000, 4095, 4096,
+                                 4097, 20_000, 70_000)))
+        lit += lit[-rng.randrange(4, 60):] * rng.randrange(1, 4)
+    cases.append(bytes(lit))
+    for i, data in enumerate(cases):
+        comp = O.compress(data)
+        got, e = stream_decode(ctx, comp, len(data))
+        assert e[0] == 0, (i, e)
+        assert got == data, (i, len(data), len(comp))
+        assert raw.stream_decode_path(ctx) == 0, i
+
+
 def test_scalar_decompress_uses_long_stream_path(ctx):
     import rust_snappy_amd as R
     data = b"".join(d for _, d in O.corpus_round()) * 2
