@@ -175,6 +175,15 @@ const char *snapmi_version(void);
  *                          launch, up to 34 GB) is freed by
  *                          snapmi_ctx_synchronize instead of being kept for
  *                          the next batch (default 0)
+ *   "batch_long_streams"   1 (default): snapmi_decompress_batch looks at a
+ *                          batch of at most 16 384 streams first (one small
+ *                          kernel, one synchronisation of the context's
+ *                          stream, ~30 us) and decodes up to 1 024 long
+ *                          streams in it - 32 KiB compressed or more that
+ *                          expand - through their 64 KiB pieces, like
+ *                          snapmi_decompress_stream, instead of one wavefront
+ *                          each (a batch otherwise waits 3-5 ms for a 700 KB
+ *                          stream); 0: never, the call only enqueues
  *   "decode_kernel"        3 (default) k_decompress_streams3; 0 one element
  *                          at a time [2, the second generation alone, is a
  *                          cross-check of the test build]
@@ -250,6 +259,10 @@ int snapmi_compress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
  * Decompress n streams.  d_out_caps[i] is the capacity of d_out_ptrs[i]
  * (reference: output.len(), src/decompress.rs:84-89); d_out_lens[i] gets the
  * decompressed length on success, 0 on error.
+ * A stream is decoded by one wavefront - except the long streams of a batch
+ * of at most 16 384 streams, which are cut into pieces like the one stream of
+ * snapmi_decompress_stream (option "batch_long_streams": that look at the
+ * batch waits once for the context's stream).
  */
 int snapmi_decompress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                             const uint64_t *d_in_lens,
@@ -270,7 +283,8 @@ int snapmi_decompress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
  * cut), or with any error, is decoded by the sequential path, so results and
  * errors are those of snapmi_decompress_batch with n = 1.  Asynchronous on
  * the context's stream; d_out_len[0] / d_err[0] as in the batch call.
- * The scalar entry points use it for inputs of 256 KiB and more.
+ * The scalar entry points use it for inputs of 128 KiB and more, and of
+ * 64 KiB and more that announce 256 KiB of output.
  */
 int snapmi_decompress_stream(snapmi_ctx *ctx, const void *d_in,
                              uint64_t in_len, void *d_out, uint64_t out_cap,

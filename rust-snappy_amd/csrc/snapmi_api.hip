@@ -219,7 +219,7 @@ void snapmi_ctx_destroy(snapmi_ctx *ctx)
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
     host_pipe_destroy(ctx);
-    for (void *p : {ctx->pin_in, ctx->pin_out, ctx->pin_desc})
+    for (void *p : {ctx->pin_in, ctx->pin_out, ctx->pin_desc, ctx->pin_bl})
         if (p)
             (void)hipHostFree(p);
     if (ctx->h_mail)
@@ -234,7 +234,8 @@ void snapmi_ctx_destroy(snapmi_ctx *ctx)
                       &ctx->fr_meta, &ctx->fr_scan, &ctx->fr_slots,
                       &ctx->fr_chunk_off,
                       &ctx->tokens, &ctx->ntok, &ctx->lane_tables,
-                      &ctx->lane_epochs, &ctx->sd_tables, &ctx->sd_desc})
+                      &ctx->lane_epochs, &ctx->sd_tables, &ctx->sd_desc,
+                      &ctx->bl_modes, &ctx->bl_list, &ctx->bl_descs})
         if (b->p)
             (void)hipFree(b->p);
     for (auto &ev : ctx->ev)
@@ -302,6 +303,9 @@ int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value)
         ctx->match_spans_ratio_pct = (uint32_t)value;
     else if (strcmp(name, "release_scratch") == 0 && value >= 0 && value <= 1)
         ctx->release_scratch = (int)value;
+    else if (strcmp(name, "batch_long_streams") == 0 && value >= 0 &&
+             value <= 1)
+        ctx->batch_long_streams = (int)value;
     else if (strcmp(name, "both_wave_cus") == 0 && value >= 0 &&
              value <= 4096)
         ctx->both_wave_cus = (uint32_t)value;
@@ -1150,6 +1154,251 @@ int launch_decompress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     return SNAPMI_OK;
 }
 
+// ---------------------------------------------------------------------
+// A batch of few streams waits for its longest one: a stream is decoded by
+// one wavefront, 0.14 GiB/s, so the 702 KB of urls.10K are 4.9 ms whatever
+// else the batch holds (extras.sweep: 64 MiB of the corpus round decoded at
+// 12.8 GiB/s).  For batches of at most kBatchLongMaxN streams the long ones
+// (kLongStreamBatch compressed bytes and more that expand, k_long_plan; at
+// most kBatchLongMaxL of them) go the way of snapmi_decompress_stream instead - scan, cuts, pieces,
+// all long streams of the batch in the same launches (k_bstream_*) - and the
+// batch's own launch skips them (mode 3).  The price is one look at the
+// lengths on the host (k_long_plan, a copy of what it found, a stream
+// synchronisation: ~30 us), which is why large batches, whose long streams
+// hide behind each other, do not take it.
+// ---------------------------------------------------------------------
+constexpr size_t kBatchLongMaxN = 16384;
+constexpr uint32_t kBatchLongMaxL = 1024;
+constexpr uint64_t kLongStreamBatch = 32 << 10;
+
+#define BL_CHECK(name)                                                        \
+    do {                                                                      \
+        hipError_t _e = hipGetLastError();                                    \
+        if (_e != hipSuccess)                                                 \
+            return fail_ctx(ctx, SNAPMI_E_DEVICE, "launch of " #name ": %s",  \
+                            hipGetErrorString(_e));                           \
+    } while (0)
+
+static int decompress_batch_long(snapmi_ctx *ctx,
+                                 const void *const *d_in_ptrs,
+                                 const uint64_t *d_in_lens,
+                                 void *const *d_out_ptrs,
+                                 const uint64_t *d_out_caps,
+                                 uint64_t *d_out_lens, snapmi_error *d_errs,
+                                 size_t n, bool *done)
+{
+    *done = false;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    int rc;
+    const size_t list_bytes = 16 + (size_t)kBatchLongMaxL * sizeof(LongItem);
+    if ((rc = reserve(ctx, ctx->bl_modes, 2 * n + 64)) ||
+        (rc = reserve(ctx, ctx->bl_list, list_bytes)))
+        return rc;
+    if (ctx->pin_bl_cap < list_bytes) {
+        if (ctx->pin_bl) {
+            HIP_TRY(ctx, hipStreamSynchronize(s));
+            HIP_TRY(ctx, hipHostFree(ctx->pin_bl));
+            ctx->pin_bl = nullptr;
+            ctx->pin_bl_cap = 0;
+        }
+        HIP_TRY(ctx, hipHostMalloc(&ctx->pin_bl, list_bytes,
+                                   hipHostMallocDefault));
+        ctx->pin_bl_cap = list_bytes;
+    }
+    uint8_t *modes = (uint8_t *)ctx->bl_modes.p, *modes2 = modes + n;
+    uint32_t *d_count = (uint32_t *)ctx->bl_list.p;
+    LongItem *d_list = (LongItem *)((uint8_t *)ctx->bl_list.p + 16);
+    HIP_TRY(ctx, hipMemsetAsync(d_count, 0, 16, s));
+    hipLaunchKernelGGL(k_long_plan, dim3(1), dim3(1024), 0, s, d_in_ptrs,
+                       d_in_lens, d_out_ptrs, d_out_caps, (uint32_t)n,
+                       kLongStreamBatch, modes, d_list, kBatchLongMaxL,
+                       d_count);
+    BL_CHECK(k_long_plan);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->pin_bl, ctx->bl_list.p, list_bytes,
+                                hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    const uint32_t found = *(const uint32_t *)ctx->pin_bl;
+    // (none - or so many that they fill the chip a wavefront each: 3 058
+    // streams of urls.10K decode at 288 GiB/s that way and at 194 through
+    // pieces, 1 100 long streams of the corpus round at 171 and 183: the
+    // caller goes on without modes)
+    if (found == 0 || found > kBatchLongMaxL)
+        return SNAPMI_OK;
+    const uint32_t L = found;
+    const LongItem *items = (const LongItem *)((const uint8_t *)ctx->pin_bl + 16);
+
+    // ---- geometry, scratch, descriptors ----------------------------------
+    std::vector<StreamArgs> descs(L);
+    // first workgroup of every stream, per kernel: scan, super, super3,
+    // spread3, spread2, cuts, pieces
+    enum { kPScan, kPSuper, kPSuper3, kPSpread3, kPSpread2, kPCuts, kPPieces, kPre };
+    std::vector<uint32_t> pre((size_t)kPre * (L + 1));
+    size_t rows = 0, blocks = 0, cuts = 0, pieces = 0;
+    for (uint32_t j = 0; j < L; j++) {
+        StreamArgs &a = descs[j];
+        memset(&a, 0, sizeof a);
+        a.in = (const uint8_t *)items[j].in;
+        a.in_len = items[j].in_len;
+        a.out = (uint8_t *)items[j].out;
+        a.out_cap = items[j].out_cap;
+        a.out_len = (unsigned long long *)(d_out_lens + items[j].idx);
+        a.err = d_errs ? d_errs + items[j].idx : nullptr;
+        a.fb_mode = modes2 + items[j].idx;
+        a.nseg = (uint32_t)((a.in_len + kSeg - 1) / kSeg + 1);
+        a.nsuper = (a.nseg + kSegPerSuper - 1) / kSegPerSuper;
+        a.nsuper3 = (a.nsuper + kSegPerSuper - 1) / kSegPerSuper;
+        a.kmax = (uint32_t)(items[j].dlen / kStreamChunk + 2);
+        uint32_t *pj = &pre[j];
+        const size_t st = L + 1;
+        pj[kPScan * st] = (a.nseg + kWave - 1) / kWave;
+        pj[kPSuper * st] = a.nsuper;
+        pj[kPSuper3 * st] = a.nsuper3;
+        pj[kPSpread3 * st] = (a.nsuper3 + 63) / 64;
+        pj[kPSpread2 * st] = (a.nsuper + 63) / 64;
+        pj[kPCuts * st] = (a.nseg + kCutSegs - 1) / kCutSegs;
+        pj[kPPieces * st] = (a.kmax + 255) / 256;
+        rows += (size_t)a.nseg + ((size_t)a.nsuper + a.nsuper3) * kSegPerSuper;
+        blocks += (size_t)a.nseg + a.nsuper + a.nsuper3;
+        cuts += (size_t)a.kmax + 1;
+        pieces += a.kmax;
+    }
+    uint32_t grid[kPre];
+    for (int k = 0; k < kPre; k++) { // counts -> exclusive prefix, total last
+        uint32_t *pk = &pre[(size_t)k * (L + 1)];
+        uint32_t acc = 0;
+        for (uint32_t j = 0; j < L; j++) {
+            const uint32_t c = pk[j];
+            pk[j] = acc;
+            acc += c;
+        }
+        pk[L] = acc;
+        grid[k] = acc;
+    }
+    const size_t t_bytes = 64 + (size_t)L * 64 + rows * kEntry * 16 +
+                           blocks * 16 + cuts * 16;
+    const size_t d_stride = 8 + 8 + 8 + 8 + 8 + sizeof(snapmi_error) + 1;
+    const size_t d_bytes = pieces * d_stride + 64;
+    const size_t desc_bytes = (size_t)L * sizeof(StreamArgs);
+    const size_t pre_bytes = pre.size() * sizeof(uint32_t);
+    if ((rc = reserve(ctx, ctx->sd_tables, t_bytes)) ||
+        (rc = reserve(ctx, ctx->sd_desc, d_bytes)) ||
+        (rc = reserve(ctx, ctx->bl_descs, desc_bytes + pre_bytes + 64)))
+        return rc;
+    {
+        unsigned long long *t = (unsigned long long *)ctx->sd_tables.p;
+        unsigned long long *meta = t;
+        t += (size_t)L * 8;
+        unsigned long long *e_all = t; // the e-tables of all streams: one fill
+        unsigned long long *e = e_all;
+        t += blocks * 2;
+        uint8_t *q = (uint8_t *)ctx->sd_desc.p;
+        const void **c_in = (const void **)q;
+        q += pieces * 8;
+        unsigned long long *c_inlen = (unsigned long long *)q;
+        q += pieces * 8;
+        void **c_out = (void **)q;
+        q += pieces * 8;
+        unsigned long long *c_cap = (unsigned long long *)q;
+        q += pieces * 8;
+        unsigned long long *c_outlen = (unsigned long long *)q;
+        q += pieces * 8;
+        snapmi_error *c_err = (snapmi_error *)q;
+        q += pieces * sizeof(snapmi_error);
+        uint8_t *c_mode = q;
+        size_t k0 = 0;
+        for (uint32_t j = 0; j < L; j++) {
+            StreamArgs &a = descs[j];
+            a.meta = meta + (size_t)j * 8;
+            a.e1 = e;
+            e += (size_t)a.nseg * 2;
+            a.e2 = e;
+            e += (size_t)a.nsuper * 2;
+            a.e3 = e;
+            e += (size_t)a.nsuper3 * 2;
+            a.s1 = t;
+            t += (size_t)a.nseg * kEntry * 2;
+            a.s2 = t;
+            t += (size_t)a.nsuper * kSegPerSuper * kEntry * 2;
+            a.s3 = t;
+            t += (size_t)a.nsuper3 * kSegPerSuper * kEntry * 2;
+            a.cuts = t;
+            t += ((size_t)a.kmax + 1) * 2;
+            a.c_in = c_in + k0;
+            a.c_inlen = c_inlen + k0;
+            a.c_out = c_out + k0;
+            a.c_cap = c_cap + k0;
+            a.c_outlen = c_outlen + k0;
+            a.c_err = c_err + k0;
+            a.c_mode = c_mode + k0;
+            k0 += a.kmax;
+        }
+        // (pageable staging is fine here: two small copies; the vectors live
+        // until the synchronisation hipMemcpyAsync from pageable memory makes)
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->bl_descs.p, descs.data(), desc_bytes,
+                                    hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipMemcpyAsync((uint8_t *)ctx->bl_descs.p + desc_bytes,
+                                    pre.data(), pre_bytes,
+                                    hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        HIP_TRY(ctx, hipMemsetAsync(e_all, 0xFF, blocks * 16, s));
+        HIP_TRY(ctx, hipMemsetAsync(modes2, 3, n, s));
+        const StreamArgs *dd = (const StreamArgs *)ctx->bl_descs.p;
+        const uint32_t *dp =
+            (const uint32_t *)((uint8_t *)ctx->bl_descs.p + desc_bytes);
+        auto B = [&](int k) {
+            BatchStreams b;
+            b.descs = dd;
+            b.pre = k < 0 ? nullptr : dp + (size_t)k * (L + 1);
+            b.n = L;
+            return b;
+        };
+        hipLaunchKernelGGL(k_bstream_head, dim3(L), dim3(1), 0, s, B(-1));
+        BL_CHECK(k_bstream_head);
+        hipLaunchKernelGGL(k_bstream_scan, dim3(grid[kPScan]), dim3(64), 0, s,
+                           B(kPScan));
+        BL_CHECK(k_bstream_scan);
+        hipLaunchKernelGGL(k_bstream_super, dim3(grid[kPSuper]), dim3(kEntry),
+                           0, s, B(kPSuper));
+        BL_CHECK(k_bstream_super);
+        hipLaunchKernelGGL(k_bstream_super3, dim3(grid[kPSuper3]),
+                           dim3(kEntry), 0, s, B(kPSuper3));
+        BL_CHECK(k_bstream_super3);
+        hipLaunchKernelGGL(k_bstream_chain, dim3(L), dim3(1), 0, s, B(-1));
+        BL_CHECK(k_bstream_chain);
+        hipLaunchKernelGGL(k_bstream_spread3, dim3(grid[kPSpread3]), dim3(64),
+                           0, s, B(kPSpread3));
+        BL_CHECK(k_bstream_spread3);
+        hipLaunchKernelGGL(k_bstream_spread2, dim3(grid[kPSpread2]), dim3(64),
+                           0, s, B(kPSpread2));
+        BL_CHECK(k_bstream_spread2);
+        hipLaunchKernelGGL(k_bstream_cuts, dim3(grid[kPCuts]), dim3(64), 0, s,
+                           B(kPCuts));
+        BL_CHECK(k_bstream_cuts);
+        hipLaunchKernelGGL(k_bstream_pieces, dim3(grid[kPPieces]), dim3(256),
+                           0, s, B(kPPieces));
+        BL_CHECK(k_bstream_pieces);
+        // the batch's other streams; the pieces of the long ones; which of
+        // the long ones were irregular; those, by the wavefront decoder
+        if ((rc = launch_decompress(ctx, d_in_ptrs, d_in_lens, d_out_ptrs,
+                                    d_out_caps, d_out_lens, d_errs, modes,
+                                    n)) ||
+            (rc = launch_decompress(ctx, c_in, (const uint64_t *)c_inlen,
+                                    c_out, (const uint64_t *)c_cap,
+                                    (uint64_t *)c_outlen, c_err, c_mode,
+                                    pieces)))
+            return rc;
+        hipLaunchKernelGGL(k_bstream_finish, dim3(L), dim3(1024), 0, s, B(-1));
+        BL_CHECK(k_bstream_finish);
+        if ((rc = launch_decompress(ctx, d_in_ptrs, d_in_lens, d_out_ptrs,
+                                    d_out_caps, d_out_lens, d_errs, modes2,
+                                    n)))
+            return rc;
+    }
+    *done = true;
+    return SNAPMI_OK;
+}
+
 } // namespace snapmi
 
 extern "C" {
@@ -1167,6 +1416,14 @@ int snapmi_decompress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     if (!d_in_ptrs || !d_in_lens || !d_out_ptrs || !d_out_caps ||
         !d_out_lens || n > 0x7FFFFFFFu)
         return fail_ctx(ctx, SNAPMI_E_ARGUMENT, "decompress_batch: bad args");
+    if (ctx->batch_long_streams && n <= kBatchLongMaxN) {
+        bool done = false;
+        const int rc = decompress_batch_long(ctx, d_in_ptrs, d_in_lens,
+                                             d_out_ptrs, d_out_caps,
+                                             d_out_lens, d_errs, n, &done);
+        if (rc || done)
+            return rc;
+    }
     return launch_decompress(ctx, d_in_ptrs, d_in_lens, d_out_ptrs, d_out_caps,
                              d_out_lens, d_errs, nullptr, n);
 }
@@ -1208,6 +1465,7 @@ int snapmi_decompress_stream(snapmi_ctx *ctx, const void *d_in,
     a.nsuper = (a.nseg + kSegPerSuper - 1) / kSegPerSuper;
     a.nsuper3 = (a.nsuper + kSegPerSuper - 1) / kSegPerSuper;
     a.kmax = (uint32_t)kmax64;
+    a.fb_mode = nullptr;
     const size_t blocks = (size_t)a.nseg + a.nsuper + a.nsuper3;
     const size_t rows = (size_t)a.nseg +
                         ((size_t)a.nsuper + a.nsuper3) * kSegPerSuper;

@@ -137,6 +137,14 @@ struct snapmi_ctx {
     snapmi::DevBuf st_in, st_out, st_desc, st_prof, ticket, order;
     // long-stream decode scratch (snapmi_decompress_stream)
     snapmi::DevBuf sd_tables, sd_desc;
+    // the long streams of a small batch get their pieces
+    // (snapmi_decompress_batch, option batch_long_streams): modes of the
+    // batch's own launch and of the one behind, what k_long_plan found, the
+    // streams' descriptors and workgroup prefixes; pinned staging of both
+    int batch_long_streams = 1;
+    snapmi::DevBuf bl_modes, bl_list, bl_descs;
+    void *pin_bl = nullptr;
+    size_t pin_bl_cap = 0;
     // frame layer scratch (snapmi_frame.hip)
     snapmi::DevBuf fr_tables, fr_desc, fr_meta, fr_scan, fr_slots, fr_chunk_off;
     bool fr_tables_ready = false;

@@ -341,6 +341,8 @@ __device__ __forceinline__ uint32_t plan_class(const DecompressArgs &a,
                                                uint32_t i)
 {
     const uint64_t len = a.in_lens[i];
+    if (a.modes && a.modes[i] == 3) // not this launch's: behind everything
+        return 0;
     uint32_t bk = len ? 63 - (uint32_t)__builtin_clzll(len) : 0;
     if (len && bk < kTinyLog2) {
         const uint32_t mode = a.modes ? a.modes[i] : 0;
@@ -631,6 +633,8 @@ __device__ __forceinline__ bool open_stream(const DecompressArgs &a,
     const uint64_t in_len = a.in_lens[st];
     const bool piece = a.modes && a.modes[st] == 2;
 
+    if (a.modes && a.modes[st] == 3)
+        return false; // another launch decodes this stream
     if (a.modes && a.modes[st] == 1) {
         // stored frame chunk (reference src/read.rs:173-199): the payload is
         // the data (wave_copy)
@@ -1487,6 +1491,8 @@ __device__ __forceinline__ void decode_tiny(const DecompressArgs &a,
     gptr dst = (gptr)a.out_ptrs[st];
     const uint32_t mode = a.modes ? a.modes[st] : 0;
     const uint64_t cap = a.out_caps[st];
+    if (mode == 3)
+        return; // another launch decodes this stream
     if (mode == 1) { // stored frame chunk (reference src/read.rs:173-199)
         if (in_len > cap)
             SNAPMI_TINY_FAIL(SNAPMI_BUFFER_TOO_SMALL, cap, in_len, 0);
@@ -1937,13 +1943,14 @@ __device__ __forceinline__ bool reach_end(const StreamArgs &a, uint64_t &p,
 
 // table of one level-L block (L = 2, 3), children right to left: entering at
 // child c continues, after that child, with an entry already tabulated
-template <int L> __device__ __forceinline__ void build_level(const StreamArgs &a)
+template <int L>
+__device__ __forceinline__ void build_level(const StreamArgs &a, uint32_t wg)
 {
     __shared__ su64x2 tab[kSegPerSuper * kEntry]; // 16 KiB
     if (a.meta[2])
         return;
     const uint64_t B = level_bytes<L>(), Bc = level_bytes<L - 1>();
-    const uint64_t blk = blockIdx.x;
+    const uint64_t blk = wg;
     uint64_t end = (blk + 1) * B;
     if (end > a.in_len)
         end = a.in_len;
@@ -1972,11 +1979,12 @@ template <int L> __device__ __forceinline__ void build_level(const StreamArgs &a
 
 // entries of level L-1 from the entries of level L: one lane per block of
 // level L walks its children
-template <int L> __device__ __forceinline__ void spread_level(const StreamArgs &a)
+template <int L>
+__device__ __forceinline__ void spread_level(const StreamArgs &a, uint32_t wg)
 {
     if (a.meta[2])
         return;
-    const uint64_t blk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t blk = (uint64_t)wg * blockDim.x + threadIdx.x;
     const uint64_t B = level_bytes<L>(), Bc = level_bytes<L - 1>();
     if (blk * B >= a.in_len)
         return;
@@ -1997,7 +2005,7 @@ template <int L> __device__ __forceinline__ void spread_level(const StreamArgs &
 }
 } // namespace
 
-__global__ void k_stream_head(StreamArgs a)
+__device__ __forceinline__ void stream_head(const StreamArgs &a, const uint32_t wg)
 {
     // header checks of Decoder::decompress (src/decompress.rs:75-95); any
     // failure is left to the sequential decoder, which reports it
@@ -2329,7 +2337,7 @@ __device__ __forceinline__ void hop_lut(uint16_t *lutbuf)
     __syncthreads();
 }
 
-__global__ __launch_bounds__(64) void k_stream_scan(StreamArgs a)
+__device__ __forceinline__ void stream_scan(const StreamArgs &a, const uint32_t wg)
 {
     __shared__ uint32_t winbuf[kHopLines * (kHopLine / 4) * 64];
     __shared__ uint16_t lutbuf[256];
@@ -2346,7 +2354,7 @@ __global__ __launch_bounds__(64) void k_stream_scan(StreamArgs a)
     h.lut = (l_u16x *)lutbuf;
     h.in = (gcptr)a.in;
     h.in_len = a.in_len;
-    const uint64_t seg0 = (uint64_t)blockIdx.x * 64;
+    const uint64_t seg0 = (uint64_t)wg * 64;
     h.wbase = seg0 * kSeg;
     h.mis = (uint32_t)((uintptr_t)a.in + h.wbase) & (kHopLine - 1);
     const uint64_t left = a.in_len - h.wbase; // > 0: the grid covers nseg
@@ -2474,17 +2482,9 @@ __global__ __launch_bounds__(64) void k_stream_scan(StreamArgs a)
         }
     }
 }
-__global__ __launch_bounds__(kEntry) void k_stream_super(StreamArgs a)
-{
-    build_level<2>(a);
-}
-__global__ __launch_bounds__(kEntry) void k_stream_super3(StreamArgs a)
-{
-    build_level<3>(a);
-}
 
 // the one sequential pass: a table lookup per 16 MiB of input
-__global__ void k_stream_chain(StreamArgs a)
+__device__ __forceinline__ void stream_chain(const StreamArgs &a, const uint32_t wg)
 {
     if (a.meta[2])
         return;
@@ -2499,14 +2499,6 @@ __global__ void k_stream_chain(StreamArgs a)
     if (!ok || p != a.in_len || out != a.meta[1])
         a.meta[2] = 1;
 }
-__global__ void k_stream_spread3(StreamArgs a)
-{
-    spread_level<3>(a);
-}
-__global__ void k_stream_spread2(StreamArgs a)
-{
-    spread_level<2>(a);
-}
 
 // The element boundary at (or first behind) every 64 KiB of output: the
 // segments whose stretch of the chain holds such a boundary are collected -
@@ -2515,7 +2507,7 @@ __global__ void k_stream_spread2(StreamArgs a)
 // a lane per segment, standing at every boundary on the way.  (Rounds 1-3:
 // one lane per segment hopping through HBM, the wavefront as slow as its
 // slowest lane: 1.7 ms of a 2 GiB stream.)
-__global__ __launch_bounds__(64) void k_stream_cuts(StreamArgs a)
+__device__ __forceinline__ void stream_cuts(const StreamArgs &a, const uint32_t wg)
 {
     __shared__ uint32_t winbuf[kHopLines * (kHopLine / 4) * 64];
     __shared__ uint16_t lutbuf[256];
@@ -2523,7 +2515,7 @@ __global__ __launch_bounds__(64) void k_stream_cuts(StreamArgs a)
     if (a.meta[2])
         return;
     const uint32_t lane = threadIdx.x;
-    const uint64_t seg0 = (uint64_t)blockIdx.x * kCutSegs;
+    const uint64_t seg0 = (uint64_t)wg * kCutSegs;
     if (seg0 == 0 && lane == 0) {
         const uint64_t K = a.meta[3];
         a.cuts[0] = a.meta[0];
@@ -2613,9 +2605,9 @@ __global__ __launch_bounds__(64) void k_stream_cuts(StreamArgs a)
         });
 }
 
-__global__ void k_stream_pieces(StreamArgs a)
+__device__ __forceinline__ void stream_pieces(const StreamArgs &a, const uint32_t wg)
 {
-    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t k = (uint64_t)wg * blockDim.x + threadIdx.x;
     if (k >= a.kmax)
         return;
     const bool live = a.meta[2] == 0 && k < a.meta[3];
@@ -2632,7 +2624,7 @@ __global__ void k_stream_pieces(StreamArgs a)
     a.c_err[k].kind = SNAPMI_OK;
 }
 
-__global__ __launch_bounds__(1024) void k_stream_finish(StreamArgs a)
+__device__ __forceinline__ void stream_finish(const StreamArgs &a, const uint32_t wg)
 {
     __shared__ uint32_t bad;
     if (threadIdx.x == 0)
@@ -2646,10 +2638,108 @@ __global__ __launch_bounds__(1024) void k_stream_finish(StreamArgs a)
     __syncthreads();
     if (threadIdx.x == 0) {
         a.meta[2] = bad; // 1: the sequential decoder runs next
+        if (a.fb_mode) // in a batch: 0 = decode it in the launch behind, 3 = not
+            *a.fb_mode = bad ? 0 : 3;
         if (!bad) {
             a.out_len[0] = a.meta[1];
             set_error(a.err, 0, SNAPMI_OK, 0, 0, 0);
         }
+    }
+}
+
+// ---------------------------------------------------------------------
+// The kernels: for ONE stream (snapmi_decompress_stream), and for the long
+// streams of a batch (snapmi_decompress_batch, few streams: every long stream
+// gets its pieces instead of one wavefront) - the same bodies, a workgroup of
+// the batched launch first finds its stream.
+// ---------------------------------------------------------------------
+// b.pre[s] = first workgroup of stream s in this launch, pre[L] = all of them;
+// pre == nullptr: one workgroup per stream
+__device__ __forceinline__ bool batch_find(const BatchStreams &b, uint32_t &s,
+                                           uint32_t &wg)
+{
+    const uint32_t g = blockIdx.x;
+    if (!b.pre) {
+        s = g;
+        wg = 0;
+        return g < b.n;
+    }
+    if (g >= b.pre[b.n])
+        return false;
+    uint32_t lo = 0, hi = b.n; // pre[lo] <= g < pre[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (b.pre[mid] <= g)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    s = lo;
+    wg = g - b.pre[lo];
+    return true;
+}
+#define SNAPMI_STREAM_KERNEL(name, bounds, call)                              \
+    __global__ __launch_bounds__(bounds) void k_stream_##name(StreamArgs a)   \
+    {                                                                         \
+        const uint32_t wg = blockIdx.x;                                       \
+        call;                                                                 \
+    }                                                                         \
+    __global__ __launch_bounds__(bounds) void k_bstream_##name(BatchStreams b) \
+    {                                                                         \
+        uint32_t s_, wg;                                                      \
+        if (!batch_find(b, s_, wg))                                           \
+            return;                                                           \
+        const StreamArgs a = b.descs[s_];                                     \
+        call;                                                                 \
+    }
+SNAPMI_STREAM_KERNEL(head, 64, stream_head(a, wg))
+SNAPMI_STREAM_KERNEL(scan, 64, stream_scan(a, wg))
+SNAPMI_STREAM_KERNEL(super, kEntry, build_level<2>(a, wg))
+SNAPMI_STREAM_KERNEL(super3, kEntry, build_level<3>(a, wg))
+SNAPMI_STREAM_KERNEL(chain, 64, stream_chain(a, wg))
+SNAPMI_STREAM_KERNEL(spread3, 64, spread_level<3>(a, wg))
+SNAPMI_STREAM_KERNEL(spread2, 64, spread_level<2>(a, wg))
+SNAPMI_STREAM_KERNEL(cuts, 64, stream_cuts(a, wg))
+SNAPMI_STREAM_KERNEL(pieces, 256, stream_pieces(a, wg))
+SNAPMI_STREAM_KERNEL(finish, 1024, stream_finish(a, wg))
+
+// The long streams of a batch: those of min_len compressed bytes and more
+// whose header announces 96 KiB of output or more, and no more than the
+// elements could produce and the caller's buffer holds (anything else is left
+// to the wavefront decoder, which names the error).  modes[i] = 3 for them (the
+// batch's own launch skips them), 0 for the others.
+__global__ __launch_bounds__(1024) void k_long_plan(
+    const void *const *in_ptrs, const uint64_t *in_lens, void *const *out_ptrs,
+    const uint64_t *out_caps, uint32_t n, uint64_t min_len, uint8_t *modes,
+    LongItem *list, uint32_t cap, uint32_t *count)
+{
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint64_t len = in_lens[i];
+        uint8_t mode = 0;
+        if (len >= min_len) {
+            uint64_t dl = 0;
+            const uint32_t hdr = read_varint((gcptr)in_ptrs[i], len, &dl);
+            // (one and a half pieces of output or more, and half as much
+            // again as the input: the elements are what a wavefront is slow
+            // at, a stream of literals it copies at 0.85 GB/s)
+            if (hdr && 2 * dl >= 3 * (uint64_t)kStreamChunk &&
+                2 * dl >= 3 * len && dl <= out_caps[i] && dl / 22 <= len) {
+                const uint32_t slot = atomicAdd(count, 1u);
+                if (slot < cap) {
+                    LongItem it;
+                    it.idx = i;
+                    it.pad = 0;
+                    it.in_len = len;
+                    it.dlen = dl;
+                    it.in = in_ptrs[i];
+                    it.out = out_ptrs[i];
+                    it.out_cap = out_caps[i];
+                    list[slot] = it;
+                    mode = 3;
+                }
+            }
+        }
+        modes[i] = mode;
     }
 }
 

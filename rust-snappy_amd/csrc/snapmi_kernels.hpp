@@ -68,7 +68,9 @@ struct DecompressArgs {
     snapmi_error *errs; // [n] or nullptr
     // optional [n]: 1 = stored chunk (frame type 0x01): plain copy of the
     // input; 2 = headerless piece of a long stream (k_stream_*): elements only,
-    // out_caps[i] is the exact output length
+    // out_caps[i] is the exact output length; 3 = not this launch's (a long
+    // stream of a batch, decoded through its pieces): nothing is read, nothing
+    // written
     const uint8_t *modes;
     // optional: the launch does nothing unless *gate == gate_value
     const unsigned long long *gate;
@@ -156,17 +158,41 @@ struct StreamArgs {
     unsigned long long *c_outlen;
     snapmi_error *c_err;
     uint8_t *c_mode;
+    // a long stream of a batch: where k_stream_finish says whether the
+    // launch behind it must decode the stream (0) or not (3); else nullptr
+    uint8_t *fb_mode;
 };
-__global__ void k_stream_head(StreamArgs a);
-__global__ void k_stream_scan(StreamArgs a);
-__global__ void k_stream_super(StreamArgs a);
-__global__ void k_stream_super3(StreamArgs a);
-__global__ void k_stream_chain(StreamArgs a);
-__global__ void k_stream_spread3(StreamArgs a);
-__global__ void k_stream_spread2(StreamArgs a);
-__global__ void k_stream_cuts(StreamArgs a);
-__global__ void k_stream_pieces(StreamArgs a);
-__global__ void k_stream_finish(StreamArgs a);
+// the long streams of a batch: their descriptors and, per kernel, the first
+// workgroup of every stream (nullptr: one workgroup each)
+struct BatchStreams {
+    const StreamArgs *descs;
+    const uint32_t *pre; // [n + 1]
+    uint32_t n;
+};
+struct LongItem { // what k_long_plan hands to the host
+    uint32_t idx, pad;
+    unsigned long long in_len, dlen;
+    const void *in;
+    void *out;
+    unsigned long long out_cap;
+};
+#define SNAPMI_STREAM_KERNEL_DECL(name)                                       \
+    __global__ void k_stream_##name(StreamArgs a);                            \
+    __global__ void k_bstream_##name(BatchStreams b);
+SNAPMI_STREAM_KERNEL_DECL(head)
+SNAPMI_STREAM_KERNEL_DECL(scan)
+SNAPMI_STREAM_KERNEL_DECL(super)
+SNAPMI_STREAM_KERNEL_DECL(super3)
+SNAPMI_STREAM_KERNEL_DECL(chain)
+SNAPMI_STREAM_KERNEL_DECL(spread3)
+SNAPMI_STREAM_KERNEL_DECL(spread2)
+SNAPMI_STREAM_KERNEL_DECL(cuts)
+SNAPMI_STREAM_KERNEL_DECL(pieces)
+SNAPMI_STREAM_KERNEL_DECL(finish)
+__global__ void k_long_plan(const void *const *in_ptrs, const uint64_t *in_lens,
+                            void *const *out_ptrs, const uint64_t *out_caps,
+                            uint32_t n, uint64_t min_len, uint8_t *modes,
+                            LongItem *list, uint32_t cap, uint32_t *count);
 
 __global__ void k_plan_decompress(DecompressArgs a);
 __global__ void k_plan_decompress_a(DecompressArgs a);

@@ -570,6 +570,66 @@ def test_long_stream_scan_shapes(ctx):
         assert raw.stream_decode_path(ctx) == 0, i
 
 
+def test_batch_with_long_streams(ctx):
+    """A small batch gives its long streams their pieces (k_long_plan,
+    k_bstream_*): long and short streams side by side, long ones that are
+    corrupt, truncated, lie in their header, come from a foreign encoder
+    (copies across pieces: the wavefront decoder in the launch behind), or
+    do not fit the caller's buffer - bytes and errors are the oracle's stream
+    by stream, with the option on (default) and off."""
+    import foreign
+    import rust_snappy_amd as R
+    rng = random.Random(5)
+    rnd = O.corpus_round()
+    big = b"".join(d for _, d in rnd) * 3
+    plain = [d for _, d in rnd] + [big, b"", b"a", bytes(500000),
+                                   bytes(rng.randrange(256)
+                                         for _ in range(300000))]
+    comps = [O.compress(d) for d in plain]
+    assert sum(len(c) >= (128 << 10) for c in comps) >= 5
+    long_ones = [c for c in comps if len(c) >= (128 << 10)]
+    muts = []
+    for c in long_ones[:4]:
+        for _ in range(6):
+            b = bytearray(c)
+            for _ in range(rng.randrange(1, 4)):
+                b[rng.randrange(len(b))] = rng.randrange(256)
+            muts.append(bytes(b))
+        muts += [c[:len(c) // 2], c[:-1], c + b"\x00"]
+        # headers that announce more / less than the elements produce
+        n, hd = O.decompress_len(c), 0
+        while c[hd] & 0x80:
+            hd += 1
+        hd += 1
+        muts += [foreign.varint(n + 70000) + c[hd:],
+                 foreign.varint(n - 70000) + c[hd:]]
+    far = [foreign.build(100 + k, 600000) for k in range(3)]   # 3 long ones
+    streams = comps + muts + [st for st, _ in far]
+    caps = []
+    for m in streams:
+        try:
+            caps.append(min(O.decompress_len(m), 1 << 25))
+        except O.SnapError:
+            caps.append(1024)
+    # ... and long streams whose output buffer is too small
+    streams += long_ones[:2]
+    caps += [O.decompress_len(long_ones[0]) - 1, 70000]
+    assert len(streams) < 200
+    plain_ctx = R.raw.Context(0)
+    plain_ctx.set_option("batch_long_streams", 0)
+    try:
+        for c in (ctx, plain_ctx):
+            got, errs = gpu_decompress(c, streams, caps)
+            for i, (m, cap, g, e) in enumerate(zip(streams, caps, got, errs)):
+                try:
+                    want = O.decompress(m, cap)
+                    assert e[0] == 0 and g == want, (i, e, len(m))
+                except O.SnapError as oe:
+                    assert (oe.kind, oe.a, oe.b, oe.c) == e, (i, e, oe)
+    finally:
+        plain_ctx.close()
+
+
 def test_scalar_decompress_uses_long_stream_path(ctx):
     import rust_snappy_amd as R
     data = b"".join(d for _, d in O.corpus_round()) * 2
