@@ -178,7 +178,7 @@ const char *snapmi_version(void);
  *   "batch_long_streams"   1 (default): snapmi_decompress_batch looks at a
  *                          batch of at most 16 384 streams first (one small
  *                          kernel, one synchronisation of the context's
- *                          stream, ~30 us) and decodes up to 1 024 long
+ *                          stream, ~30 us) and decodes up to 4 096 long
  *                          streams in it - 32 KiB compressed or more that
  *                          expand - through their 64 KiB pieces, like
  *                          snapmi_decompress_stream, instead of one wavefront

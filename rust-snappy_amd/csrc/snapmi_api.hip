@@ -235,7 +235,8 @@ void snapmi_ctx_destroy(snapmi_ctx *ctx)
                       &ctx->fr_chunk_off,
                       &ctx->tokens, &ctx->ntok, &ctx->lane_tables,
                       &ctx->lane_epochs, &ctx->sd_tables, &ctx->sd_desc,
-                      &ctx->bl_modes, &ctx->bl_list, &ctx->bl_descs})
+                      &ctx->bl_modes, &ctx->bl_list, &ctx->bl_descs,
+                      &ctx->bl_order})
         if (b->p)
             (void)hipFree(b->p);
     for (auto &ev : ctx->ev)
@@ -1072,9 +1073,11 @@ int launch_decompress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                       const uint64_t *d_out_caps, uint64_t *d_out_lens,
                       snapmi_error *d_errs, const uint8_t *d_modes, size_t n,
                       const unsigned long long *d_gate,
-                      unsigned long long gate_value)
+                      unsigned long long gate_value, hipStream_t side,
+                      DevBuf *side_order)
 {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf &order = side_order ? *side_order : ctx->order;
     DecompressArgs a;
     a.gate = d_gate;
     a.gate_value = gate_value;
@@ -1089,11 +1092,11 @@ int launch_decompress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     {
         // (+ 64 bucket counters of the many-workgroup sort behind the order,
         // + the number of streams that are not tiny)
-        int rc = reserve(ctx, ctx->order, (n + 72) * sizeof(uint32_t));
+        int rc = reserve(ctx, order, (n + 72) * sizeof(uint32_t));
         if (rc)
             return rc;
     }
-    a.order = (uint32_t *)ctx->order.p;
+    a.order = (uint32_t *)order.p;
     a.bucket_pos = a.order + n;
     a.prof = nullptr;
 #ifdef SNAPMI_PROFILE
@@ -1106,9 +1109,11 @@ int launch_decompress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
         a.prof = (unsigned long long *)ctx->st_prof.p;
     }
 #endif
-    hipStream_t s = ctx->stream;
-    ctx->timing_valid = false;
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], s));
+    hipStream_t s = side ? side : ctx->stream;
+    if (!side) {
+        ctx->timing_valid = false;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[0], s));
+    }
     if (n > kPlanOneWg) {
         const uint32_t parts = (uint32_t)((n + 1023) / 1024);
         HIP_TRY(ctx, hipMemsetAsync(a.bucket_pos, 0, 64 * sizeof(uint32_t), s));
@@ -1120,7 +1125,8 @@ int launch_decompress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     } else {
         hipLaunchKernelGGL(k_plan_decompress, dim3(1), dim3(1024), 0, s, a);
     }
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], s));
+    if (!side)
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[1], s));
     if (ctx->decode_kernel == 0)
         hipLaunchKernelGGL(k_decompress_sequential, dim3((uint32_t)n),
                            dim3(64), 0, s, a);
@@ -1144,9 +1150,11 @@ int launch_decompress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
         hipLaunchKernelGGL(k_decompress_tiny,
                            dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, s, a);
     }
+    HIP_TRY(ctx, hipGetLastError());
+    if (side)
+        return SNAPMI_OK;
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], s));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[3], s));
-    HIP_TRY(ctx, hipGetLastError());
     ctx->timing_valid = true;
     ctx->timing_is_compress = false;
     ctx->dominant_split = false;
@@ -1158,7 +1166,7 @@ int launch_decompress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
 // A batch of few streams waits for its longest one: a stream is decoded by
 // one wavefront, 0.14 GiB/s, so the 702 KB of urls.10K are 4.9 ms whatever
 // else the batch holds (extras.sweep: 64 MiB of the corpus round decoded at
-// 12.8 GiB/s).  For batches of at most kBatchLongMaxN streams the long ones
+// 12.8 GiB/s; now 34).  For batches of at most kBatchLongMaxN streams the long ones
 // (kLongStreamBatch compressed bytes and more that expand, k_long_plan; at
 // most kBatchLongMaxL of them) go the way of snapmi_decompress_stream instead - scan, cuts, pieces,
 // all long streams of the batch in the same launches (k_bstream_*) - and the
@@ -1168,7 +1176,7 @@ int launch_decompress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
 // hide behind each other, do not take it.
 // ---------------------------------------------------------------------
 constexpr size_t kBatchLongMaxN = 16384;
-constexpr uint32_t kBatchLongMaxL = 1024;
+constexpr uint32_t kBatchLongMaxL = 4096;
 constexpr uint64_t kLongStreamBatch = 32 << 10;
 
 #define BL_CHECK(name)                                                        \
@@ -1219,10 +1227,11 @@ static int decompress_batch_long(snapmi_ctx *ctx,
                                 hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
     const uint32_t found = *(const uint32_t *)ctx->pin_bl;
-    // (none - or so many that they fill the chip a wavefront each: 3 058
-    // streams of urls.10K decode at 288 GiB/s that way and at 194 through
-    // pieces, 1 100 long streams of the corpus round at 171 and 183: the
-    // caller goes on without modes)
+    // (none - or so many that they fill the chip a wavefront each: 3 670
+    // long streams in 1 GiB of the corpus round decode in 4.0 ms through
+    // pieces and in 5.9 a wavefront each, 3 058 streams of urls.10K at 314
+    // and 288 GiB/s, and the gain goes on shrinking: the caller goes on
+    // without modes)
     if (found == 0 || found > kBatchLongMaxL)
         return SNAPMI_OK;
     const uint32_t L = found;
@@ -1353,6 +1362,16 @@ static int decompress_batch_long(snapmi_ctx *ctx,
             b.n = L;
             return b;
         };
+        // the batch's other streams beside all this, on the second stream
+        // (their longest is 0.6-0.8 ms of one wavefront on the corpus)
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+        if ((rc = launch_decompress(ctx, d_in_ptrs, d_in_lens, d_out_ptrs,
+                                    d_out_caps, d_out_lens, d_errs, modes, n,
+                                    nullptr, 0, ctx->stream2,
+                                    &ctx->bl_order)))
+            return rc;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
         hipLaunchKernelGGL(k_bstream_head, dim3(L), dim3(1), 0, s, B(-1));
         BL_CHECK(k_bstream_head);
         hipLaunchKernelGGL(k_bstream_scan, dim3(grid[kPScan]), dim3(64), 0, s,
@@ -1378,18 +1397,16 @@ static int decompress_batch_long(snapmi_ctx *ctx,
         hipLaunchKernelGGL(k_bstream_pieces, dim3(grid[kPPieces]), dim3(256),
                            0, s, B(kPPieces));
         BL_CHECK(k_bstream_pieces);
-        // the batch's other streams; the pieces of the long ones; which of
-        // the long ones were irregular; those, by the wavefront decoder
-        if ((rc = launch_decompress(ctx, d_in_ptrs, d_in_lens, d_out_ptrs,
-                                    d_out_caps, d_out_lens, d_errs, modes,
-                                    n)) ||
-            (rc = launch_decompress(ctx, c_in, (const uint64_t *)c_inlen,
+        // the pieces of the long streams; which of the long ones were
+        // irregular; those, by the wavefront decoder
+        if ((rc = launch_decompress(ctx, c_in, (const uint64_t *)c_inlen,
                                     c_out, (const uint64_t *)c_cap,
                                     (uint64_t *)c_outlen, c_err, c_mode,
                                     pieces)))
             return rc;
         hipLaunchKernelGGL(k_bstream_finish, dim3(L), dim3(1024), 0, s, B(-1));
         BL_CHECK(k_bstream_finish);
+        HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
         if ((rc = launch_decompress(ctx, d_in_ptrs, d_in_lens, d_out_ptrs,
                                     d_out_caps, d_out_lens, d_errs, modes2,
                                     n)))

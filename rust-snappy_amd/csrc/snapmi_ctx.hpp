@@ -142,7 +142,7 @@ struct snapmi_ctx {
     // batch's own launch and of the one behind, what k_long_plan found, the
     // streams' descriptors and workgroup prefixes; pinned staging of both
     int batch_long_streams = 1;
-    snapmi::DevBuf bl_modes, bl_list, bl_descs;
+    snapmi::DevBuf bl_modes, bl_list, bl_descs, bl_order;
     void *pin_bl = nullptr;
     size_t pin_bl_cap = 0;
     // frame layer scratch (snapmi_frame.hip)
@@ -242,5 +242,8 @@ int launch_decompress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                       const uint64_t *d_out_caps, uint64_t *d_out_lens,
                       snapmi_error *d_errs, const uint8_t *d_modes, size_t n,
                       const unsigned long long *d_gate = nullptr,
-                      unsigned long long gate_value = 0);
+                      unsigned long long gate_value = 0,
+                      // a launch beside the context's stream: its stream and
+                      // its own dispatch-order scratch (no timing events)
+                      hipStream_t side = nullptr, DevBuf *side_order = nullptr);
 } // namespace snapmi
