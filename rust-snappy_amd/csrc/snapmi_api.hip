@@ -1407,9 +1407,10 @@ static int decompress_batch_long(snapmi_ctx *ctx,
         hipLaunchKernelGGL(k_bstream_finish, dim3(L), dim3(1024), 0, s, B(-1));
         BL_CHECK(k_bstream_finish);
         HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+        // (without timing events: snapmi_last_timing reports the pieces)
         if ((rc = launch_decompress(ctx, d_in_ptrs, d_in_lens, d_out_ptrs,
                                     d_out_caps, d_out_lens, d_errs, modes2,
-                                    n)))
+                                    n, nullptr, 0, s, nullptr)))
             return rc;
     }
     *done = true;
