@@ -633,8 +633,10 @@ def sink_n(sink, framed):
 def stream(args, ctx, dev):
     """ONE raw stream of --gib (the 12 corpus files repeated): compressed as
     one Encoder::compress call (blocks in parallel), decoded by
-    snapmi_decompress_stream (many wavefronts) and, for comparison, as a
-    batch of one stream (a single wavefront, 1/16 of the data)."""
+    snapmi_decompress_stream (many wavefronts) and, for comparison, 1/16 of
+    it as a batch of one stream: through snapmi_decompress_batch as it is
+    (the long stream gets its pieces) and with batch_long_streams 0 (a
+    single wavefront)."""
     import oracle_lib as O
     from rust_snappy_amd import batch, raw
     blob = b"".join(d for _, d in O.corpus_round())
@@ -677,11 +679,17 @@ def stream(args, ctx, dev):
     def dec1():
         raw.decompress_batch(ctx, comp.d_ptrs, clen, optr, cap1, out_len, None)
 
-    t1 = time_it(dec1, 1, ctx)
+    tb = time_it(dec1, 2, ctx)    # the batch call: the stream gets its pieces
+    ctx.set_option("batch_long_streams", 0)
+    try:
+        t1 = time_it(dec1, 1, ctx)   # ... and a wavefront to itself
+    finally:
+        ctx.set_option("batch_long_streams", 1)
     return {"config": "one raw stream, device resident",
             "gib": round(n / GIB, 3), "ratio": round(c / n, 4),
             "decompress_stream_gibs": round(n / GIB / td, 2),
             "decompress_stream_ms": round(td * 1e3, 2),
+            "batch_of_one_gibs": round(m / GIB / tb, 2),
             "one_wavefront_gibs": round(m / GIB / t1, 3),
             "one_wavefront_gib": round(m / GIB, 3)}
 

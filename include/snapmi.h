@@ -180,7 +180,8 @@ const char *snapmi_version(void);
  *                          kernel, one synchronisation of the context's
  *                          stream, ~30 us) and decodes up to 4 096 long
  *                          streams in it - 32 KiB compressed or more that
- *                          expand - through their 64 KiB pieces, like
+ *                          expand by half, 256 KiB or more of anything -
+ *                          through their 64 KiB pieces, like
  *                          snapmi_decompress_stream, instead of one wavefront
  *                          each (a batch otherwise waits 3-5 ms for a 700 KB
  *                          stream); 0: never, the call only enqueues
@@ -283,8 +284,10 @@ int snapmi_decompress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
  * cut), or with any error, is decoded by the sequential path, so results and
  * errors are those of snapmi_decompress_batch with n = 1.  Asynchronous on
  * the context's stream; d_out_len[0] / d_err[0] as in the batch call.
- * The scalar entry points use it for inputs of 128 KiB and more, and of
- * 64 KiB and more that announce 256 KiB of output.
+ * The scalar entry points use it for inputs of 32 KiB and more that announce
+ * half as much output again (and 96 KiB or more), and from 256 KiB on for
+ * any input - the rule snapmi_decompress_batch applies to the long streams
+ * of a batch.
  */
 int snapmi_decompress_stream(snapmi_ctx *ctx, const void *d_in,
                              uint64_t in_len, void *d_out, uint64_t out_cap,

@@ -1167,7 +1167,7 @@ int launch_decompress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
 // one wavefront, 0.14 GiB/s, so the 702 KB of urls.10K are 4.9 ms whatever
 // else the batch holds (extras.sweep: 64 MiB of the corpus round decoded at
 // 12.8 GiB/s; now 34).  For batches of at most kBatchLongMaxN streams the long ones
-// (kLongStreamBatch compressed bytes and more that expand, k_long_plan; at
+// (long_stream_rule, k_long_plan; at
 // most kBatchLongMaxL of them) go the way of snapmi_decompress_stream instead - scan, cuts, pieces,
 // all long streams of the batch in the same launches (k_bstream_*) - and the
 // batch's own launch skips them (mode 3).  The price is one look at the
@@ -1175,9 +1175,27 @@ int launch_decompress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
 // synchronisation: ~30 us), which is why large batches, whose long streams
 // hide behind each other, do not take it.
 // ---------------------------------------------------------------------
+// compressed bytes from which a stream can be worth its pieces
+// (long_stream_rule; the test build reads SNAPMI_LONG_STREAM: the scalar
+// entry points and snapmi_decompress_batch both use it).  Measured per bench
+// input at 16 / 64 / 256 KiB (profiles/r4_scalar_latency.txt): the ten small
+// launches of the scan cost ~0.5 ms, a wavefront decodes 100-250 MB/s of
+// text: html (23 KB) 0.62 -> 0.73 ms through pieces, kppkn.gtb's 69 KB
+// 2.12 -> 1.43, urls.10K 4.7 -> 1.3, fireworks.jpeg (literals) 0.17 -> 0.40
+static size_t long_stream_min()
+{
+    static const size_t v = [] {
+#ifdef SNAPMI_TESTING
+        if (const char *e = getenv("SNAPMI_LONG_STREAM"))
+            return (size_t)atoll(e);
+#endif
+        return (size_t)(32 << 10);
+    }();
+    return v;
+}
+
 constexpr size_t kBatchLongMaxN = 16384;
 constexpr uint32_t kBatchLongMaxL = 4096;
-constexpr uint64_t kLongStreamBatch = 32 << 10;
 
 #define BL_CHECK(name)                                                        \
     do {                                                                      \
@@ -1220,7 +1238,8 @@ static int decompress_batch_long(snapmi_ctx *ctx,
     HIP_TRY(ctx, hipMemsetAsync(d_count, 0, 16, s));
     hipLaunchKernelGGL(k_long_plan, dim3(1), dim3(1024), 0, s, d_in_ptrs,
                        d_in_lens, d_out_ptrs, d_out_caps, (uint32_t)n,
-                       kLongStreamBatch, modes, d_list, kBatchLongMaxL,
+                       (uint64_t)long_stream_min(), modes, d_list,
+                       kBatchLongMaxL,
                        d_count);
     BL_CHECK(k_long_plan);
     HIP_TRY(ctx, hipMemcpyAsync(ctx->pin_bl, ctx->bl_list.p, list_bytes,
@@ -1686,20 +1705,6 @@ struct OneDesc {
 // staging (one host memcpy each way, no pageable device copy)
 constexpr size_t kPinStage = 8u << 20;
 
-// compressed bytes from which the scalar decompress entry points use
-// snapmi_decompress_stream (one stream on many wavefronts).  The ten small
-// launches of the hierarchical scan cost ~0.5 ms; a single wavefront decodes
-// 100-250 MB/s: measured per bench input at 16 KiB and at 256 KiB
-// (profiles/r4_scalar_latency.txt: the test build reads SNAPMI_LONG_STREAM),
-// the scan pays from ~150 KB of compressed input on (lcet10.txt 3.6 -> 2.0
-// ms) and costs below (html 0.61 -> 0.89 ms, fireworks.jpeg 0.14 -> 0.50)
-static const size_t kLongStream = [] {
-#ifdef SNAPMI_TESTING
-    if (const char *e = getenv("SNAPMI_LONG_STREAM"))
-        return (size_t)atoll(e);
-#endif
-    return (size_t)(128 << 10);
-}();
 
 // pinned host staging of a context (grow-only): pageable copies go through
 // the runtime's own staging buffer one at a time, process-wide - eight
@@ -1781,18 +1786,17 @@ int run_one(snapmi_ctx *ctx, bool compress, const uint8_t *input,
         rc = snapmi_compress_batch(ctx, &d->in_ptr, &d->in_len, &hl,
                                    &d->out_ptr, &d->out_cap, &d->out_len,
                                    &d->err, 1);
-    } else if (input_len >= kLongStream ||
-               (input_len >= kLongStream / 2 && dl >= 4 * (size_t)kStreamChunk)) {
+    } else if (long_stream_rule(input_len, dl, long_stream_min())) {
         // one wavefront decodes ~140 MB/s: long streams go through the
-        // parallel single-stream path - and so do half as long ones that
-        // announce four pieces of output or more (html x4: 2.20 -> 1.23 ms;
-        // profiles/r4_scalar_latency.txt)
+        // parallel single-stream path
         rc = snapmi_decompress_stream(ctx, ctx->st_in.p, input_len,
                                       ctx->st_out.p, output_cap, &d->out_len,
                                       &d->err);
     } else {
-        rc = snapmi_decompress_batch(ctx, &d->in_ptr, &d->in_len, &d->out_ptr,
-                                     &d->out_cap, &d->out_len, &d->err, 1);
+        // (straight to the wavefront decoder: the host has just made the
+        // decision snapmi_decompress_batch would wait for the device to make)
+        rc = launch_decompress(ctx, &d->in_ptr, &d->in_len, &d->out_ptr,
+                               &d->out_cap, &d->out_len, &d->err, nullptr, 1);
     }
     if (rc)
         return rc;

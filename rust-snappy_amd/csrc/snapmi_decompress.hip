@@ -2703,10 +2703,9 @@ SNAPMI_STREAM_KERNEL(cuts, 64, stream_cuts(a, wg))
 SNAPMI_STREAM_KERNEL(pieces, 256, stream_pieces(a, wg))
 SNAPMI_STREAM_KERNEL(finish, 1024, stream_finish(a, wg))
 
-// The long streams of a batch: those of min_len compressed bytes and more
-// whose header announces 96 KiB of output or more, and no more than the
-// elements could produce and the caller's buffer holds (anything else is left
-// to the wavefront decoder, which names the error).  modes[i] = 3 for them (the
+// The long streams of a batch (long_stream_rule) whose header announces no
+// more than the caller's buffer holds (anything else is left to the wavefront
+// decoder, which names the error).  modes[i] = 3 for them (the
 // batch's own launch skips them), 0 for the others.
 __global__ __launch_bounds__(1024) void k_long_plan(
     const void *const *in_ptrs, const uint64_t *in_lens, void *const *out_ptrs,
@@ -2719,11 +2718,7 @@ __global__ __launch_bounds__(1024) void k_long_plan(
         if (len >= min_len) {
             uint64_t dl = 0;
             const uint32_t hdr = read_varint((gcptr)in_ptrs[i], len, &dl);
-            // (one and a half pieces of output or more, and half as much
-            // again as the input: the elements are what a wavefront is slow
-            // at, a stream of literals it copies at 0.85 GB/s)
-            if (hdr && 2 * dl >= 3 * (uint64_t)kStreamChunk &&
-                2 * dl >= 3 * len && dl <= out_caps[i] && dl / 22 <= len) {
+            if (hdr && dl <= out_caps[i] && long_stream_rule(len, dl, min_len)) {
                 const uint32_t slot = atomicAdd(count, 1u);
                 if (slot < cap) {
                     LongItem it;

@@ -169,6 +169,19 @@ struct BatchStreams {
     const uint32_t *pre; // [n + 1]
     uint32_t n;
 };
+// Is a raw stream of `len` compressed bytes that announces `dl` bytes of
+// output worth cutting into pieces (ten small launches, ~0.5 ms, instead of
+// one wavefront at 0.14 GiB/s of elements or 0.85 GB/s of literal bytes)?
+// From min_len (32 KiB) on when it expands by half and fills a piece and a
+// half; from 256 KiB on whatever it holds (profiles/r4_scalar_latency.txt).
+__host__ __device__ inline bool long_stream_rule(unsigned long long len,
+                                                 unsigned long long dl,
+                                                 unsigned long long min_len)
+{
+    const bool sane = dl / 22 <= len && 2 * dl >= 3ull * kStreamChunk;
+    return sane && len >= min_len &&
+           (2 * dl >= 3 * len || len >= (256ull << 10));
+}
 struct LongItem { // what k_long_plan hands to the host
     uint32_t idx, pad;
     unsigned long long in_len, dlen;

@@ -18,7 +18,7 @@ find $R/gpurun_out/prof_$tag -type f -size +4M -delete
 # one Encoder::compress / Decoder::decompress call per bench input: the
 # product library's rule, then the test build at four long-stream thresholds
 cd $R
-{ echo "# product library (long streams: 128 KiB of input, or 64 KiB that announce 256 KiB of output)";
+{ echo "# product library (pieces for inputs of 32 KiB and more that expand by half, and of 256 KiB and more)";
   python tests/hw/scalar_latency.py 2>/dev/null;
   for t in 16384 65536 262144; do echo "# test build, SNAPMI_LONG_STREAM=$t";
     SNAPMI_TESTING=1 SNAPMI_LONG_STREAM=$t python tests/hw/scalar_latency.py 2>/dev/null | cut -c1-76; done; } > $R/gpurun_out/scalar_latency_$tag.txt
