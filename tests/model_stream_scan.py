@@ -1,0 +1,159 @@
+"""k_stream_scan (rust-snappy_amd/csrc/snapmi_decompress.hip) as a model: the
+level-1 table of snapmi_decompress_stream - for every 4 KiB segment and every
+entry offset o < 8, where the chain that starts at byte o leaves the segment
+(the first element start at or behind the segment's end within 8 bytes of a
+segment boundary, or the end of the stream) and what it has produced.
+
+naive_table() is the definition (rounds 1-3: one walk per entry).  pooled_table()
+is what the kernel of round 4 does per wavefront of 64 segments: phase A walks
+every entry 128 bytes far; entries that stand where entry 0 of their segment
+stands share its trunk; a walk that overruns its segment stands 128 bytes into
+the next one and, if that is where that segment's trunk started, is that trunk
+from there on (links to higher segments, resolved from the last one down).
+tests/test_model_cpu.py compares the two."""
+
+SEG, ENTRY, MID, OVERRUN = 4096, 8, 128, 8192
+
+
+def step(comp, p):
+    """position behind the element at p and what it produces; None if it
+    does not fit (elem_step)"""
+    n = len(comp)
+    tag = comp[p]
+    t = tag & 3
+    if t == 0:
+        n6 = tag >> 2
+        if n6 < 60:
+            q, out = p + n6 + 2, n6 + 1
+        else:
+            nb = n6 - 59
+            if p + 1 + nb > n:
+                return None
+            ln = int.from_bytes(comp[p + 1:p + 1 + nb], "little") + 1
+            q, out = p + 1 + nb + ln, ln
+    else:
+        q = p + (2 if t == 1 else 3 if t == 2 else 5)
+        out = 4 + ((tag >> 2) & 7) if t == 1 else 1 + (tag >> 2)
+    return (q, out) if q <= n else None
+
+
+def more(comp, p, end):
+    return p < len(comp) and (p < end or (p & (SEG - 1)) >= ENTRY)
+
+
+def seg_end(comp, s):
+    return min((s + 1) * SEG, len(comp))
+
+
+def naive_walk(comp, s, p, cap=OVERRUN):
+    """(exit, produced) of the chain from p for segment s, or (None, .)"""
+    end, out, over = seg_end(comp, s), 0, 0
+    while more(comp, p, end):
+        if p >= end:
+            over += 1
+            if cap is not None and over > cap:
+                return None, out
+        r = step(comp, p)
+        if r is None:
+            return None, out
+        p, out = r[0], out + r[1]
+    return p, out
+
+
+def naive_table(comp):
+    nseg = (len(comp) + SEG - 1) // SEG
+    tab = {}
+    for s in range(nseg):
+        for o in range(ENTRY):
+            p = s * SEG + o
+            tab[(s, o)] = naive_walk(comp, s, p) if p < len(comp) \
+                else (None, 0)
+    return tab
+
+
+def pooled_table(comp, stats=None):
+    nseg = (len(comp) + SEG - 1) // SEG
+    tab = {}
+    for w0 in range(0, nseg, 64):
+        nloc = min(64, nseg - w0)
+        mid = {}                                  # (sl, o) -> (pos, out) | None
+        # ---- phase A
+        for sl in range(nloc):
+            s, end = w0 + sl, seg_end(comp, w0 + sl)
+            for o in range(ENTRY):
+                p, out, ok = s * SEG + o, 0, True
+                if p >= len(comp):
+                    tab[(s, o)] = (None, 0)
+                    mid[(sl, o)] = None
+                    continue
+                while more(comp, p, end) and p < s * SEG + MID:
+                    r = step(comp, p)
+                    if r is None:
+                        ok = False
+                        break
+                    p, out = r[0], out + r[1]
+                if ok and more(comp, p, end):
+                    mid[(sl, o)] = (p, out)        # stands at the stop
+                else:
+                    mid[(sl, o)] = None            # over, or cannot be followed
+                    tab[(s, o)] = (p if ok else None, out)
+        # ---- phase B: trunks (from the last segment down) and the others
+        def walk(sl, p, out):
+            """-> ('exit', pos | None, out) or ('link', t, out)"""
+            end, over = seg_end(comp, w0 + sl), 0
+            stop = (w0 + sl + 1) * SEG + MID if sl + 1 < nloc else None
+            while more(comp, p, end):
+                if stop is not None and p >= stop:
+                    t = p // SEG - w0
+                    if t < nloc and mid[(t, 0)] is not None and \
+                            mid[(t, 0)][0] == p:
+                        return "link", t, out
+                    stop = (w0 + t + 1) * SEG + MID if t + 1 < nloc else None
+                    continue
+                if p >= end:
+                    over += 1
+                    if over > OVERRUN:
+                        return "exit", None, out
+                r = step(comp, p)
+                if r is None:
+                    return "exit", None, out
+                p, out = r[0], out + r[1]
+            return "exit", p, out
+        trunk = {}
+        others = []
+        for sl in reversed(range(nloc)):
+            m0 = mid[(sl, 0)]
+            trunk[sl] = walk(sl, m0[0], 0) if m0 is not None else None
+            for o in range(1, ENTRY):
+                m = mid[(sl, o)]
+                if m is not None and (m0 is None or m[0] != m0[0]):
+                    others.append((sl, o, walk(sl, m[0], m[1])))
+        res = {}
+        for sl in reversed(range(nloc)):           # links go up: resolve down
+            t = trunk[sl]
+            if t is None:
+                continue
+            if t[0] == "link":
+                up = res[t[1]]
+                res[sl] = (up[0], t[2] + up[1])
+            else:
+                res[sl] = (t[1], t[2])
+        for sl in range(nloc):
+            m0 = mid[(sl, 0)]
+            for o in range(ENTRY):
+                m = mid[(sl, o)]
+                if m is not None and m0 is not None and m[0] == m0[0]:
+                    tab[(w0 + sl, o)] = (res[sl][0], res[sl][1] + m[1])
+        for sl, o, r in others:
+            if r[0] == "link":
+                up = res[r[1]]
+                tab[(w0 + sl, o)] = (up[0], r[2] + up[1])
+            else:
+                tab[(w0 + sl, o)] = (r[1], r[2])
+        if stats is not None:
+            stats["links"] = stats.get("links", 0) + sum(
+                1 for t in trunk.values() if t and t[0] == "link")
+            stats["others"] = stats.get("others", 0) + len(others)
+            stats["trunks"] = stats.get("trunks", 0) + sum(
+                1 for t in trunk.values() if t)
+    return tab
