@@ -263,7 +263,10 @@ int snapmi_compress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
  * A stream is decoded by one wavefront - except the long streams of a batch
  * of at most 16 384 streams, which are cut into pieces like the one stream of
  * snapmi_decompress_stream (option "batch_long_streams": that look at the
- * batch waits once for the context's stream).
+ * batch waits once for the context's stream, so with it the call is NOT
+ * enqueue-only.  A host that pipelines many small batches from one thread
+ * sets the option to 0; while the context's stream is being captured into a
+ * hipGraph the look is skipped by itself and the call only enqueues).
  */
 int snapmi_decompress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                             const uint64_t *d_in_lens,

@@ -61,6 +61,26 @@ size_t host_varint(const uint8_t *p, size_t n, uint64_t *value)
 
 } // namespace
 
+namespace snapmi {
+// option release_scratch: the compressor's per-batch scratch goes back to
+// the allocator.  Only behind a synchronisation of ctx->stream (nothing of a
+// batch is in flight): snapmi_ctx_synchronize and the scalar / libsnappy
+// entry points, which wait for their result anyway.
+int release_batch_scratch(snapmi_ctx *ctx)
+{
+    if (!ctx->release_scratch)
+        return SNAPMI_OK;
+    for (DevBuf *b : {&ctx->tokens, &ctx->slots}) {
+        if (b->p) {
+            HIP_TRY(ctx, hipFree(b->p));
+            b->p = nullptr;
+            b->cap = 0;
+        }
+    }
+    return SNAPMI_OK;
+}
+} // namespace snapmi
+
 extern "C" {
 
 const char *snapmi_version(void) { return "snapmi 0.1.0 gfx950"; }
@@ -424,17 +444,7 @@ int snapmi_ctx_synchronize(snapmi_ctx *ctx)
         return SNAPMI_E_ARGUMENT;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->release_scratch) {
-        // (option release_scratch: nothing of the batch is in flight now)
-        for (snapmi::DevBuf *b : {&ctx->tokens, &ctx->slots}) {
-            if (b->p) {
-                HIP_TRY(ctx, hipFree(b->p));
-                b->p = nullptr;
-                b->cap = 0;
-            }
-        }
-    }
-    return SNAPMI_OK;
+    return snapmi::release_batch_scratch(ctx);
 }
 
 size_t snapmi_max_compress_len(size_t input_len)
@@ -1385,12 +1395,31 @@ static int decompress_batch_long(snapmi_ctx *ctx,
         // (their longest is 0.6-0.8 ms of one wavefront on the corpus)
         HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+        // from here on every way out joins the side stream again: whatever
+        // it was given still writes the caller's arrays and reads bl_modes /
+        // bl_order, which the next call reuses
+        struct SideJoin {
+            snapmi_ctx *c;
+            hipStream_t s;
+            bool joined = false;
+            void join()
+            {
+                if (joined)
+                    return;
+                joined = true;
+                if (hipEventRecord(c->ev_join, c->stream2) != hipSuccess ||
+                    hipStreamWaitEvent(s, c->ev_join, 0) != hipSuccess) {
+                    (void)hipGetLastError();
+                    (void)hipStreamSynchronize(c->stream2);
+                }
+            }
+            ~SideJoin() { join(); }
+        } side{ctx, s};
         if ((rc = launch_decompress(ctx, d_in_ptrs, d_in_lens, d_out_ptrs,
                                     d_out_caps, d_out_lens, d_errs, modes, n,
                                     nullptr, 0, ctx->stream2,
                                     &ctx->bl_order)))
             return rc;
-        HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
         hipLaunchKernelGGL(k_bstream_head, dim3(L), dim3(1), 0, s, B(-1));
         BL_CHECK(k_bstream_head);
         hipLaunchKernelGGL(k_bstream_scan, dim3(grid[kPScan]), dim3(64), 0, s,
@@ -1425,7 +1454,7 @@ static int decompress_batch_long(snapmi_ctx *ctx,
             return rc;
         hipLaunchKernelGGL(k_bstream_finish, dim3(L), dim3(1024), 0, s, B(-1));
         BL_CHECK(k_bstream_finish);
-        HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+        side.join();
         // (without timing events: snapmi_last_timing reports the pieces)
         if ((rc = launch_decompress(ctx, d_in_ptrs, d_in_lens, d_out_ptrs,
                                     d_out_caps, d_out_lens, d_errs, modes2,
@@ -1453,7 +1482,16 @@ int snapmi_decompress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     if (!d_in_ptrs || !d_in_lens || !d_out_ptrs || !d_out_caps ||
         !d_out_lens || n > 0x7FFFFFFFu)
         return fail_ctx(ctx, SNAPMI_E_ARGUMENT, "decompress_batch: bad args");
-    if (ctx->batch_long_streams && n <= kBatchLongMaxN) {
+    // (the look at the batch waits for the device once: never while the
+    // caller's stream is being captured into a graph - such a caller gets the
+    // enqueue-only path, a wavefront per stream)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(ctx->stream, &cap) != hipSuccess) {
+        (void)hipGetLastError();
+        cap = hipStreamCaptureStatusNone;
+    }
+    if (ctx->batch_long_streams && n <= kBatchLongMaxN &&
+        cap == hipStreamCaptureStatusNone) {
         bool done = false;
         const int rc = decompress_batch_long(ctx, d_in_ptrs, d_in_lens,
                                              d_out_ptrs, d_out_caps,
@@ -1809,6 +1847,8 @@ int run_one(snapmi_ctx *ctx, bool compress, const uint8_t *input,
                                     dev_out, hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(ctx, hipStreamSynchronize(s));
+    if (compress && (rc = release_batch_scratch(ctx)))
+        return rc;
     const OneDesc &h = hd[1];
     if (err)
         *err = h.err;

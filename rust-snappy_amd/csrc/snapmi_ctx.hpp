@@ -75,8 +75,10 @@ struct snapmi_ctx {
     // 1: the per-batch scratch of the compressor (token arrays: 128 KiB per
     // block of a lane-kernel segment, up to 34 GB; block slots of the
     // wavefront kernels) is given back when the batch's results are waited
-    // for (snapmi_ctx_synchronize, snapmi_last_timing, the scalar and host
-    // entry points) instead of being kept for the next batch.  For a host
+    // for (snapmi_ctx_synchronize; the scalar and libsnappy entry points,
+    // which wait for their own result) instead of being kept for the next
+    // batch.  snapmi_last_timing waits for events only and the host frame
+    // calls keep their pipeline's scratch: neither frees.  For a host
     // that compresses now and then and shares the GPU; costs a hipFree /
     // hipMalloc pair per batch.  The lane tables are not scratch: they are
     // bounded by lane_table_budget_pct.

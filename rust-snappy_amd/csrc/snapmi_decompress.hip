@@ -2357,7 +2357,9 @@ __device__ __forceinline__ void stream_scan(const StreamArgs &a, const uint32_t 
     const uint64_t seg0 = (uint64_t)wg * 64;
     h.wbase = seg0 * kSeg;
     h.mis = (uint32_t)((uintptr_t)a.in + h.wbase) & (kHopLine - 1);
-    const uint64_t left = a.in_len - h.wbase; // > 0: the grid covers nseg
+    // the grid covers nseg + 1 sentinel: its last workgroup can begin behind
+    // the input (lastR = 0 then: every walk is invalid and reads nothing)
+    const uint64_t left = a.in_len > h.wbase ? a.in_len - h.wbase : 0;
     h.lastR = left < (1ull << 31) ? (uint32_t)left : 1u << 31;
     h.lastP = left + h.mis;
     const uint32_t nloc =
@@ -2530,7 +2532,7 @@ __device__ __forceinline__ void stream_cuts(const StreamArgs &a, const uint32_t 
     h.in_len = a.in_len;
     h.wbase = seg0 * kSeg;
     h.mis = (uint32_t)((uintptr_t)a.in + h.wbase) & (kHopLine - 1);
-    const uint64_t left = a.in_len - h.wbase;
+    const uint64_t left = a.in_len > h.wbase ? a.in_len - h.wbase : 0;
     h.lastR = left < (1ull << 31) ? (uint32_t)left : 1u << 31;
     h.lastP = left + h.mis;
     hop_lut(lutbuf);
