@@ -1037,6 +1037,58 @@ template <class OUT> struct SpanSink {
 };
 } // namespace
 
+// the wave of span_par_walk (snapmi_span.hpp) on the hardware
+struct WaveDev {
+    typedef uint32_t u32;
+    typedef bool b1;
+    uint32_t l;
+    __device__ __forceinline__ u32 lane() const { return l; }
+    __device__ __forceinline__ u32 sel(b1 c, u32 a, u32 b) const
+    {
+        return c ? a : b;
+    }
+    __device__ __forceinline__ b1 lt(u32 a, u32 b) const { return a < b; }
+    __device__ __forceinline__ b1 ge(u32 a, u32 b) const { return a >= b; }
+    __device__ __forceinline__ b1 eq(u32 a, u32 b) const { return a == b; }
+    __device__ __forceinline__ b1 band(b1 a, b1 b) const { return a & b; }
+    __device__ __forceinline__ b1 bor(b1 a, b1 b) const { return a | b; }
+    __device__ __forceinline__ b1 bnot(b1 a) const { return !a; }
+    __device__ __forceinline__ uint64_t ballot(b1 a) const
+    {
+        return __builtin_amdgcn_ballot_w64(a);
+    }
+    __device__ __forceinline__ u32 bperm(u32 idx, u32 v) const
+    {
+        return (u32)__builtin_amdgcn_ds_bpermute((int)(idx << 2), (int)v);
+    }
+    __device__ __forceinline__ uint32_t readlane(u32 v, uint32_t i) const
+    {
+        return rdlane(v, i);
+    }
+    __device__ __forceinline__ b1 bit(uint64_t mask, u32 i) const
+    {
+        return ((uint32_t)(mask >> i) & 1u) != 0;
+    }
+    __device__ __forceinline__ u32 next_bit(uint64_t mask, u32 t) const
+    {
+        const uint64_t x = mask >> t;
+        return x ? t + (u32)__builtin_ctzll(x) : 64u;
+    }
+    __device__ __forceinline__ u32 prev_bit(uint64_t mask, u32 t) const
+    {
+        const uint64_t x = mask & ((1ull << t) - 1);
+        return x ? 63u - (u32)__builtin_clzll(x) : 64u;
+    }
+    __device__ __forceinline__ u32 bit_lo(u32 x) const
+    {
+        return x < 32 ? 1u << x : 0u;
+    }
+    __device__ __forceinline__ u32 bit_hi(u32 x) const
+    {
+        return x - 32u < 32u ? 1u << (x - 32u) : 0u;
+    }
+};
+
 template <bool kLds, bool kTok = false>
 __device__ __forceinline__ void compress_one_block_span(
     const CompressArgs &a, const uint32_t b, const uint32_t lane,
@@ -1253,14 +1305,48 @@ __device__ __forceinline__ void compress_one_block_span(
             ln.mv = common16(x, y);
             ln.ov = old;
             const bool cbit = active && old >= lo;
-            const uint64_t hits = __ballot(active && lane && ln.mv >= 4);
-            const uint64_t cbits = __ballot(cbit);
+            const uint64_t hits = __builtin_amdgcn_ballot_w64(
+                active && lane && ln.mv >= 4);
+            const uint64_t cbits = __builtin_amdgcn_ballot_w64(cbit);
             uint64_t touched = 0;
             uint32_t at = 0, rc = kSpanCont;
             st.next_emit = sink.emit;
             // the fast walk (snapmi_span.hpp): the scalar unit follows the
             // chain of copies, the lanes derive everything else at once
             bool fast = span_fast_ok(st, hits, n);
+#ifndef SNAPMI_SPAN_SCALAR_WALK
+            if (fast) {
+                // the lane-parallel walk (span_par_walk): the copies of the
+                // step by pointer jumping, everything else per lane
+                const WaveDev w{lane};
+                uint64_t vh;
+                uint32_t lit;
+                rc = span_par_walk(w, st, hits, cbits, ln.mv, old, cbit,
+                                   sink.emit, vh, lit, touched, at);
+                const uint32_t cnt = (uint32_t)__builtin_popcountll(vh);
+                if (cnt) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi(
+                        (uint32_t)(vh >> 32),
+                        __builtin_amdgcn_mbcnt_lo((uint32_t)vh, 0));
+                    const bool is_vh = (vh >> lane) & 1;
+                    // token of lane X goes to sink lane t + rank: a push
+                    // (ds_permute); the other lanes push to a lane outside
+                    // [t, t + cnt) whose value is not taken
+                    const uint32_t to =
+                        is_vh ? out.t + rank : (out.t + cnt) & 63u;
+                    const uint32_t ta = (lit & 0xFFFFu) | ((P - old) << 16);
+                    const uint32_t tb = ln.mv | ((P - lit) << 16);
+                    const uint32_t ra = (uint32_t)__builtin_amdgcn_ds_permute(
+                        (int)(to << 2), (int)ta);
+                    const uint32_t rb = (uint32_t)__builtin_amdgcn_ds_permute(
+                        (int)(to << 2), (int)tb);
+                    const bool got = lane - out.t < cnt;
+                    out.a = got ? ra : out.a;
+                    out.b = got ? rb : out.b;
+                    out.t += cnt;
+                }
+            }
+#else
             if (fast) {
                 const uint64_t longs =
                     __ballot(active && lane && ln.mv >= 16);
@@ -1288,9 +1374,6 @@ __device__ __forceinline__ void compress_one_block_span(
                     span_fast_token(lane, base, sink.emit, f.inside, vh, lit,
                                     rank);
                     const bool is_vh = (vh >> lane) & 1;
-                    // token of lane X goes to sink lane t + rank: a push
-                    // (ds_permute); the other lanes push to a lane outside
-                    // [t, t + cnt) whose value is not taken
                     const uint32_t to =
                         is_vh ? out.t + rank : (out.t + cnt) & 63u;
                     const uint32_t ta = (lit & 0xFFFFu) | ((P - old) << 16);
@@ -1307,6 +1390,7 @@ __device__ __forceinline__ void compress_one_block_span(
                 rc = span_fast_state(st, f, cut, sink.emit);
                 at = f.at;
             }
+#endif
             if (!fast)
                 rc = span_walk(st, hits, cbits, s_limit, ln, sink, touched,
                                at);

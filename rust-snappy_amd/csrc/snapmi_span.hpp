@@ -341,5 +341,144 @@ SNAPMI_LANE_FN uint32_t span_fast_state(SpanState &st, const SpanFast &f,
     return is_long ? kSpanLong : kSpanCont;
 }
 
+// ---------------------------------------------------------------------
+// The lane-parallel walk (round 5).  span_fast_walk above still follows the
+// chain of copies on the scalar unit - a v_readlane, ~14 scalar instructions
+// and a loop branch per copy, and the masks and the state behind it another
+// ~150 scalar instructions: half of a step's time at five wavefronts per CU,
+// where every instruction a lone wavefront issues costs 4-5 cycles.  But the
+// chain is pointer jumping over per-lane successors: behind a copy at hit lane
+// X (m bytes, ending inside the window) the next copy is at the first hit lane
+// at or behind X + m - a find-first-set every hit lane does for itself - so
+// the set of copies the reference emits is the orbit of the window's first
+// hit under that map.  A copy is 4 bytes or more: at most 16 in a window, and
+// four rounds of doubling (R |= R[frontier]: the set a lane reaches and the
+// last lane in it, three ds_bpermute per round) give every lane the orbit it
+// starts.  Everything else is per-lane arithmetic on the orbit of the first
+// hit: the copy below a lane and where it ends (one more ds_bpermute) say
+// whether the lane lies inside a copy, is its last byte (the insert of e - 1,
+// src/compress.rs:290-297), or is looked up; a token's literal starts where
+// the copy below ended.  ~70 vector + ~30 scalar instructions where the scalar
+// walk had ~100 + ~300, no loop.  The cut (an inserted lane with a C bit whose
+// lower lane is not inserted), one step in five on text, goes on through
+// span_fast_masks / span_fast_state above.
+//
+// W is the wave: per-lane values W::u32 / flags W::b1 with the operators of
+// uint32_t, and
+//   lane()               0..63
+//   sel(b, x, y)  lt / ge / eq(x, y)  band / bor / bnot
+//   ballot(b)            uniform 64-bit mask
+//   bperm(idx, v)        v of lane idx (0..63, any lane)
+//   readlane(v, l)       v of the uniform lane l
+//   bit(mask, i)         bit i (per lane, 0..63) of a uniform mask
+//   next_bit(mask, t)    lowest set bit >= t (per lane, 0..63) or 64
+//   prev_bit(mask, t)    highest set bit < t (per lane, 0..63) or 64
+//   bit_lo(x), bit_hi(x) the halves of 1 << x, x = 0..63
+// snapmi_compress.hip instantiates it over the hardware, tests/
+// span_wave_host.cpp over arrays of 64 - the same text - and
+// test_span_wave_cpu.py compares it with span_walk on random windows and the
+// streams it gives with the oracle's.
+// ---------------------------------------------------------------------
+#if defined(__HIPCC__)
+#define SNAPMI_WAVE_FN __device__ __forceinline__
+#else
+#define SNAPMI_WAVE_FN inline
+#endif
+
+// hits (lanes 1..63, at least one: span_fast_ok) / cbits as for span_walk;
+// m, old, cbit: this lane's match length, exchanged entry and C bit.
+// emit: in, the first byte not covered by a token; out, the same behind the
+// step.  Out: vh = lanes whose copy is a token of this step, lit = a vh
+// lane's literal length, touched = lanes the reference inserts, at = the lane
+// of a long match (kSpanLong).
+template <class W>
+SNAPMI_WAVE_FN uint32_t
+span_par_walk(const W &w, SpanState &st, const uint64_t hits,
+              const uint64_t cbits, const typename W::u32 m,
+              const typename W::u32 old, const typename W::b1 cbit,
+              uint32_t &emit, uint64_t &vh, typename W::u32 &lit,
+              uint64_t &touched, uint32_t &at)
+{
+    typedef typename W::u32 u32;
+    typedef typename W::b1 b1;
+    const uint32_t base = st.s, emit0 = emit;
+    const u32 lane = w.lane();
+    const b1 hit = w.bit(hits, lane);
+    // a hit lane's copy ends in front of lane `end`; it is the last of the
+    // step if it is long (the caller extends it) or reaches lane 63's insert
+    const u32 end = lane + m;
+    const b1 last = w.bor(w.ge(m, u32(16)), w.ge(end, u32(64)));
+    const u32 nx = w.next_bit(hits, w.sel(w.lt(end, u32(63)), end, u32(63)));
+    const b1 go = w.band(hit, w.band(w.bnot(last), w.lt(nx, u32(64))));
+    // R = the hit lanes reached from here, F = the last of them
+    u32 F = w.sel(go, nx, lane);
+    u32 Rlo = w.bit_lo(lane) | w.bit_lo(F), Rhi = w.bit_hi(lane) | w.bit_hi(F);
+    for (int r = 0; r < 4; r++) {
+        const u32 flo = w.bperm(F, Rlo), fhi = w.bperm(F, Rhi);
+        F = w.bperm(F, F);
+        Rlo = Rlo | flo;
+        Rhi = Rhi | fhi;
+    }
+    const uint32_t X0 = 1 + (uint32_t)__builtin_ctzll(hits >> 1);
+    const uint64_t V = (uint64_t)w.readlane(Rlo, X0) |
+                       ((uint64_t)w.readlane(Rhi, X0) << 32);
+    // the last copy of the step
+    const uint32_t Xl = 63u - (uint32_t)__builtin_clzll(V);
+    const uint32_t ml = w.readlane(m, Xl), el = Xl + ml;
+    const bool is_long = ml >= 16, is_out = !is_long & (el >= 64);
+    const uint32_t stop = is_long ? Xl + 1 : 64; // lanes 1 .. stop-1 walked
+    // the copy below this lane and where it ends
+    const u32 Xp = w.prev_bit(V, lane);
+    const b1 has = w.lt(Xp, u32(64));
+    const u32 eP = w.bperm(w.sel(has, Xp, lane), end);
+    const b1 in_range =
+        w.band(w.ge(lane, u32(1)), w.lt(lane, u32(stop)));
+    const b1 inside = w.band(has, w.lt(lane, eP));
+    const b1 looked = w.band(in_range, w.bnot(inside));
+    const b1 ins = w.band(w.band(in_range, inside),
+                          w.band(w.eq(lane + u32(1), eP),
+                                 w.lt(lane, u32(63))));
+    const b1 tb = w.bor(w.bor(looked, ins),
+                        w.band(w.eq(lane, u32(0)), w.ge(u32(st.chain), u32(1))));
+    const uint64_t T = w.ballot(tb);
+    // an inserted lane with a C bit needs the lane it collided with inserted
+    const u32 pred = (old - u32(base - 1)) & u32(63);
+    const uint64_t bad =
+        w.ballot(w.band(w.band(tb, cbit), w.bnot(w.bit(T, pred))));
+    lit = w.sel(has, lane - eP, lane + u32(base - 1 - emit0));
+    const uint64_t lbit = is_long ? 1ull << Xl : 0;
+    const bool prev = (V & ((1ull << Xl) - 1)) != 0; // a copy below the last
+    const uint32_t ePl = w.readlane(eP, Xl);
+    if (bad == 0) {
+        vh = V & ~lbit;
+        touched = T;
+        at = Xl;
+        if (is_long) {
+            emit = prev ? base - 1 + ePl : emit0;
+            st.s = base - 1 + Xl;
+            st.next_emit = emit;
+            return kSpanLong;
+        }
+        const uint32_t pe = base - 1 + el; // where the last copy ends
+        st.s = is_out ? pe : base + 63;
+        st.q = is_out ? 0 : 63 - el;
+        st.chain = is_out ? 1 : 0;
+        st.next_emit = pe;
+        emit = pe;
+        return kSpanCont;
+    }
+    // the step ends in front of lane `cut`
+    const uint32_t cut = (uint32_t)__builtin_ctzll(bad);
+    SpanFast f;
+    f.inside = w.ballot(w.band(inside, w.lt(lane, u32(stop)))) & ~1ull;
+    f.kind = is_long ? kFastLong : (is_out ? kFastCopyOut : kFastRun);
+    f.at = (is_long | is_out) ? Xl : el;
+    f.end = is_out ? el : 0;
+    span_fast_masks(f, hits, st.chain, cut, vh, touched);
+    at = f.at;
+    (void)cbits;
+    return span_fast_state(st, f, cut, emit);
+}
+
 } // namespace snapmi
 #endif

@@ -10,6 +10,7 @@
 // linked into the product library.
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string>
 #include <string.h>
 
@@ -84,6 +85,151 @@ struct Out {
             bad = 1;
         else
             memcpy(p + k, &v, 4);
+    }
+};
+
+// The wave of span_par_walk on the host: 64 values side by side, every
+// operator elementwise, the cross-lane operations as array gathers.
+struct HV {
+    uint32_t v[64];
+    HV() { memset(v, 0, sizeof v); }
+    explicit HV(uint32_t x)
+    {
+        for (int i = 0; i < 64; i++)
+            v[i] = x;
+    }
+};
+struct HB {
+    bool v[64];
+};
+#define HV_OP(op)                                                             \
+    HV operator op(const HV &a, const HV &b)                                  \
+    {                                                                         \
+        HV r;                                                                 \
+        for (int i = 0; i < 64; i++)                                          \
+            r.v[i] = a.v[i] op b.v[i];                                        \
+        return r;                                                             \
+    }
+HV_OP(+) HV_OP(-) HV_OP(&) HV_OP(|)
+#undef HV_OP
+struct WaveHost {
+    typedef HV u32;
+    typedef HB b1;
+    mutable uint64_t bperms = 0;
+    HV lane() const
+    {
+        HV r;
+        for (int i = 0; i < 64; i++)
+            r.v[i] = i;
+        return r;
+    }
+    HV sel(const HB &c, const HV &a, const HV &b) const
+    {
+        HV r;
+        for (int i = 0; i < 64; i++)
+            r.v[i] = c.v[i] ? a.v[i] : b.v[i];
+        return r;
+    }
+#define HB_CMP(name, op)                                                      \
+    HB name(const HV &a, const HV &b) const                                   \
+    {                                                                         \
+        HB r;                                                                 \
+        for (int i = 0; i < 64; i++)                                          \
+            r.v[i] = a.v[i] op b.v[i];                                        \
+        return r;                                                             \
+    }
+    HB_CMP(lt, <) HB_CMP(ge, >=) HB_CMP(eq, ==)
+#undef HB_CMP
+    HB band(const HB &a, const HB &b) const
+    {
+        HB r;
+        for (int i = 0; i < 64; i++)
+            r.v[i] = a.v[i] && b.v[i];
+        return r;
+    }
+    HB bor(const HB &a, const HB &b) const
+    {
+        HB r;
+        for (int i = 0; i < 64; i++)
+            r.v[i] = a.v[i] || b.v[i];
+        return r;
+    }
+    HB bnot(const HB &a) const
+    {
+        HB r;
+        for (int i = 0; i < 64; i++)
+            r.v[i] = !a.v[i];
+        return r;
+    }
+    uint64_t ballot(const HB &a) const
+    {
+        uint64_t m = 0;
+        for (int i = 0; i < 64; i++)
+            m |= (uint64_t)a.v[i] << i;
+        return m;
+    }
+    HV bperm(const HV &idx, const HV &val) const
+    {
+        HV r;
+        for (int i = 0; i < 64; i++) {
+            if (idx.v[i] > 63)
+                abort(); // the kernel's ds_bpermute would wrap silently
+            r.v[i] = val.v[idx.v[i]];
+        }
+        bperms++;
+        return r;
+    }
+    uint32_t readlane(const HV &val, uint32_t l) const
+    {
+        if (l > 63)
+            abort();
+        return val.v[l];
+    }
+    HB bit(uint64_t mask, const HV &i) const
+    {
+        HB r;
+        for (int k = 0; k < 64; k++) {
+            if (i.v[k] > 63)
+                abort();
+            r.v[k] = (mask >> i.v[k]) & 1;
+        }
+        return r;
+    }
+    HV next_bit(uint64_t mask, const HV &t) const
+    {
+        HV r;
+        for (int k = 0; k < 64; k++) {
+            if (t.v[k] > 63)
+                abort();
+            const uint64_t x = mask >> t.v[k];
+            r.v[k] = x ? t.v[k] + (uint32_t)__builtin_ctzll(x) : 64;
+        }
+        return r;
+    }
+    HV prev_bit(uint64_t mask, const HV &t) const
+    {
+        HV r;
+        for (int k = 0; k < 64; k++) {
+            if (t.v[k] > 63)
+                abort();
+            const uint64_t x = mask & ((1ull << t.v[k]) - 1);
+            r.v[k] = x ? 63u - (uint32_t)__builtin_clzll(x) : 64;
+        }
+        return r;
+    }
+    HV bit_lo(const HV &x) const
+    {
+        HV r;
+        for (int k = 0; k < 64; k++)
+            r.v[k] = x.v[k] < 32 ? 1u << x.v[k] : 0;
+        return r;
+    }
+    HV bit_hi(const HV &x) const
+    {
+        HV r;
+        for (int k = 0; k < 64; k++)
+            r.v[k] = x.v[k] >= 32 && x.v[k] < 64 ? 1u << (x.v[k] - 32) : 0;
+        return r;
     }
 };
 } // namespace
@@ -199,42 +345,30 @@ extern "C" uint32_t span_wave_compress(const uint8_t *src, uint32_t n,
         // exact walk otherwise
         bool fast = span_fast_ok(st, hits, n);
         if (fast) {
-            uint64_t longs = 0;
-            for (uint32_t l = 1; l < 64; l++)
-                if (act[l] && ln.mv[l] >= 16)
-                    longs |= 1ull << l;
-            SpanFast f;
-            span_fast_walk(hits, longs, ln, f);
-            uint64_t vh;
-            span_fast_masks(f, hits, st.chain, 64, vh, T);
-            uint32_t cut = 64;
+            WaveHost w;
+            HV m, old;
+            HB cb;
             for (uint32_t l = 0; l < 64; l++) {
-                const uint32_t pred = ln.ov[l] - (base - 1);
-                if (((T >> l) & 1) && ((cbits >> l) & 1) &&
-                    !((T >> (pred & 63)) & 1)) {
-                    cut = l;
-                    break;
-                }
+                m.v[l] = ln.mv[l];
+                old.v[l] = ln.ov[l];
+                cb.v[l] = (cbits >> l) & 1;
             }
-            if (cut < 64) {
-                stats[2]++;
-                span_fast_masks(f, hits, st.chain, cut, vh, T);
-            }
+            uint64_t vh;
+            HV lit;
+            uint32_t emit = st.next_emit;
+            const uint32_t emit0 = emit;
+            rc = span_par_walk(w, st, hits, cbits, m, old, cb, emit, vh, lit,
+                               T, at);
+            (void)emit0;
             stats[7]++;
             for (uint32_t l = 1; l < 64; l++) {
                 if (!((vh >> l) & 1))
                     continue;
-                uint32_t lit, rank;
-                span_fast_token(l, base, st.next_emit, f.inside, vh, lit,
-                                rank);
-                if (rank != sink.t.size() - tok0)
-                    return 0x80000002u;
                 const uint32_t P = base - 1 + l;
-                sink.token(lit, ln.mv[l], P - ln.ov[l]);
+                sink.token(lit.v[l], ln.mv[l], P - ln.ov[l]);
             }
-            uint32_t emit = st.next_emit;
-            rc = span_fast_state(st, f, cut, emit);
-            at = f.at;
+            if (st.next_emit != emit)
+                return 0x80000003u;
         }
         if (!fast)
             rc = span_walk(st, hits, cbits, s_limit, ln, sink, T, at);
@@ -407,6 +541,42 @@ extern "C" uint32_t span_walk_diff(uint32_t seed, uint32_t cases,
             return c;
         if (sa.s != sb.s || sa.next_emit != sb.next_emit)
             return c;
+        // ... and the lane-parallel walk (span_par_walk) against both
+        {
+            SpanState sc = st;
+            WaveHost w;
+            HV m, old;
+            HB cb;
+            for (uint32_t l = 0; l < 64; l++) {
+                m.v[l] = ln.mv[l];
+                old.v[l] = ln.ov[l];
+                cb.v[l] = (cbits >> l) & 1;
+            }
+            uint64_t vhc, Tc;
+            HV lit;
+            uint32_t emitc = st.next_emit, atc = 0;
+            const uint32_t rcc = span_par_walk(w, sc, hits, cbits, m, old, cb,
+                                               emitc, vhc, lit, Tc, atc);
+            if (rcc != ra || Tc != Ta || sc.s != sa.s ||
+                sc.next_emit != sa.next_emit || emitc != sa.next_emit)
+                return c;
+            if ((uint32_t)__builtin_popcountll(vhc) != ka.t.size())
+                return c;
+            size_t i = 0;
+            for (uint32_t l = 1; l < 64; l++) {
+                if (!((vhc >> l) & 1))
+                    continue;
+                if (ka.t[i].lit != lit.v[l] || ka.t[i].len != ln.mv[l] ||
+                    ka.t[i].off != base - 1 + l - ln.ov[l])
+                    return c;
+                i++;
+            }
+            if (ra == kSpanLong && atc != ata)
+                return c;
+            if (ra != kSpanLong &&
+                (sa.chain != sc.chain || (!sa.chain && sa.q != sc.q)))
+                return c;
+        }
         seen[0]++;
         seen[1] += cut < 64;
         seen[2] += ra == kSpanLong;
