@@ -395,9 +395,17 @@ __device__ __forceinline__ uint32_t extend_match(P src, uint32_t n,
 }
 
 #ifdef SNAPMI_PROFILE
+// (SNAPMI_PROFILE=2: the boundaries do not wait for outstanding memory
+// operations - a wait is then counted where the product build has it, in the
+// phase that first needs the data)
+#if SNAPMI_PROFILE == 2
+#define TICK_WAIT()
+#else
+#define TICK_WAIT() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#endif
 #define TICK(i)                                                               \
     do {                                                                      \
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");           \
+        TICK_WAIT();                                                          \
         const uint64_t _t = __builtin_readcyclecounter();                     \
         pt[i] += _t - t_last;                                                 \
         t_last = _t;                                                          \
@@ -1043,6 +1051,7 @@ struct WaveDev {
     typedef bool b1;
     uint32_t l;
     __device__ __forceinline__ u32 lane() const { return l; }
+    __device__ __forceinline__ void count_cut() const {}
     __device__ __forceinline__ u32 sel(b1 c, u32 a, u32 b) const
     {
         return c ? a : b;
@@ -1203,7 +1212,7 @@ __device__ __forceinline__ void compress_one_block_span(
     sink.out = &out;
     sink.emit = 0;
 #ifdef SNAPMI_PROFILE
-    uint64_t pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t pt[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t t_last = __builtin_readcyclecounter();
     uint64_t n_batches = 0, n_copies = 0;
 #endif
@@ -1314,15 +1323,19 @@ __device__ __forceinline__ void compress_one_block_span(
             // the fast walk (snapmi_span.hpp): the scalar unit follows the
             // chain of copies, the lanes derive everything else at once
             bool fast = span_fast_ok(st, hits, n);
-#ifndef SNAPMI_SPAN_SCALAR_WALK
+            TICK(13);
             if (fast) {
                 // the lane-parallel walk (span_par_walk): the copies of the
                 // step by pointer jumping, everything else per lane
                 const WaveDev w{lane};
                 uint64_t vh;
                 uint32_t lit;
-                rc = span_par_walk(w, st, hits, cbits, ln.mv, old, cbit,
-                                   sink.emit, vh, lit, touched, at);
+                rc = span_par_walk(w, st, hits, ln.mv, old, cbit, sink.emit,
+                                   vh, lit, touched, at);
+#ifdef SNAPMI_ABL_NOPUSH
+                vh = 0; // (timing experiment, wrong bytes: no tokens)
+#endif
+                TICK(14);
                 const uint32_t cnt = (uint32_t)__builtin_popcountll(vh);
                 if (cnt) {
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi(
@@ -1346,51 +1359,6 @@ __device__ __forceinline__ void compress_one_block_span(
                     out.t += cnt;
                 }
             }
-#else
-            if (fast) {
-                const uint64_t longs =
-                    __ballot(active && lane && ln.mv >= 16);
-                SpanFast f;
-                span_fast_walk(hits, longs, ln, f);
-                uint64_t vh;
-                span_fast_masks(f, hits, st.chain, 64, vh, touched);
-                // an inserted lane with a C bit needs the lane it collided
-                // with inserted too: the step ends in front of the lowest
-                // lane where that fails (span_walk's cut)
-                uint32_t cut = 64;
-                if (cbits & touched) {
-                    const uint32_t pred = old - (base - 1);
-                    const bool mine = (touched >> lane) & 1;
-                    const uint64_t bad = __ballot(
-                        mine && cbit && !((touched >> (pred & 63)) & 1));
-                    if (bad) {
-                        cut = (uint32_t)__builtin_ctzll(bad);
-                        span_fast_masks(f, hits, st.chain, cut, vh, touched);
-                    }
-                }
-                const uint32_t cnt = (uint32_t)__builtin_popcountll(vh);
-                if (cnt) {
-                    uint32_t lit, rank;
-                    span_fast_token(lane, base, sink.emit, f.inside, vh, lit,
-                                    rank);
-                    const bool is_vh = (vh >> lane) & 1;
-                    const uint32_t to =
-                        is_vh ? out.t + rank : (out.t + cnt) & 63u;
-                    const uint32_t ta = (lit & 0xFFFFu) | ((P - old) << 16);
-                    const uint32_t tb = ln.mv | ((P - lit) << 16);
-                    const uint32_t ra = (uint32_t)__builtin_amdgcn_ds_permute(
-                        (int)(to << 2), (int)ta);
-                    const uint32_t rb = (uint32_t)__builtin_amdgcn_ds_permute(
-                        (int)(to << 2), (int)tb);
-                    const bool got = lane - out.t < cnt;
-                    out.a = got ? ra : out.a;
-                    out.b = got ? rb : out.b;
-                    out.t += cnt;
-                }
-                rc = span_fast_state(st, f, cut, sink.emit);
-                at = f.at;
-            }
-#endif
             if (!fast)
                 rc = span_walk(st, hits, cbits, s_limit, ln, sink, touched,
                                at);
@@ -1404,6 +1372,10 @@ __device__ __forceinline__ void compress_one_block_span(
             TICK(5);
             if (rc == kSpanLong) {
                 const uint32_t pk = st.s, ck = rdlane(old, at);
+                // (requesting the next 16 bytes of every 16-byte match under
+                // the walk, so that a long match is measured to 32 bytes
+                // without this round trip, was built and measured: 8 % SLOWER
+                // on text and HTML alike - profiles/r5_span_ablations.txt)
                 const uint32_t len =
                     16 + extend_match(msrc, n, ck + 16, pk + 16, lane);
                 sink.token(pk - sink.emit, len, pk - ck);
@@ -1421,8 +1393,13 @@ __device__ __forceinline__ void compress_one_block_span(
         }
         // keep the register window covering s - 1 .. s + 126
         if constexpr (!kLds) {
-            uint32_t D = st.s - 1 - wbase;
-            if (D >= 192) {
+            // (ONE slide per step and its load straight into wv4: a loop
+            // here is unrolled by the compiler into register rotations that
+            // wait for the load they have just issued - a memory round trip
+            // per step, 770 of a step's 4 800 cycles in round 4's kernel.  A
+            // step that went further - behind a long match - reloads)
+            const uint32_t D = st.s - 1 - wbase;
+            if (D >= 128) {
                 wbase = st.s - 1;
                 const uint32_t w0 = wbase + lane;
                 wv0 = ld32u(msrc + (w0 < n4 ? w0 : n4));
@@ -1430,17 +1407,14 @@ __device__ __forceinline__ void compress_one_block_span(
                 wv2 = ld32u(msrc + (w0 + 128 < n4 ? w0 + 128 : n4));
                 wv3 = ld32u(msrc + (w0 + 192 < n4 ? w0 + 192 : n4));
                 wv4 = ld32u(msrc + (w0 + 256 < n4 ? w0 + 256 : n4));
-            } else {
-                while (D >= 64) {
-                    wv0 = wv1;
-                    wv1 = wv2;
-                    wv2 = wv3;
-                    wv3 = wv4;
-                    wbase += 64;
-                    D -= 64;
-                    const uint32_t wp = wbase + 256 + lane;
-                    wv4 = ld32u(msrc + (wp < n4 ? wp : n4));
-                }
+            } else if (D >= 64) {
+                wv0 = wv1;
+                wv1 = wv2;
+                wv2 = wv3;
+                wv3 = wv4;
+                wbase += 64;
+                const uint32_t wp = wbase + 256 + lane;
+                wv4 = ld32u(msrc + (wp < n4 ? wp : n4));
             }
         }
         TICK(7);
@@ -1458,6 +1432,8 @@ __device__ __forceinline__ void compress_one_block_span(
     TICK(8);
     if (lane == 0 && a.prof) {
         for (int i = 0; i < 9; i++)
+            atomicAdd(&a.prof[i], (unsigned long long)pt[i]);
+        for (int i = 13; i < 16; i++)
             atomicAdd(&a.prof[i], (unsigned long long)pt[i]);
         atomicAdd(&a.prof[10], (unsigned long long)n_batches);
         atomicAdd(&a.prof[11], (unsigned long long)n_copies);

@@ -179,37 +179,17 @@ SNAPMI_LANE_FN uint32_t span_walk(SpanState &st, const uint64_t hits,
 
 // ---------------------------------------------------------------------
 // The fast walk.  span_walk above costs the scalar unit ~70 instructions and
-// ten branches per copy (measured: 5 700 of a step's 10 000 cycles on text,
-// nine copies per step).  But where the parse GOES depends on nothing but the
-// hit mask and the match lengths: from a lookup at lane L the next hit X is a
-// find-first-set, the lookup after a copy of m bytes is lane X + m.  So the
-// scalar unit only follows the chain of copies and collects the lanes INSIDE
-// them (X+1 .. X+m-1: never looked up) - a dozen instructions per copy - and
-// everything else is derived for all lanes at once: the lanes looked up are
-// the ones outside copies, the lanes inserted are those plus the last lane
-// inside every copy (src/compress.rs:290-297: insert e - 1), a hit lane's
-// literal starts behind the last inside lane below it, its place among the
-// wave's tokens is a population count.  Conditions the derivation does not
-// cover send the step to span_walk instead, which is exact everywhere:
+// ten branches per copy (measured in round 4: 5 700 of a step's 10 000 cycles
+// on text, nine copies per step).  But where the parse GOES depends on nothing
+// but the hit mask and the match lengths, so it can be derived for all lanes
+// at once (span_par_walk below).  Conditions the derivation does not cover
+// send the step to span_walk instead, which is exact everywhere:
 //   * the window reaches the block's limit region (s_limit checks, done());
 //   * 32 lanes in a row without a hit (the run-length rule, kSpanRun).
-// span_walk's cut (an inserted lane with a C bit whose lower lane is not
-// inserted) is a mask operation here: the step ends in front of the lowest
-// such lane.
 // ---------------------------------------------------------------------
-enum : uint32_t {
-    kFastRun = 0,     // no hit from lane `at` (a chain check) to the window's end
-    kFastCopyOut = 1, // the copy at lane `at` ends at lane `end` >= 64
-    kFastLong = 2,    // lane `at` hits with >= 16 equal bytes
-};
-struct SpanFast {
-    uint64_t inside; // lanes inside copies
-    uint32_t kind, at, end;
-};
-
 // may this step take the fast walk?  n = block length, st.s = window base
-// (written without branches, like the functions below: at five wavefronts
-// per CU a taken scalar branch costs as much as a dozen ALU instructions)
+// (written without branches: at five wavefronts per CU a taken scalar branch
+// costs as much as a dozen ALU instructions)
 SNAPMI_LANE_FN bool span_fast_ok(const SpanState &st, const uint64_t hits,
                                  const uint32_t n)
 {
@@ -228,140 +208,25 @@ SNAPMI_LANE_FN bool span_fast_ok(const SpanState &st, const uint64_t hits,
     return (st.s + 93 <= n) & (r == 0) & run_ok;
 }
 
-// hits: lanes (1..63) whose lookup would hit; longs: those of them with 16
-// equal bytes or more.  LN::m(lane) = the match length there.
-template <class LN>
-SNAPMI_LANE_FN void span_fast_walk(const uint64_t hits, const uint64_t longs,
-                                   const LN &ln, SpanFast &f)
-{
-    uint64_t inside = 0, ahead;
-    uint32_t L = 1, X = 0, e = 0;
-    for (;;) {
-        ahead = hits >> L; // L <= 63
-        if (!ahead)
-            break; // no hit from the chain check at L on
-        X = L + (uint32_t)__builtin_ctzll(ahead);
-        e = X + ln.m(X);
-        // a long match, or a copy whose last byte is lane 63 or beyond (the
-        // insert of e - 1 and the check at e are the next step's)
-        if (((longs >> X) & 1) | (e >= 64))
-            break;
-        inside |= ((1ull << (e - X - 1)) - 1) << (X + 1); // X+1 .. e-1
-        L = e;
-    }
-    const bool run = !ahead;
-    const bool lng = !run & (((longs >> X) & 1) != 0);
-    const bool out = !run & !lng;
-    f.inside = inside | (out ? (~0ull << X) << 1 : 0);
-    f.kind = run ? kFastRun : (lng ? kFastLong : kFastCopyOut);
-    f.at = run ? L : X;
-    f.end = out ? e : 0;
-}
-
-// What the lanes are, as masks: vh = lanes whose copy becomes a token of this
-// step, touched = lanes the reference inserts (bit 0: the insert of s - 1).
-// cut < 64: the step ends in front of lane `cut` (an inserted lane with a C
-// bit whose lower lane is not inserted: span_walk's cut; cut >= 1) - what
-// lies below stands as it is.
-SNAPMI_LANE_FN void span_fast_masks(const SpanFast &f, const uint64_t hits,
-                                    const uint32_t chain0, const uint32_t cut,
-                                    uint64_t &vh, uint64_t &touched)
-{
-    // lanes 1 .. stop-1 were walked: a long match ends the walk at its lane
-    // (which is looked up, hence inserted), a cut in front of its lane
-    const uint32_t lstop = f.kind == kFastLong ? f.at + 1 : 64;
-    const uint32_t stop = cut < lstop ? cut : lstop; // 1 .. 64
-    const uint64_t range = (~0ull >> (64 - stop)) & ~1ull;
-    const uint64_t visited = range & ~f.inside;
-    const uint64_t lbit = f.kind == kFastLong ? 1ull << f.at : 0;
-    vh = visited & hits & ~lbit;
-    // the last lane inside every copy is inserted; lane 63 never is (a copy
-    // that reaches it leaves the window: kFastCopyOut)
-    const uint64_t ins =
-        f.inside & ~(f.inside >> 1) & ~(1ull << 63) & range;
-    touched = visited | ins | (chain0 ? 1ull : 0ull);
-}
-
-// lane l's token if it is in vh: literal length and start; its rank among the
-// step's tokens.  emit0 = first byte not covered when the step began.
-SNAPMI_LANE_FN void span_fast_token(const uint32_t l, const uint32_t base,
-                                    const uint32_t emit0, const uint64_t inside,
-                                    const uint64_t vh, uint32_t &lit,
-                                    uint32_t &rank)
-{
-    const uint64_t below = (1ull << l) - 1; // l <= 63
-    const uint64_t in_b = inside & below;
-    const uint32_t P = base - 1 + l;
-    // the literal starts behind the last lane inside a copy below l
-    lit = in_b ? l - 1 - (63u - (uint32_t)__builtin_clzll(in_b)) : P - emit0;
-    rank = (uint32_t)__builtin_popcountll(vh & below);
-}
-
-// the state behind a fast step (returns kSpanLong with st.s = the hit's
-// position when the caller has a long match to finish, kSpanCont otherwise);
-// emit = the new "first byte not covered"
-SNAPMI_LANE_FN uint32_t span_fast_state(SpanState &st, const SpanFast &f,
-                                        const uint32_t cut, uint32_t &emit)
-{
-    const uint32_t base = st.s;
-    const bool is_cut = cut < 64;
-    const bool is_long = !is_cut & (f.kind == kFastLong);
-    const bool is_out = !is_cut & (f.kind == kFastCopyOut);
-    const bool is_run = !is_cut & (f.kind == kFastRun);
-    // the inside lanes that count: below the cut, below a long match's lane
-    const uint32_t lim = is_cut ? cut : (is_long ? f.at : 64); // 1 .. 64
-    const uint64_t in_b = f.inside & (~0ull >> (64 - lim));
-    const uint32_t hb = 63u - (uint32_t)__builtin_clzll(in_b | 1);
-    // a cut: in front of the insert behind a copy (the copy stands, insert
-    // and check are the next step's), of a chain check, or of a probe
-    const bool cut_ins = is_cut & (((f.inside >> (cut & 63)) & 1) != 0);
-    const bool cut_chk =
-        is_cut & !cut_ins &
-        (cut == 1 ? st.chain != 0
-                  : ((f.inside >> ((cut - 1) & 63)) & 1) != 0);
-    const bool cut_run = is_cut & !cut_ins & !cut_chk;
-    const uint32_t q_cut =
-        in_b ? cut - (hb + 2) : (st.chain ? cut - 2 : st.q + cut - 1);
-    uint32_t nemit = in_b ? base + hb : emit;
-    nemit = cut_ins ? base + cut : nemit;
-    nemit = is_out ? base - 1 + f.end : nemit;
-    const uint32_t ns = (cut_ins | is_out)
-                            ? nemit
-                            : (is_run ? base + 63
-                                      : base - 1 + (is_cut ? cut : f.at));
-    const uint32_t nchain =
-        (cut_ins | cut_chk | is_out) ? 1 : (is_long ? st.chain : 0);
-    const uint32_t nq =
-        cut_run ? q_cut : (is_run ? 63 - f.at : (is_long ? st.q : 0));
-    st.s = ns;
-    st.q = nq;
-    st.chain = nchain;
-    st.next_emit = nemit;
-    emit = nemit;
-    return is_long ? kSpanLong : kSpanCont;
-}
-
 // ---------------------------------------------------------------------
-// The lane-parallel walk (round 5).  span_fast_walk above still follows the
-// chain of copies on the scalar unit - a v_readlane, ~14 scalar instructions
-// and a loop branch per copy, and the masks and the state behind it another
-// ~150 scalar instructions: half of a step's time at five wavefronts per CU,
-// where every instruction a lone wavefront issues costs 4-5 cycles.  But the
-// chain is pointer jumping over per-lane successors: behind a copy at hit lane
+// The lane-parallel walk (round 5).  Round 4's fast walk followed the chain
+// of copies on the scalar unit - a v_readlane, ~14 scalar instructions and a
+// loop branch per copy, and the masks and the state behind it another ~150
+// scalar instructions: half of a step's time at five wavefronts per CU, where
+// every instruction a lone wavefront issues costs 4-5 cycles (alice29.txt
+// tiled to 1 GiB: 37.1 ms with it, 28.1 with this one).  But the chain is
+// pointer jumping over per-lane successors: behind a copy at hit lane
 // X (m bytes, ending inside the window) the next copy is at the first hit lane
 // at or behind X + m - a find-first-set every hit lane does for itself - so
 // the set of copies the reference emits is the orbit of the window's first
-// hit under that map.  A copy is 4 bytes or more: at most 16 in a window, and
-// four rounds of doubling (R |= R[frontier]: the set a lane reaches and the
-// last lane in it, three ds_bpermute per round) give every lane the orbit it
-// starts.  Everything else is per-lane arithmetic on the orbit of the first
-// hit: the copy below a lane and where it ends (one more ds_bpermute) say
+// hit under that map: a v_readlane per copy, at most 16 in a window (a copy is
+// 4 bytes or more).  Everything else is per-lane arithmetic on that orbit: the copy below a lane and where it ends (one more ds_bpermute) say
 // whether the lane lies inside a copy, is its last byte (the insert of e - 1,
 // src/compress.rs:290-297), or is looked up; a token's literal starts where
 // the copy below ended.  ~70 vector + ~30 scalar instructions where the scalar
-// walk had ~100 + ~300, no loop.  The cut (an inserted lane with a C bit whose
-// lower lane is not inserted), one step in five on text, goes on through
-// span_fast_masks / span_fast_state above.
+// walk had ~100 + ~300, no loop.  span_walk's cut (an inserted lane with a C
+// bit whose lower lane is not inserted: one step in five on text) is a mask:
+// the step ends in front of the lowest such lane.
 //
 // W is the wave: per-lane values W::u32 / flags W::b1 with the operators of
 // uint32_t, and
@@ -373,7 +238,7 @@ SNAPMI_LANE_FN uint32_t span_fast_state(SpanState &st, const SpanFast &f,
 //   bit(mask, i)         bit i (per lane, 0..63) of a uniform mask
 //   next_bit(mask, t)    lowest set bit >= t (per lane, 0..63) or 64
 //   prev_bit(mask, t)    highest set bit < t (per lane, 0..63) or 64
-//   bit_lo(x), bit_hi(x) the halves of 1 << x, x = 0..63
+//   count_cut()          a hook for the host test's statistics
 // snapmi_compress.hip instantiates it over the hardware, tests/
 // span_wave_host.cpp over arrays of 64 - the same text - and
 // test_span_wave_cpu.py compares it with span_walk on random windows and the
@@ -385,7 +250,7 @@ SNAPMI_LANE_FN uint32_t span_fast_state(SpanState &st, const SpanFast &f,
 #define SNAPMI_WAVE_FN inline
 #endif
 
-// hits (lanes 1..63, at least one: span_fast_ok) / cbits as for span_walk;
+// hits (lanes 1..63, at least one: span_fast_ok) as for span_walk;
 // m, old, cbit: this lane's match length, exchanged entry and C bit.
 // emit: in, the first byte not covered by a token; out, the same behind the
 // step.  Out: vh = lanes whose copy is a token of this step, lit = a vh
@@ -394,7 +259,7 @@ SNAPMI_LANE_FN uint32_t span_fast_state(SpanState &st, const SpanFast &f,
 template <class W>
 SNAPMI_WAVE_FN uint32_t
 span_par_walk(const W &w, SpanState &st, const uint64_t hits,
-              const uint64_t cbits, const typename W::u32 m,
+              const typename W::u32 m,
               const typename W::u32 old, const typename W::b1 cbit,
               uint32_t &emit, uint64_t &vh, typename W::u32 &lit,
               uint64_t &touched, uint32_t &at)
@@ -410,18 +275,24 @@ span_par_walk(const W &w, SpanState &st, const uint64_t hits,
     const b1 last = w.bor(w.ge(m, u32(16)), w.ge(end, u32(64)));
     const u32 nx = w.next_bit(hits, w.sel(w.lt(end, u32(63)), end, u32(63)));
     const b1 go = w.band(hit, w.band(w.bnot(last), w.lt(nx, u32(64))));
-    // R = the hit lanes reached from here, F = the last of them
-    u32 F = w.sel(go, nx, lane);
-    u32 Rlo = w.bit_lo(lane) | w.bit_lo(F), Rhi = w.bit_hi(lane) | w.bit_hi(F);
-    for (int r = 0; r < 4; r++) {
-        const u32 flo = w.bperm(F, Rlo), fhi = w.bperm(F, Rhi);
-        F = w.bperm(F, F);
-        Rlo = Rlo | flo;
-        Rhi = Rhi | fhi;
+    // The copies of the step: the orbit of the first hit under J.  The scalar
+    // unit hops through it - a v_readlane per copy whose wait states hold the
+    // mask update and the exit test, ~20 cycles a hop, 9 hops on text - which
+    // beats four rounds of doubling over ds_bpermute (R |= R[frontier]: exact
+    // too, built first, 4 x ~140 cycles of LDS round trips for a lone
+    // wavefront).  At most 16 copies of 4 bytes or more fit a window.
+    const u32 J = w.sel(go, nx, u32(64));
+    uint64_t V = 0;
+    uint32_t cur = 1 + (uint32_t)__builtin_ctzll(hits >> 1);
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int i = 0; i < 16; i++) {
+        V |= 1ull << cur;
+        cur = w.readlane(J, cur);
+        if (cur >= 64)
+            break;
     }
-    const uint32_t X0 = 1 + (uint32_t)__builtin_ctzll(hits >> 1);
-    const uint64_t V = (uint64_t)w.readlane(Rlo, X0) |
-                       ((uint64_t)w.readlane(Rhi, X0) << 32);
     // the last copy of the step
     const uint32_t Xl = 63u - (uint32_t)__builtin_clzll(V);
     const uint32_t ml = w.readlane(m, Xl), el = Xl + ml;
@@ -467,17 +338,31 @@ span_par_walk(const W &w, SpanState &st, const uint64_t hits,
         emit = pe;
         return kSpanCont;
     }
-    // the step ends in front of lane `cut`
-    const uint32_t cut = (uint32_t)__builtin_ctzll(bad);
-    SpanFast f;
-    f.inside = w.ballot(w.band(inside, w.lt(lane, u32(stop)))) & ~1ull;
-    f.kind = is_long ? kFastLong : (is_out ? kFastCopyOut : kFastRun);
-    f.at = (is_long | is_out) ? Xl : el;
-    f.end = is_out ? el : 0;
-    span_fast_masks(f, hits, st.chain, cut, vh, touched);
-    at = f.at;
-    (void)cbits;
-    return span_fast_state(st, f, cut, emit);
+    // The step ends in front of lane `cut` (span_walk's cut): what lies below
+    // stands.  Lane `cut` is the insert behind a copy (the copy stands, insert
+    // and check are the next step's), a chain check, or a probe of a run.
+    const uint32_t cut = (uint32_t)__builtin_ctzll(bad); // >= 1
+    w.count_cut(); // (a test's statistics; nothing on the device)
+    const uint64_t below = (1ull << cut) - 1;
+    vh = V & below;
+    touched = T & below;
+    at = 0;
+    const bool has_c = vh != 0; // a copy below the cut, ending at lane e_c
+    const uint32_t e_c = w.readlane(eP, cut);
+    const bool c_ins = has_c & (cut < e_c);
+    const bool c_chk =
+        !c_ins & ((has_c & (e_c == cut)) | ((cut == 1) & (st.chain != 0)));
+    const bool c_run = !c_ins & !c_chk;
+    const uint32_t q_run =
+        has_c ? cut - e_c - 1 : (st.chain ? cut - 2 : st.q + cut - 1);
+    const uint32_t nemit =
+        c_ins ? base + cut : (has_c ? base - 1 + e_c : emit0);
+    st.s = c_ins ? base + cut : base - 1 + cut;
+    st.q = c_run ? q_run : 0;
+    st.chain = c_run ? 0 : 1;
+    st.next_emit = nemit;
+    emit = nemit;
+    return kSpanCont;
 }
 
 } // namespace snapmi

@@ -1,7 +1,7 @@
 """Per-phase cycle split of k_compress_spans (profile build: make -C
 rust-snappy_amd/csrc profile)."""
 import ctypes as C, os, sys
-os.environ["SNAPMI_LIB"] = "/root/repo/rust-snappy_amd/libsnapmi_profile.so"
+os.environ.setdefault("SNAPMI_LIB", "/root/repo/rust-snappy_amd/libsnapmi_profile.so")
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 import numpy as np, torch
 import oracle_lib as O
@@ -26,7 +26,8 @@ for k, streams in sets.items():
     out = (C.c_uint64 * 16)()
     L.snapmi_debug_profile(ctx._h, out)
     v = list(out)
-    tot = sum(v[:9]); nb, nc, nblk = v[10], v[11], v[12]
+    tot = sum(v[:9]) + sum(v[13:16]); nb, nc, nblk = v[10], v[11], v[12]
     ub = sum(len(s) for s in streams)
     print(f"== {k}: {ub/2**30:.2f} GiB, codec {t['codec_ms']:.1f} ms -> {ub/2**30/(t['codec_ms']/1e3):.2f} GiB/s; blocks {nblk}, steps/blk {nb/max(nblk,1):.0f}, cycles/blk {tot/max(nblk,1)/1e6:.2f}M, cycles/step {tot/max(nb,1):.0f}")
     print("   " + "  ".join(f"{names[i]}={v[i]/max(nb,1):.0f}" for i in range(9)))
+    print(f"   (cmp+walk = push/rest; before it: wait x,y + compare + ballots {v[13]/max(nb,1):.0f}, walk {v[14]/max(nb,1):.0f})")

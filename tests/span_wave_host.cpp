@@ -115,7 +115,8 @@ HV_OP(+) HV_OP(-) HV_OP(&) HV_OP(|)
 struct WaveHost {
     typedef HV u32;
     typedef HB b1;
-    mutable uint64_t bperms = 0;
+    mutable uint64_t bperms = 0, cuts = 0;
+    void count_cut() const { cuts++; }
     HV lane() const
     {
         HV r;
@@ -357,8 +358,7 @@ extern "C" uint32_t span_wave_compress(const uint8_t *src, uint32_t n,
             HV lit;
             uint32_t emit = st.next_emit;
             const uint32_t emit0 = emit;
-            rc = span_par_walk(w, st, hits, cbits, m, old, cb, emit, vh, lit,
-                               T, at);
+            rc = span_par_walk(w, st, hits, m, old, cb, emit, vh, lit, T, at);
             (void)emit0;
             stats[7]++;
             for (uint32_t l = 1; l < 64; l++) {
@@ -369,6 +369,7 @@ extern "C" uint32_t span_wave_compress(const uint8_t *src, uint32_t n,
             }
             if (st.next_emit != emit)
                 return 0x80000003u;
+            stats[2] += w.cuts;
         }
         if (!fast)
             rc = span_walk(st, hits, cbits, s_limit, ln, sink, T, at);
@@ -473,75 +474,8 @@ extern "C" uint32_t span_walk_diff(uint32_t seed, uint32_t cases,
         uint32_t ata = 0;
         const uint32_t ra =
             span_walk(sa, hits, cbits, s_limit, ln, ka, Ta, ata);
-        // fast walk, as the kernel drives it
-        SpanState sb = st;
-        Sink kb;
-        uint64_t longs = 0;
-        for (uint32_t l = 1; l < 64; l++)
-            if (((hits >> l) & 1) && ln.mv[l] >= 16)
-                longs |= 1ull << l;
-        SpanFast f;
-        span_fast_walk(hits, longs, ln, f);
-        uint64_t vh, Tb;
-        span_fast_masks(f, hits, st.chain, 64, vh, Tb);
-        uint32_t cut = 64;
-        for (uint32_t l = 0; l < 64; l++) {
-            const uint32_t pred = ln.ov[l] - (base - 1);
-            if (((Tb >> l) & 1) && ((cbits >> l) & 1) &&
-                !((Tb >> (pred & 63)) & 1)) {
-                cut = l;
-                break;
-            }
-        }
-        if (cut < 64)
-            span_fast_masks(f, hits, st.chain, cut, vh, Tb);
-        for (uint32_t l = 1; l < 64; l++) {
-            if (!((vh >> l) & 1))
-                continue;
-            uint32_t lit, rank;
-            span_fast_token(l, base, st.next_emit, f.inside, vh, lit, rank);
-            if (rank != kb.t.size())
-                return c;
-            kb.token(lit, ln.mv[l], base - 1 + l - ln.ov[l]);
-        }
-        uint32_t emit = st.next_emit;
-        const uint32_t rb = span_fast_state(sb, f, cut, emit);
-#ifdef SPAN_DIFF_DEBUG
-        if (ra != rb || Ta != Tb || ka.t.size() != kb.t.size() ||
-            sa.s != sb.s || sa.next_emit != sb.next_emit ||
-            (ra != kSpanLong && (sa.chain != sb.chain ||
-                                 (!sa.chain && sa.q != sb.q)))) {
-            fprintf(stderr,
-                    "case %u base %u st(q %u chain %u emit %u) hits %016llx "
-                    "cbits %016llx\n ra %u rb %u Ta %016llx Tb %016llx ntok "
-                    "%zu %zu cut %u kind %u at %u end %u\n sa(s %u q %u c %u "
-                    "e %u) sb(s %u q %u c %u e %u)\n",
-                    c, base, st.q, st.chain, st.next_emit,
-                    (unsigned long long)hits, (unsigned long long)cbits, ra,
-                    rb, (unsigned long long)Ta, (unsigned long long)Tb,
-                    ka.t.size(), kb.t.size(), cut, f.kind, f.at, f.end, sa.s,
-                    sa.q, sa.chain, sa.next_emit, sb.s, sb.q, sb.chain,
-                    sb.next_emit);
-            for (uint32_t l = 0; l < 64; l++)
-                fprintf(stderr, "%u:m%u%s ", l, ln.mv[l],
-                        ((cbits >> l) & 1)
-                            ? (" p" + std::to_string(ln.ov[l] - (base - 1)))
-                                  .c_str()
-                            : "");
-            fprintf(stderr, "\n");
-        }
-#endif
-        if (ra != rb || Ta != Tb || ka.t.size() != kb.t.size())
-            return c;
-        for (size_t i = 0; i < ka.t.size(); i++)
-            if (ka.t[i].lit != kb.t[i].lit || ka.t[i].len != kb.t[i].len ||
-                ka.t[i].off != kb.t[i].off)
-                return c;
-        if (ra == kSpanLong && ata != f.at)
-            return c;
-        if (sa.s != sb.s || sa.next_emit != sb.next_emit)
-            return c;
-        // ... and the lane-parallel walk (span_par_walk) against both
+        // the lane-parallel walk (span_par_walk), as the kernel drives it
+        uint32_t cutc = 0;
         {
             SpanState sc = st;
             WaveHost w;
@@ -555,8 +489,8 @@ extern "C" uint32_t span_walk_diff(uint32_t seed, uint32_t cases,
             uint64_t vhc, Tc;
             HV lit;
             uint32_t emitc = st.next_emit, atc = 0;
-            const uint32_t rcc = span_par_walk(w, sc, hits, cbits, m, old, cb,
-                                               emitc, vhc, lit, Tc, atc);
+            const uint32_t rcc = span_par_walk(w, sc, hits, m, old, cb, emitc,
+                                               vhc, lit, Tc, atc);
             if (rcc != ra || Tc != Ta || sc.s != sa.s ||
                 sc.next_emit != sa.next_emit || emitc != sa.next_emit)
                 return c;
@@ -576,15 +510,12 @@ extern "C" uint32_t span_walk_diff(uint32_t seed, uint32_t cases,
             if (ra != kSpanLong &&
                 (sa.chain != sc.chain || (!sa.chain && sa.q != sc.q)))
                 return c;
+            cutc = (uint32_t)w.cuts;
         }
         seen[0]++;
-        seen[1] += cut < 64;
+        seen[1] += cutc;
         seen[2] += ra == kSpanLong;
-        seen[3] += cut == 64 && f.kind == kFastRun;
-        // (q only means something while no chain check is pending)
-        if (ra != kSpanLong &&
-            (sa.chain != sb.chain || (!sa.chain && sa.q != sb.q)))
-            return c;
+        seen[3] += !cutc && ra == kSpanCont && sa.s == base + 63;
     }
     return 0;
 }
