@@ -1088,14 +1088,6 @@ struct WaveDev {
         const uint64_t x = mask & ((1ull << t) - 1);
         return x ? 63u - (u32)__builtin_clzll(x) : 64u;
     }
-    __device__ __forceinline__ u32 bit_lo(u32 x) const
-    {
-        return x < 32 ? 1u << x : 0u;
-    }
-    __device__ __forceinline__ u32 bit_hi(u32 x) const
-    {
-        return x - 32u < 32u ? 1u << (x - 32u) : 0u;
-    }
 };
 
 template <bool kLds, bool kTok = false>

@@ -210,23 +210,26 @@ SNAPMI_LANE_FN bool span_fast_ok(const SpanState &st, const uint64_t hits,
 
 // ---------------------------------------------------------------------
 // The lane-parallel walk (round 5).  Round 4's fast walk followed the chain
-// of copies on the scalar unit - a v_readlane, ~14 scalar instructions and a
-// loop branch per copy, and the masks and the state behind it another ~150
-// scalar instructions: half of a step's time at five wavefronts per CU, where
-// every instruction a lone wavefront issues costs 4-5 cycles (alice29.txt
-// tiled to 1 GiB: 37.1 ms with it, 28.1 with this one).  But the chain is
-// pointer jumping over per-lane successors: behind a copy at hit lane
-// X (m bytes, ending inside the window) the next copy is at the first hit lane
-// at or behind X + m - a find-first-set every hit lane does for itself - so
-// the set of copies the reference emits is the orbit of the window's first
-// hit under that map: a v_readlane per copy, at most 16 in a window (a copy is
-// 4 bytes or more).  Everything else is per-lane arithmetic on that orbit: the copy below a lane and where it ends (one more ds_bpermute) say
-// whether the lane lies inside a copy, is its last byte (the insert of e - 1,
-// src/compress.rs:290-297), or is looked up; a token's literal starts where
-// the copy below ended.  ~70 vector + ~30 scalar instructions where the scalar
-// walk had ~100 + ~300, no loop.  span_walk's cut (an inserted lane with a C
-// bit whose lower lane is not inserted: one step in five on text) is a mask:
-// the step ends in front of the lowest such lane.
+// of copies on the scalar unit and collected the lanes inside them as it went
+// - a v_readlane, ~14 scalar instructions and a loop branch per copy, and the
+// masks and the state behind it another ~150 scalar instructions: half of a
+// step's time at five wavefronts per CU, where every instruction a lone
+// wavefront issues costs 4-5 cycles (alice29.txt tiled to 1 GiB: 37.1 ms with
+// it, 28.1 with the first version of this one).  But the chain is pointer
+// chasing over per-lane successors: behind a copy at hit lane X (m bytes,
+// ending inside the window) the next copy is at the first hit lane at or
+// behind X + m - a find-first-set every hit lane does for itself - so the
+// set of copies the reference emits is the orbit of the window's first hit
+// under that map: one v_readlane per copy, five instructions a hop, at most
+// 16 in a window (a copy is 4 bytes or more).  Everything else is per-lane
+// arithmetic on that orbit: the copy below a lane and where it ends (one
+// ds_bpermute) say whether the lane lies inside a copy, is its last byte (the
+// insert of e - 1, src/compress.rs:290-297), or is looked up; a token's
+// literal starts where the copy below ended.  span_walk's cut (an inserted
+// lane with a C bit whose lower lane is not inserted: one step in five on
+// text) is a mask: the step ends in front of the lowest such lane.  Per step
+// 170 scalar + 185 vector instructions and 31 branches where round 4 had 404 +
+// 190 and 58 (profiles/r5_span_kernel_counters.txt).
 //
 // W is the wave: per-lane values W::u32 / flags W::b1 with the operators of
 // uint32_t, and
@@ -242,7 +245,7 @@ SNAPMI_LANE_FN bool span_fast_ok(const SpanState &st, const uint64_t hits,
 // snapmi_compress.hip instantiates it over the hardware, tests/
 // span_wave_host.cpp over arrays of 64 - the same text - and
 // test_span_wave_cpu.py compares it with span_walk on random windows and the
-// streams it gives with the oracle's.
+// streams it gives with the reference restatement's.
 // ---------------------------------------------------------------------
 #if defined(__HIPCC__)
 #define SNAPMI_WAVE_FN __device__ __forceinline__

@@ -218,20 +218,6 @@ struct WaveHost {
         }
         return r;
     }
-    HV bit_lo(const HV &x) const
-    {
-        HV r;
-        for (int k = 0; k < 64; k++)
-            r.v[k] = x.v[k] < 32 ? 1u << x.v[k] : 0;
-        return r;
-    }
-    HV bit_hi(const HV &x) const
-    {
-        HV r;
-        for (int k = 0; k < 64; k++)
-            r.v[k] = x.v[k] >= 32 && x.v[k] < 64 ? 1u << (x.v[k] - 32) : 0;
-        return r;
-    }
 };
 } // namespace
 
