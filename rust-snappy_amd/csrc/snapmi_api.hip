@@ -309,6 +309,13 @@ int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value)
     else if (strcmp(name, "lane_table_budget_pct") == 0 && value >= 1 &&
              value <= 90)
         ctx->lane_table_budget_pct = (uint32_t)value;
+    else if (strcmp(name, "window_tokens") == 0 && value >= 0 && value <= 1)
+        ctx->window_tokens = (int)value;
+    else if (strcmp(name, "small_table_kernel") == 0 && value >= 0 &&
+             value <= 1)
+        ctx->small_table_kernel = (int)value;
+    else if (strcmp(name, "small_table_min_blocks") == 0 && value >= 1)
+        ctx->small_table_min_blocks = (uint64_t)value;
     else if (strcmp(name, "small_batch_kernel") == 0 && value >= 0 &&
              value <= 2)
         ctx->small_batch_kernel = (int)value;
@@ -519,7 +526,7 @@ int snapmi_compress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         h_in_lens = fetched.data();
     }
-    uint64_t blocks = 0, slots = 0;
+    uint64_t blocks = 0, slots = 0, cnt4 = 0, cnt8 = 0;
     // streams under this length are the lane-per-stream kernels': no block
     const uint64_t small = small_stream_limit(ctx);
     uint32_t classes = 0; // which of those kernels have anything to do
@@ -538,9 +545,14 @@ int snapmi_compress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
         const uint64_t nb = (len + kMaxBlock - 1) / kMaxBlock;
         blocks += nb;
         slots += nb - 1;
+        // the stream's last block: a page, a short chunk, a tail?
+        const uint64_t last = len - (nb - 1) * kMaxBlock;
+        cnt4 += last <= 4096;
+        cnt8 += last > 4096 && last <= 8192;
     }
     return launch_compress(ctx, d_in_ptrs, d_in_lens, d_out_ptrs, d_out_caps,
-                           d_out_lens, d_errs, n, blocks, slots, classes);
+                           d_out_lens, d_errs, n, blocks, slots, classes,
+                           cnt4, cnt8);
 }
 
 } // extern "C"
@@ -572,7 +584,8 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                     const uint64_t *d_in_lens, void *const *d_out_ptrs,
                     const uint64_t *d_out_caps, uint64_t *d_out_lens,
                     snapmi_error *d_errs, size_t n, uint64_t blocks,
-                    uint64_t slots, uint32_t small_classes)
+                    uint64_t slots, uint32_t small_classes, uint64_t cnt4,
+                    uint64_t cnt8)
 {
     if (blocks > 0x7FFFFFFFu)
         return fail_ctx(ctx, SNAPMI_E_ARGUMENT,
@@ -616,14 +629,42 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     a.n_lanes = 0;
     a.tok_base = 0;
     a.small_limit = (uint32_t)small_stream_limit(ctx);
+    a.cls_lo = 0;
+    a.cls_hi = kMaxBlock;
     // Small batches are latency-bound: the wavefront kernel finishes a block
     // in ~2 ms, a lane needs tens of ms.  Large batches are throughput-bound
     // and go to the lane-per-block kernel.
-    const bool big = blocks >= ctx->lane_min_blocks;
+    // Blocks of at most 8 KiB (cnt4 of them <= 4 KiB, cnt8 more <= 8 KiB: the
+    // caller counted one-block streams and tails): window kernels with the
+    // tables the reference gives such blocks, 20 / 10 per CU instead of 5
+    // (k_match_spans_4k / _8k), whatever the size of the batch - every probe
+    // of the lane kernel into a block's fresh table is an HBM transaction,
+    // and the 64 KiB window kernel keeps four fifths of a CU idle.
+    const uint64_t nb_small = cnt4 + cnt8 < blocks ? cnt4 + cnt8 : blocks;
+    const bool use_small = blocks > 0 && ctx->lds_order_ok &&
+                           ctx->compress_mode == 1 &&
+                           ctx->small_table_kernel &&
+                           nb_small >= ctx->small_table_min_blocks;
+    const uint64_t nb_big = use_small ? blocks - nb_small : blocks;
+    const bool big = nb_big >= ctx->lane_min_blocks;
     // (a device that failed the LDS order self-check only has the lane kernel)
+    // Round 5: a mid-size batch (more than two blocks per CU, fewer than
+    // lane_min_blocks) takes the token path as well, with the WINDOW kernel
+    // as its match finder (k_match_spans): every block at its final position,
+    // no slots, no k_compact, and the encoder is a wide kernel of its own
+    // instead of one flush per five steps of a lone wavefront.  Costs 128 KiB
+    // of tokens per block of the batch (at most 1 GiB); compress_mode 0 and
+    // window_tokens 0 keep the kernel that encodes while it matches.
+    const bool win_tok =
+        blocks > 0 && ctx->lds_order_ok && ctx->compress_mode == 1 && !big &&
+        (use_small ||
+         (ctx->window_tokens &&
+          !(ctx->small_batch_kernel == 2 ||
+            (ctx->small_batch_kernel == 1 &&
+             blocks <= 2 * (uint64_t)ctx->num_cus))));
     const bool lanes_mode =
         blocks > 0 &&
-        (!ctx->lds_order_ok || (ctx->compress_mode != 0 && big));
+        (!ctx->lds_order_ok || (ctx->compress_mode != 0 && big) || win_tok);
     // the lane kernel runs over segments of the block list so that the token
     // scratch (128 KiB per block) stays bounded; "both at once" needs the
     // whole list in one segment
@@ -653,7 +694,7 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     // nothing (cfg5: 12 ms of lane kernel for 32 GiB against ~4 of windows).
     bool span_match = false;
     if (lanes_mode && !waves_mode && ctx->lds_order_ok) {
-        if (ctx->match_kernel == 1) {
+        if (ctx->match_kernel == 1 || win_tok) {
             span_match = true;
         } else if (ctx->match_kernel == 2 && ctx->h_ratio) {
             // the slot of the latest batch that has finished (a slot reads
@@ -971,7 +1012,7 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                 // it does: 121.6 -> 135 ms at cfg2.  Kept as a measured dead
                 // end that the encoder tests still run through.
                 uint64_t mid = hi;
-                if (!waves_mode &&
+                if (!waves_mode && !use_small &&
                     (ctx->lane_overlap_encode == 2
                          ? hi - lo >= 2
                          : (ctx->lane_overlap_encode == 1 &&
@@ -993,9 +1034,15 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                 const bool spec = ctx->lane_speculate &&
                                   hi - lo <= a.n_lanes &&
                                   hi - lo <= ctx->lane_speculate_max_blocks;
-                if (span_match) {
+                // (with the small-block kernels on, this launch's class is
+                // the blocks of more than 8 KiB - if the batch has any)
+                a.cls_lo = use_small ? 8192 : 0;
+                if (use_small && nb_big == 0) {
+                } else if (span_match) {
+                    const uint64_t mine =
+                        use_small && nb_big < mid - lo ? nb_big : mid - lo;
                     const uint64_t want =
-                        (mid - lo + kCompressWaves - 1) / kCompressWaves;
+                        (mine + kCompressWaves - 1) / kCompressWaves;
                     hipLaunchKernelGGL(
                         k_match_spans,
                         dim3((uint32_t)(want < (uint64_t)ctx->num_cus
@@ -1004,6 +1051,36 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                 } else
                 hipLaunchKernelGGL(spec ? k_match_blocks_spec : k_match_blocks,
                                    dim3(a.n_lanes / 64), dim3(64), 0, s, a);
+                if (use_small) {
+                    // 640-thread workgroups: two per CU with 8 KiB tables,
+                    // one with 16 KiB tables
+                    if (cnt4) {
+                        HIP_TRY(ctx, hipMemsetAsync(ctx->ticket.p, 0, 64, s));
+                        a.cls_lo = 0;
+                        a.cls_hi = 4096;
+                        const uint64_t want =
+                            (cnt4 + kSmallTableWaves - 1) / kSmallTableWaves;
+                        const uint64_t room = 2 * (uint64_t)ctx->num_cus;
+                        hipLaunchKernelGGL(
+                            k_match_spans_4k,
+                            dim3((uint32_t)(want < room ? want : room)),
+                            dim3(kSmallTableWaves * 64), 0, s, a);
+                    }
+                    if (cnt8) {
+                        HIP_TRY(ctx, hipMemsetAsync(ctx->ticket.p, 0, 64, s));
+                        a.cls_lo = 4096;
+                        a.cls_hi = 8192;
+                        const uint64_t want =
+                            (cnt8 + kSmallTableWaves - 1) / kSmallTableWaves;
+                        const uint64_t room = ctx->num_cus;
+                        hipLaunchKernelGGL(
+                            k_match_spans_8k,
+                            dim3((uint32_t)(want < room ? want : room)),
+                            dim3(kSmallTableWaves * 64), 0, s, a);
+                    }
+                }
+                a.cls_lo = 0;
+                a.cls_hi = kMaxBlock;
                 if (mid < hi) {
                     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
                     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2,

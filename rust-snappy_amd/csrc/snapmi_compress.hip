@@ -968,58 +968,69 @@ __device__ __forceinline__ void lds_mskor(uint32_t byte_addr, uint32_t mask,
 }
 
 namespace {
-// The window kernel as a MATCH FINDER for the lane kernel's encoder
-// (k_match_spans): the same record / flush interface as TokenSink, but a
-// flush stores the wave's pending tokens in k_encode_tokens' format (literal
-// length | copy length << 17 | offset << 33), 64 of them coalesced, and adds
-// up what they will encode to (token_bytes) - so that, as behind
-// k_match_blocks, every block's size is known before a byte of it is written
-// and k_encode_tokens can put it at its final position (no scratch slots, no
-// k_compact).
+// The window kernel as a MATCH FINDER for k_encode_tokens (k_match_spans):
+// tokens leave in that kernel's format (literal length | copy length << 17 |
+// offset << 33) and what they will encode to is added up (token_bytes) - so
+// that, as behind k_match_blocks, every block's size is known before a byte
+// of it is written and the encoder can put it at its final position (no
+// scratch slots, no k_compact).  Round 5: a step's tokens are stored by the
+// lanes that found them, at their rank among the step's copies - no push into
+// a token register (two ds_permute and their round trip per step), no flush:
+// one predicated 8-byte store and a per-lane sum of sizes.
 struct TokenWriter {
     typedef __attribute__((address_space(1))) unsigned long long g_u64;
     g_u64 *tok;    // this block's token array
     uint32_t ntok; // tokens stored so far (uniform)
-    uint32_t d;    // encoded bytes of the tokens stored so far (uniform)
-    uint32_t a, b; // this lane's pending token (TokenSink's packing)
-    uint32_t t;    // tokens pending (uniform)
+    uint32_t dsum; // encoded bytes of the tokens THIS LANE stored
+    uint32_t d;    // finish(): encoded bytes of the block (uniform)
+    uint32_t t;    // always 0 (TokenSink's interface: nothing is pending)
     uint32_t lane;
 
     __device__ __forceinline__ void init(g_u64 *tokens, uint32_t l)
     {
         tok = tokens;
         ntok = 0;
+        dsum = 0;
         d = 0;
-        a = b = 0;
         t = 0;
         lane = l;
     }
+    // one token, the same in every lane
     __device__ __forceinline__ void record_nf(uint32_t lit_start,
                                               uint32_t lit_len,
                                               uint32_t offset,
                                               uint32_t copy_len)
     {
-        const bool me = lane == t;
-        a = me ? ((lit_len & 0xFFFFu) | (offset << 16)) : a;
-        b = me ? (copy_len | (lit_start << 16)) : b;
-        t++;
+        (void)lit_start; // (k_encode_tokens adds the lengths up)
+        if (lane == 0) {
+            tok[ntok] = (unsigned long long)lit_len |
+                        ((unsigned long long)copy_len << 17) |
+                        ((unsigned long long)offset << 33);
+            dsum += token_bytes(lit_len, copy_len, offset);
+        }
+        ntok++;
     }
-    __device__ __forceinline__ void flush()
+    // the copies of a window step: lane `mine` holds the rank-th of cnt
+    // tokens, a copy of 4..15 bytes (one element: src/compress.rs:339-356)
+    __device__ __forceinline__ void put_step(bool mine, uint32_t rank,
+                                             uint32_t cnt, uint32_t lit_len,
+                                             uint32_t copy_len,
+                                             uint32_t offset)
     {
-        const bool act = lane < t;
-        const uint32_t C = act ? (b & 0xFFFFu) : 0;
-        uint32_t L = act ? (a & 0xFFFFu) : 0;
-        if (act && L == 0 && C == 0)
-            L = kMaxBlock; // (TokenSink: the one length that needs 17 bits)
-        const uint32_t O = a >> 16;
-        if (act)
-            tok[ntok + lane] = (unsigned long long)L |
-                               ((unsigned long long)C << 17) |
-                               ((unsigned long long)O << 33);
-        const uint32_t size = act ? token_bytes(L, C, O) : 0;
-        d += rdlane(wave_inclusive_scan(size), kWave - 1);
-        ntok += t;
-        t = 0;
+        if (mine)
+            tok[ntok + rank] = (unsigned long long)lit_len |
+                               ((unsigned long long)copy_len << 17) |
+                               ((unsigned long long)offset << 33);
+        const uint32_t lt =
+            lit_len == 0 ? 0 : (lit_len <= 60 ? 1 : (lit_len <= 256 ? 2 : 3));
+        const uint32_t fin = copy_len <= 11 && offset <= 2047 ? 2 : 3;
+        dsum += mine ? lt + lit_len + fin : 0;
+        ntok += cnt;
+    }
+    __device__ __forceinline__ void flush() {}
+    __device__ __forceinline__ void finish()
+    {
+        d = rdlane(wave_inclusive_scan(dsum), kWave - 1);
     }
 };
 struct SpanLanes {
@@ -1094,7 +1105,8 @@ template <bool kLds, bool kTok = false>
 __device__ __forceinline__ void compress_one_block_span(
     const CompressArgs &a, const uint32_t b, const uint32_t lane,
     const lptr16 table, const uint32_t tbase,
-    __attribute__((address_space(3))) uint8_t *lblock = nullptr)
+    __attribute__((address_space(3))) uint8_t *lblock = nullptr,
+    const uint32_t tcap = kMaxTable)
 {
     // stream lookup: blk_first[st] <= b < blk_first[st + 1]
     uint32_t lo_s = 0, hi_s = a.n_streams;
@@ -1112,6 +1124,8 @@ __device__ __forceinline__ void compress_one_block_span(
     gcptr src = (gcptr)a.in_ptrs[st_i] + boff;
     const uint64_t avail = total - boff;
     const uint32_t n = avail < kMaxBlock ? (uint32_t)avail : kMaxBlock;
+    if (n <= a.cls_lo || n > a.cls_hi)
+        return; // another launch's block (CompressArgs::cls_lo)
 
     typename std::conditional<kTok, TokenWriter, TokenSink>::type out;
     if constexpr (kTok) {
@@ -1144,7 +1158,10 @@ __device__ __forceinline__ void compress_one_block_span(
     }
     if (n < kMinNonLiteral) { // src/compress.rs:140-146
         out.record_nf(0, n, 0, 0);
-        out.flush();
+        if constexpr (kTok)
+            out.finish();
+        else
+            out.flush();
         if (lane == 0) {
             a.blk_size[b] = out.d;
             if constexpr (kTok)
@@ -1168,8 +1185,10 @@ __device__ __forceinline__ void compress_one_block_span(
         msrc = src;
     }
     // table sizing + zero fill: src/compress.rs:491-518
+    // (tcap: the entries this kernel's table has room for - kMaxTable, or the
+    // 4 096 / 8 192 of the small-block kernels, whose class never needs more)
     uint32_t shift = 32 - 8, tsize = 256;
-    while (tsize < kMaxTable && tsize < n) {
+    while (tsize < tcap && tsize < n) {
         shift--;
         tsize *= 2;
     }
@@ -1215,8 +1234,10 @@ __device__ __forceinline__ void compress_one_block_span(
         TICK(0);
         // room for a step's tokens (at most 16 copies of a window + a long
         // match): the one place where tokens are encoded
-        if (out.t + 17 > kWave)
-            out.flush();
+        if constexpr (!kTok) {
+            if (out.t + 17 > kWave)
+                out.flush();
+        }
         if (!st.chain && st.q >= kSpanRun) {
             // ---- schedule step (k_compress_blocks' batch for q > 0): lane l
             // is probe q + l of the run that began at run0
@@ -1334,21 +1355,28 @@ __device__ __forceinline__ void compress_one_block_span(
                         (uint32_t)(vh >> 32),
                         __builtin_amdgcn_mbcnt_lo((uint32_t)vh, 0));
                     const bool is_vh = (vh >> lane) & 1;
-                    // token of lane X goes to sink lane t + rank: a push
-                    // (ds_permute); the other lanes push to a lane outside
-                    // [t, t + cnt) whose value is not taken
-                    const uint32_t to =
-                        is_vh ? out.t + rank : (out.t + cnt) & 63u;
-                    const uint32_t ta = (lit & 0xFFFFu) | ((P - old) << 16);
-                    const uint32_t tb = ln.mv | ((P - lit) << 16);
-                    const uint32_t ra = (uint32_t)__builtin_amdgcn_ds_permute(
-                        (int)(to << 2), (int)ta);
-                    const uint32_t rb = (uint32_t)__builtin_amdgcn_ds_permute(
-                        (int)(to << 2), (int)tb);
-                    const bool got = lane - out.t < cnt;
-                    out.a = got ? ra : out.a;
-                    out.b = got ? rb : out.b;
-                    out.t += cnt;
+                    if constexpr (kTok) {
+                        out.put_step(is_vh, rank, cnt, lit, ln.mv, P - old);
+                    } else {
+                        // token of lane X goes to sink lane t + rank: a push
+                        // (ds_permute); the other lanes push to a lane
+                        // outside [t, t + cnt) whose value is not taken
+                        const uint32_t to =
+                            is_vh ? out.t + rank : (out.t + cnt) & 63u;
+                        const uint32_t ta =
+                            (lit & 0xFFFFu) | ((P - old) << 16);
+                        const uint32_t tb = ln.mv | ((P - lit) << 16);
+                        const uint32_t ra =
+                            (uint32_t)__builtin_amdgcn_ds_permute(
+                                (int)(to << 2), (int)ta);
+                        const uint32_t rb =
+                            (uint32_t)__builtin_amdgcn_ds_permute(
+                                (int)(to << 2), (int)tb);
+                        const bool got = lane - out.t < cnt;
+                        out.a = got ? ra : out.a;
+                        out.b = got ? rb : out.b;
+                        out.t += cnt;
+                    }
                 }
             }
             if (!fast)
@@ -1413,8 +1441,12 @@ __device__ __forceinline__ void compress_one_block_span(
     }
     if (sink.emit < n) // done(): src/compress.rs:417-426
         out.record_nf(sink.emit, n - sink.emit, 0, 0);
-    if (out.t)
-        out.flush();
+    if constexpr (kTok) {
+        out.finish();
+    } else {
+        if (out.t)
+            out.flush();
+    }
     if (lane == 0) {
         a.blk_size[b] = out.d;
         if constexpr (kTok)
@@ -1460,6 +1492,45 @@ __global__ __launch_bounds__(kCompressWaves * 64) void k_match_spans(
         compress_one_block_span<false, true>(a, b, lane, table, tbase);
         b = a.blk_lo + uni(next_front_ticket(a.ticket, lane));
     }
+}
+
+// k_match_spans for blocks of at most kEntries bytes: a table of kEntries
+// u16 is all the reference gives such a block (src/compress.rs:491-518), so
+// kWaves x 2 workgroups (4 096 entries: 20 wavefronts per CU) or kWaves x 1
+// (8 192: 10) fit where the 64 KiB kernel has room for five.  The window
+// kernel is bound by the instructions and latencies of ONE wavefront per
+// SIMD; with five per SIMD the CU is busy.  Only blocks of the launch's class
+// (CompressArgs::cls_lo/cls_hi, <= kEntries bytes) are taken.
+template <uint32_t kEntries, uint32_t kWaves>
+__device__ __forceinline__ void match_spans_small(const CompressArgs &a)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t tables[kWaves][kEntries];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    const lptr16 table = (lptr16)&tables[wave][0];
+    const uint32_t tbase = (uint32_t)(uintptr_t)table;
+    uint32_t nblocks = a.blk_first[a.n_streams];
+    if (nblocks > a.host_blocks)
+        nblocks = a.host_blocks;
+    if (nblocks > a.blk_hi)
+        nblocks = a.blk_hi;
+    uint32_t b = a.blk_lo + uni(next_front_ticket(a.ticket, lane));
+    while (b < nblocks) {
+        compress_one_block_span<false, true>(a, b, lane, table, tbase,
+                                             nullptr, kEntries);
+        b = a.blk_lo + uni(next_front_ticket(a.ticket, lane));
+    }
+}
+__global__ __launch_bounds__(kSmallTableWaves * 64)
+    __attribute__((amdgpu_waves_per_eu(5, 5))) void k_match_spans_4k(
+        CompressArgs a)
+{
+    match_spans_small<4096, kSmallTableWaves>(a);
+}
+__global__ __launch_bounds__(kSmallTableWaves * 64) void k_match_spans_8k(
+    CompressArgs a)
+{
+    match_spans_small<8192, kSmallTableWaves>(a);
 }
 
 // What the batch compressed to, posted into pinned host memory for the NEXT
@@ -1951,7 +2022,9 @@ __device__ __forceinline__ void match_blocks(const CompressArgs &a)
                 csize = 0;
                 next_emit = 0;
                 have = true;
-                if (n < kMinNonLiteral) { // src/compress.rs:140-146
+                if (n <= a.cls_lo || n > a.cls_hi) {
+                    have = false; // another launch's block
+                } else if (n < kMinNonLiteral) { // src/compress.rs:140-146
                     tok[0] = (unsigned long long)n;
                     a.ntok[b] = 1;
                     a.blk_size[b] = token_bytes(n, 0, 0);

@@ -969,7 +969,8 @@ static int frame_compress_impl(snapmi_ctx *ctx, const void *d_in,
                                uint64_t in_len, uint32_t n,
                                const uint64_t *d_chunk_in_off, bool ident,
                                void *d_out, uint64_t *d_out_len,
-                               uint64_t *d_chunk_offsets)
+                               uint64_t *d_chunk_offsets,
+                               const uint32_t *h_chunk_lens = nullptr)
 {
     hipStream_t s = ctx->stream;
     int rc = ensure_tables(ctx);
@@ -1030,8 +1031,16 @@ static int frame_compress_impl(snapmi_ctx *ctx, const void *d_in,
         if (side)
             HIP_TRY(ctx, hipEventRecord(ctx->ev_crc[1], ctx->stream2));
         // every chunk is a one-block raw stream: cnt blocks, no scratch slots
+        // (chunks cut short by the caller - flushes, short reads - are
+        // counted for the small-block kernels)
+        uint64_t c4 = 0, c8 = 0;
+        if (h_chunk_lens)
+            for (uint32_t i = lo; i < lo + cnt; i++) {
+                c4 += h_chunk_lens[i] <= 4096;
+                c8 += h_chunk_lens[i] > 4096 && h_chunk_lens[i] <= 8192;
+            }
         rc = launch_compress(ctx, a.in_ptrs, a.in_lens, a.slot_ptrs, nullptr,
-                             a.clens, nullptr, cnt, cnt, 0);
+                             a.clens, nullptr, cnt, cnt, 0, 0xF, c4, c8);
         if (rc)
             return rc;
         if (side)
@@ -1113,7 +1122,8 @@ int snapmi_frame_compress_chunks(snapmi_ctx *ctx, const void *d_in,
     HIP_TRY(ctx, hipStreamSynchronize(s)); // `off` is pageable host memory
     return frame_compress_impl(ctx, d_in, off[n], (uint32_t)n,
                                (const uint64_t *)ctx->fr_chunk_off.p, ident,
-                               d_out, d_out_len, d_chunk_offsets);
+                               d_out, d_out_len, d_chunk_offsets,
+                               h_chunk_lens);
 }
 
 int snapmi_frame_index_host(const void *h_in, uint64_t in_len,
@@ -1730,7 +1740,7 @@ int snapmi_frame_encode_host(snapmi_ctx *ctx, const uint8_t *h_in,
             // slice; so would one of the result)
             rc = snapmi::frame_compress_impl(
                 ctx, s.in.p, x.bytes, (uint32_t)cn, s.h_off, ident, s.out.p,
-                d_len, nullptr);
+                d_len, nullptr, h_chunk_lens + x.c0);
             if (rc)
                 return rc;
             hipLaunchKernelGGL(k_post_words, dim3(1), dim3(64), 0, sK,

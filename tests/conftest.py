@@ -47,7 +47,7 @@ def ctx(request, built):
 @pytest.fixture(scope="session",
                 params=["spans", "spans_lds", "waves", "waves_lds", "lanes",
                         "lanes_segmented", "lanes_overlap", "both",
-                        "spans_match"])
+                        "spans_match", "small_tables", "small_tables_lanes"])
 def cctx(request, built):
     """A context per compressor kernel: the wavefront-per-block kernels (window
     steps and, as the cross-check, one copy per step; five tables per CU and
@@ -56,7 +56,12 @@ def cctx(request, built):
     parity test of the encoder runs through all of them.  "lanes" and
     "lanes_segmented" encode every block at its final position
     (lane_direct_encode); "lanes_overlap" and "both" go through the scratch
-    slots and k_compact."""
+    slots and k_compact.  "small_tables*": every block of at most 4 / 8 KiB
+    goes to the window kernels with 8 / 16 KiB tables (k_match_spans_4k /
+    _8k) however few there are, the larger blocks to the window kernel as
+    match finder or to the lane kernel (both skip the other classes' blocks)
+    - the configurations above switch those kernels off, so that they keep
+    testing the kernels they name on blocks of every size."""
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
@@ -65,8 +70,13 @@ def cctx(request, built):
     c.set_option("compress_mode", {"spans": 0, "spans_lds": 0, "waves": 0,
                                    "waves_lds": 0, "lanes": 1,
                                    "lanes_segmented": 1, "lanes_overlap": 1,
-                                   "both": 2, "spans_match": 1}[
+                                   "both": 2, "spans_match": 1,
+                                   "small_tables": 1,
+                                   "small_tables_lanes": 1}[
         request.param])
+    small = request.param.startswith("small_tables")
+    c.set_option("small_table_kernel", 1 if small else 0)
+    c.set_option("small_table_min_blocks", 1)
     # the token path's match finder: the lane kernel in the "lanes*"
     # configurations whatever the last batch compressed to (the default picks
     # by that), the window kernel (k_match_spans) in "spans_match"
@@ -79,7 +89,11 @@ def cctx(request, built):
                  2 if request.param in ("waves_lds", "spans_lds") else 0)
     c.set_option("span_kernel",
                  0 if request.param in ("waves", "waves_lds") else 1)
-    c.set_option("lane_min_blocks", 1)
+    # (small_tables: blocks of more than 8 KiB by the window kernel as match
+    # finder; small_tables_lanes and the others: by what lane_min_blocks 1
+    # and compress_mode select)
+    c.set_option("lane_min_blocks",
+                 1 << 30 if request.param == "small_tables" else 1)
     # streams under 256 bytes / under 2 KiB are k_compress_tiny's /
     # k_compress_small's by default; two of the six configurations keep them
     # with the block kernels, so the block kernels' handling of small blocks

@@ -23,14 +23,19 @@ print("library", os.environ.get("SNAPMI_LIB", "default"))
 for name in names:
     blob = (O.CORPUS / name).read_bytes()
     want = O.compress(blob)
-    ctx = raw.Context(0)
-    ctx.set_option("compress_mode", 0)
-    ctx.set_option("small_batch_kernel", 0)
-    for gib in (1 / 16, 0.25, 1.0):
-        n, c, reps, te, td = B.raw_tiles(ctx, dev, blob, gib, 3, want)
-        print(f"{name:14s} spans {gib:7.4f} GiB {te*1e3:9.3f} ms "
-              f"{n/2**30/te:7.1f} GiB/s", flush=True)
-    ctx.close()
+    for cfg in ("inline", "tokens"):
+        ctx = raw.Context(0)
+        if cfg == "inline":  # k_compress_spans: encodes while it matches
+            ctx.set_option("compress_mode", 0)
+            ctx.set_option("small_batch_kernel", 0)
+        else:  # k_match_spans + k_encode_tokens, whatever the batch size
+            ctx.set_option("lane_min_blocks", 1 << 30)
+            ctx.set_option("small_batch_kernel", 0)
+        for gib in (1 / 16, 0.25, 1.0):
+            n, c, reps, te, td = B.raw_tiles(ctx, dev, blob, gib, 5, want)
+            print(f"{name:14s} {cfg:6s} {gib:7.4f} GiB {te*1e3:9.3f} ms "
+                  f"{n/2**30/te:7.1f} GiB/s", flush=True)
+        ctx.close()
 enc = R.raw.Encoder()
 for name, data in O.corpus_round():
     comp = enc.compress_vec(data)

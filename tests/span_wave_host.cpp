@@ -224,7 +224,7 @@ struct WaveHost {
 // stats[0] window steps, [1] schedule steps, [2] cuts of fast steps, [3] long
 // matches,
 // [4] tokens, [5] lanes touched, [6] tokens of window steps, [7] window
-// steps that took the fast walk
+// steps that took the fast walk, [8] the table's entries
 extern "C" uint32_t span_wave_compress(const uint8_t *src, uint32_t n,
                                        uint8_t *out, uint32_t out_cap,
                                        uint64_t *stats)
@@ -245,11 +245,17 @@ extern "C" uint32_t span_wave_compress(const uint8_t *src, uint32_t n,
         d = tiny_put_literal(o, d, 0, n);
         return o.bad ? 0x80000001u : d;
     }
-    uint32_t shift = 24;
-    for (uint32_t size = 256; size < 16384 && size < n; size *= 2)
+    // the table the kernel instance for this block length has room for
+    // (k_match_spans_4k / _8k / the 64 KiB kernels): every index below is
+    // checked against what the reference would allocate (tsize) AND against
+    // that room
+    const uint32_t room = n <= 4096 ? 4096 : (n <= 8192 ? 8192 : 16384);
+    uint32_t shift = 24, tsize = 256;
+    for (; tsize < room && tsize < n; tsize *= 2)
         shift--;
-    static thread_local uint16_t table[16384];
-    memset(table, 0, sizeof table);
+    stats[8] = tsize;
+    std::vector<uint16_t> table_mem(room, 0);
+    uint16_t *const table = table_mem.data();
     const uint32_t s_limit = n - 15;
     SpanState st{1, 0, 0, 0};
     Sink sink;
@@ -274,6 +280,8 @@ extern "C" uint32_t span_wave_compress(const uint8_t *src, uint32_t n,
                 m[l] = 0;
                 if (valid[l]) {
                     h[l] = tiny_hash(le32(src + p[l]), shift);
+                    if (h[l] >= tsize)
+                        return 0x80000004u;
                     cand[l] = table[h[l]];
                     table[h[l]] = (uint16_t)p[l];
                     m[l] = common(src + p[l], src + cand[l], 16);
@@ -317,6 +325,8 @@ extern "C" uint32_t span_wave_compress(const uint8_t *src, uint32_t n,
             if (!act[l])
                 continue;
             h[l] = tiny_hash(le32(src + P), shift);
+            if (h[l] >= tsize)
+                return 0x80000004u;
             ln.ov[l] = table[h[l]];
             table[h[l]] = (uint16_t)P;
             ln.mv[l] = common(src + P, src + ln.ov[l], 16);

@@ -32,7 +32,7 @@ def span(tmp_path_factory):
     def run(data):
         cap = len(data) + len(data) // 6 + 64
         out = C.create_string_buffer(cap)
-        st = (C.c_uint64 * 8)()
+        st = (C.c_uint64 * 16)()
         r = L.span_wave_compress(bytes(data), len(data), out, cap, st)
         assert r < 0x80000000, hex(r)
         return out.raw[:r], list(st)
@@ -114,3 +114,23 @@ def test_fast_walk_equals_the_exact_walk_on_random_windows(tmp_path):
     windows, cuts, longs, runs = list(seen)
     assert windows > 500000 and cuts > 50000 and longs > 50000 \
         and runs > 5000, list(seen)
+
+
+def test_small_block_tables_at_every_length(span):
+    """The small-block window kernels (k_match_spans_4k / _8k) give a block of
+    n <= 4 096 / 8 192 bytes a table of that many entries at most: the host
+    model allocates exactly that room and checks every index, the table must
+    be what the reference sizes for n (src/compress.rs:491-518: the power of
+    two at or above n, 256 .. 16 384), and the stream the oracle's - every
+    length 1 024 .. 8 193, three kinds of data."""
+    rng = random.Random(5)
+    txt = (O.CORPUS / "alice29.txt").read_bytes()
+    noise = bytes(rng.randrange(4) for _ in range(9000))
+    for n in range(1024, 8194):
+        want_table = 256
+        while want_table < 16384 and want_table < n:
+            want_table *= 2
+        for data in (txt[n:2 * n], noise[:n], (txt[:97] * 90)[:n]):
+            got, st = span(data)
+            assert st[8] == want_table, (n, st[8])
+            assert got == O.compress(data), n
