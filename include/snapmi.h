@@ -130,20 +130,20 @@ const char *snapmi_version(void);
  *                          lane-per-block kernel on large batches (default)
  *                          [2, both at once, is a cross-check of the test
  *                          build: snapmi_test.h]
- *   "window_tokens"        1 (default): a batch of more than two blocks per
- *                          CU and fewer than lane_min_blocks runs the window
- *                          kernel as a match finder and encodes with a wide
- *                          kernel of its own (128 KiB of token scratch per
- *                          block of the batch, at most 1 GiB); 0: the window
- *                          kernel encodes while it matches, as under
- *                          compress_mode 0 (no scratch but the block slots)
- *   "small_table_kernel"   1 (default): blocks of at most 4 KiB / 8 KiB -
- *                          pages, short frame chunks, tails - are matched by
- *                          window kernels with the 8 / 16 KiB tables the
- *                          reference gives them (src/compress.rs:491-518),
- *                          20 / 10 wavefronts per CU instead of 5, when a
- *                          batch has "small_table_min_blocks" (default 256)
- *                          of them; 0: they are blocks like any other
+ *   "window_tokens"        1: a batch of more than two blocks per CU and
+ *                          fewer than lane_min_blocks runs the window kernel
+ *                          as a match finder and encodes with a wide kernel
+ *                          of its own (128 KiB of token scratch per block of
+ *                          the batch, at most 1 GiB); 0 (default): the window
+ *                          kernel encodes while it matches (no scratch but
+ *                          the block slots) - the two measure within 3 %
+ *   "small_table_kernel"   1 (default): blocks of at most 8 KiB - pages,
+ *                          short frame chunks, tails - are matched by a
+ *                          window kernel with the 16 KiB table the reference
+ *                          gives them (src/compress.rs:491-518), ten
+ *                          wavefronts per CU instead of five, when a batch
+ *                          has "small_table_min_blocks" (default 256) of
+ *                          them; 0: they are blocks like any other
  *   "small_batch_kernel"   1 (default): batches of at most two blocks per
  *                          CU run one block per CU with table AND input block
  *                          in LDS; 0 never; 2 whenever the wavefront kernel

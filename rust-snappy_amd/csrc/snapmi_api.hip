@@ -526,7 +526,7 @@ int snapmi_compress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         h_in_lens = fetched.data();
     }
-    uint64_t blocks = 0, slots = 0, cnt4 = 0, cnt8 = 0;
+    uint64_t blocks = 0, slots = 0, cnt8 = 0;
     // streams under this length are the lane-per-stream kernels': no block
     const uint64_t small = small_stream_limit(ctx);
     uint32_t classes = 0; // which of those kernels have anything to do
@@ -547,12 +547,11 @@ int snapmi_compress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
         slots += nb - 1;
         // the stream's last block: a page, a short chunk, a tail?
         const uint64_t last = len - (nb - 1) * kMaxBlock;
-        cnt4 += last <= 4096;
-        cnt8 += last > 4096 && last <= 8192;
+        cnt8 += last <= 8192;
     }
     return launch_compress(ctx, d_in_ptrs, d_in_lens, d_out_ptrs, d_out_caps,
                            d_out_lens, d_errs, n, blocks, slots, classes,
-                           cnt4, cnt8);
+                           cnt8);
 }
 
 } // extern "C"
@@ -584,8 +583,7 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                     const uint64_t *d_in_lens, void *const *d_out_ptrs,
                     const uint64_t *d_out_caps, uint64_t *d_out_lens,
                     snapmi_error *d_errs, size_t n, uint64_t blocks,
-                    uint64_t slots, uint32_t small_classes, uint64_t cnt4,
-                    uint64_t cnt8)
+                    uint64_t slots, uint32_t small_classes, uint64_t cnt8)
 {
     if (blocks > 0x7FFFFFFFu)
         return fail_ctx(ctx, SNAPMI_E_ARGUMENT,
@@ -634,13 +632,15 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     // Small batches are latency-bound: the wavefront kernel finishes a block
     // in ~2 ms, a lane needs tens of ms.  Large batches are throughput-bound
     // and go to the lane-per-block kernel.
-    // Blocks of at most 8 KiB (cnt4 of them <= 4 KiB, cnt8 more <= 8 KiB: the
-    // caller counted one-block streams and tails): window kernels with the
-    // tables the reference gives such blocks, 20 / 10 per CU instead of 5
-    // (k_match_spans_4k / _8k), whatever the size of the batch - every probe
-    // of the lane kernel into a block's fresh table is an HBM transaction,
-    // and the 64 KiB window kernel keeps four fifths of a CU idle.
-    const uint64_t nb_small = cnt4 + cnt8 < blocks ? cnt4 + cnt8 : blocks;
+    // Blocks of at most 8 KiB (cnt8 of them: the caller counted one-block
+    // streams and tails): a window kernel with the table the reference gives
+    // such blocks, ten per CU instead of five (k_match_spans_8k), whatever
+    // the size of the batch - every probe of the lane kernel into a block's
+    // fresh table is an HBM transaction, and the 64 KiB window kernel keeps a
+    // CU's issue slots four fifths idle.  (Twenty tables of 8 KiB per CU for
+    // blocks of at most 4 KiB were built too and measured the same: at ten
+    // wavefronts the CU's one scalar unit is 70 % busy.)
+    const uint64_t nb_small = cnt8 < blocks ? cnt8 : blocks;
     const bool use_small = blocks > 0 && ctx->lds_order_ok &&
                            ctx->compress_mode == 1 &&
                            ctx->small_table_kernel &&
@@ -648,13 +648,12 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     const uint64_t nb_big = use_small ? blocks - nb_small : blocks;
     const bool big = nb_big >= ctx->lane_min_blocks;
     // (a device that failed the LDS order self-check only has the lane kernel)
-    // Round 5: a mid-size batch (more than two blocks per CU, fewer than
-    // lane_min_blocks) takes the token path as well, with the WINDOW kernel
-    // as its match finder (k_match_spans): every block at its final position,
-    // no slots, no k_compact, and the encoder is a wide kernel of its own
-    // instead of one flush per five steps of a lone wavefront.  Costs 128 KiB
-    // of tokens per block of the batch (at most 1 GiB); compress_mode 0 and
-    // window_tokens 0 keep the kernel that encodes while it matches.
+    // The token path with the WINDOW kernel as its match finder
+    // (k_match_spans): every block at its final position, no slots, no
+    // k_compact, the encoder a wide kernel of its own.  What the small-block
+    // kernel runs on, and - option window_tokens - a mid-size batch (more
+    // than two blocks per CU, fewer than lane_min_blocks); costs 128 KiB of
+    // tokens per block of the batch.
     const bool win_tok =
         blocks > 0 && ctx->lds_order_ok && ctx->compress_mode == 1 && !big &&
         (use_small ||
@@ -1052,32 +1051,17 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                 hipLaunchKernelGGL(spec ? k_match_blocks_spec : k_match_blocks,
                                    dim3(a.n_lanes / 64), dim3(64), 0, s, a);
                 if (use_small) {
-                    // 640-thread workgroups: two per CU with 8 KiB tables,
-                    // one with 16 KiB tables
-                    if (cnt4) {
-                        HIP_TRY(ctx, hipMemsetAsync(ctx->ticket.p, 0, 64, s));
-                        a.cls_lo = 0;
-                        a.cls_hi = 4096;
-                        const uint64_t want =
-                            (cnt4 + kSmallTableWaves - 1) / kSmallTableWaves;
-                        const uint64_t room = 2 * (uint64_t)ctx->num_cus;
-                        hipLaunchKernelGGL(
-                            k_match_spans_4k,
-                            dim3((uint32_t)(want < room ? want : room)),
-                            dim3(kSmallTableWaves * 64), 0, s, a);
-                    }
-                    if (cnt8) {
-                        HIP_TRY(ctx, hipMemsetAsync(ctx->ticket.p, 0, 64, s));
-                        a.cls_lo = 4096;
-                        a.cls_hi = 8192;
-                        const uint64_t want =
-                            (cnt8 + kSmallTableWaves - 1) / kSmallTableWaves;
-                        const uint64_t room = ctx->num_cus;
-                        hipLaunchKernelGGL(
-                            k_match_spans_8k,
-                            dim3((uint32_t)(want < room ? want : room)),
-                            dim3(kSmallTableWaves * 64), 0, s, a);
-                    }
+                    // one 640-thread workgroup per CU: ten 16 KiB tables
+                    HIP_TRY(ctx, hipMemsetAsync(ctx->ticket.p, 0, 64, s));
+                    a.cls_lo = 0;
+                    a.cls_hi = 8192;
+                    const uint64_t want =
+                        (nb_small + kSmallTableWaves - 1) / kSmallTableWaves;
+                    const uint64_t room = ctx->num_cus;
+                    hipLaunchKernelGGL(
+                        k_match_spans_8k,
+                        dim3((uint32_t)(want < room ? want : room)),
+                        dim3(kSmallTableWaves * 64), 0, s, a);
                 }
                 a.cls_lo = 0;
                 a.cls_hi = kMaxBlock;

@@ -1186,7 +1186,7 @@ __device__ __forceinline__ void compress_one_block_span(
     }
     // table sizing + zero fill: src/compress.rs:491-518
     // (tcap: the entries this kernel's table has room for - kMaxTable, or the
-    // 4 096 / 8 192 of the small-block kernels, whose class never needs more)
+    // 8 192 of the small-block kernel, whose class never needs more)
     uint32_t shift = 32 - 8, tsize = 256;
     while (tsize < tcap && tsize < n) {
         shift--;
@@ -1494,17 +1494,20 @@ __global__ __launch_bounds__(kCompressWaves * 64) void k_match_spans(
     }
 }
 
-// k_match_spans for blocks of at most kEntries bytes: a table of kEntries
-// u16 is all the reference gives such a block (src/compress.rs:491-518), so
-// kWaves x 2 workgroups (4 096 entries: 20 wavefronts per CU) or kWaves x 1
-// (8 192: 10) fit where the 64 KiB kernel has room for five.  The window
-// kernel is bound by the instructions and latencies of ONE wavefront per
-// SIMD; with five per SIMD the CU is busy.  Only blocks of the launch's class
-// (CompressArgs::cls_lo/cls_hi, <= kEntries bytes) are taken.
-template <uint32_t kEntries, uint32_t kWaves>
-__device__ __forceinline__ void match_spans_small(const CompressArgs &a)
+// k_match_spans for blocks of at most 8 KiB: a table of 8 192 u16 is all the
+// reference gives such a block (src/compress.rs:491-518), so ten wavefronts
+// fit a CU where the 64 KiB kernel has room for five, and the window kernel
+// is bound by the instructions and latencies of ONE wavefront per SIMD.  Only
+// blocks of the launch's class (CompressArgs::cls_lo / cls_hi) are taken.
+// 4 KiB of alice29.txt per stream, 1 GiB: 38 -> 70 GiB/s.  (Twenty wavefronts
+// with 8 KiB tables for blocks of at most 4 KiB measured no better: from ten
+// on the CU's one scalar unit is the limit, profiles/r5_small_blocks.txt.)
+__global__ __launch_bounds__(kSmallTableWaves * 64) void k_match_spans_8k(
+    CompressArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t tables[kWaves][kEntries];
+    constexpr uint32_t kEntries = 8192;
+    __shared__ __attribute__((aligned(16)))
+    uint16_t tables[kSmallTableWaves][kEntries];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = uni(threadIdx.x >> 6);
     const lptr16 table = (lptr16)&tables[wave][0];
@@ -1520,17 +1523,6 @@ __device__ __forceinline__ void match_spans_small(const CompressArgs &a)
                                              nullptr, kEntries);
         b = a.blk_lo + uni(next_front_ticket(a.ticket, lane));
     }
-}
-__global__ __launch_bounds__(kSmallTableWaves * 64)
-    __attribute__((amdgpu_waves_per_eu(5, 5))) void k_match_spans_4k(
-        CompressArgs a)
-{
-    match_spans_small<4096, kSmallTableWaves>(a);
-}
-__global__ __launch_bounds__(kSmallTableWaves * 64) void k_match_spans_8k(
-    CompressArgs a)
-{
-    match_spans_small<8192, kSmallTableWaves>(a);
 }
 
 // What the batch compressed to, posted into pinned host memory for the NEXT

@@ -60,11 +60,13 @@ struct snapmi_ctx {
     int compress_mode = 1;
     // 1: batches between two blocks per CU and lane_min_blocks run the window
     // kernel as a match finder (k_match_spans) in front of k_encode_tokens;
-    // 0: k_compress_spans, which encodes while it matches (no token scratch)
-    int window_tokens = 1;
-    // 1: blocks of at most 8 KiB go to the window kernels with 8 / 16 KiB
-    // tables (k_match_spans_4k / _8k: 20 / 10 wavefronts per CU) when the
-    // batch has at least small_table_min_blocks of them
+    // 0 (default): k_compress_spans, which encodes while it matches (no token
+    // scratch).  Measured equal within 3 % either way on 64 MiB .. 1 GiB
+    // (profiles/r5_span_sweep.txt), so the path without scratch is the default
+    int window_tokens = 0;
+    // 1: blocks of at most 8 KiB go to the window kernel with 16 KiB tables
+    // (k_match_spans_8k: 10 wavefronts per CU) when the batch has at least
+    // small_table_min_blocks of them
     int small_table_kernel = 1;
     uint64_t small_table_min_blocks = 256;
     // k_compress_block_lds (one block per CU, input block in LDS as well):
@@ -247,7 +249,7 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                     const uint64_t *d_out_caps, uint64_t *d_out_lens,
                     snapmi_error *d_errs, size_t n, uint64_t blocks,
                     uint64_t slots, uint32_t small_classes = 0xF,
-                    uint64_t cnt4 = 0, uint64_t cnt8 = 0);
+                    uint64_t cnt8 = 0);
 // raw decompress; d_modes optional (1 = stored chunk, plain copy)
 int launch_decompress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                       const uint64_t *d_in_lens, void *const *d_out_ptrs,

@@ -1033,14 +1033,12 @@ static int frame_compress_impl(snapmi_ctx *ctx, const void *d_in,
         // every chunk is a one-block raw stream: cnt blocks, no scratch slots
         // (chunks cut short by the caller - flushes, short reads - are
         // counted for the small-block kernels)
-        uint64_t c4 = 0, c8 = 0;
+        uint64_t c8 = 0;
         if (h_chunk_lens)
-            for (uint32_t i = lo; i < lo + cnt; i++) {
-                c4 += h_chunk_lens[i] <= 4096;
-                c8 += h_chunk_lens[i] > 4096 && h_chunk_lens[i] <= 8192;
-            }
+            for (uint32_t i = lo; i < lo + cnt; i++)
+                c8 += h_chunk_lens[i] <= 8192;
         rc = launch_compress(ctx, a.in_ptrs, a.in_lens, a.slot_ptrs, nullptr,
-                             a.clens, nullptr, cnt, cnt, 0, 0xF, c4, c8);
+                             a.clens, nullptr, cnt, cnt, 0, 0xF, c8);
         if (rc)
             return rc;
         if (side)

@@ -50,18 +50,17 @@ struct CompressArgs {
     uint32_t small_limit;
     // block-length class of this launch: only blocks of cls_lo < n <= cls_hi
     // bytes are its work (the match finders of the token path; a launch of
-    // the whole batch has 0, kMaxBlock).  Round 5: blocks of at most 4 KiB /
-    // 8 KiB - pages, short frame chunks, tails - go to window kernels whose
-    // tables are as small as the reference makes them for such blocks
-    // (src/compress.rs:491-518), four / two times as many per CU.
+    // the whole batch has 0, kMaxBlock).  Round 5: blocks of at most 8 KiB -
+    // pages, short frame chunks, tails - go to a window kernel whose tables
+    // are as small as the reference makes them for such blocks
+    // (src/compress.rs:491-518), twice as many per CU.
     uint32_t cls_lo, cls_hi;
 };
 
 // wavefronts (= hash tables) per persistent compress workgroup: 5 x 32 KiB
 // is all of a CU's LDS
 constexpr uint32_t kCompressWaves = 5;
-// ... of the window kernels for blocks of at most 4 / 8 KiB (8 / 16 KiB
-// tables: two / one workgroups of ten wavefronts per CU)
+// ... of the window kernel for blocks of at most 8 KiB (16 KiB tables)
 constexpr uint32_t kSmallTableWaves = 10;
 // token slots per block: at most 16385 tokens (every token but the last ends
 // in a copy of >= 4 bytes), rounded up to whole 128-byte groups of 16 so a
@@ -107,7 +106,6 @@ __global__ void k_compress_blocks(CompressArgs a);
 __global__ void k_compress_block_lds(CompressArgs a);
 __global__ void k_compress_spans(CompressArgs a);    // window steps, 5 tables/CU
 __global__ void k_match_spans(CompressArgs a); // ... as the token path's match finder
-__global__ void k_match_spans_4k(CompressArgs a); // ... blocks <= 4 KiB: 20 tables / CU
 __global__ void k_match_spans_8k(CompressArgs a); // ... blocks <= 8 KiB: 10 tables / CU
 __global__ void k_post_ratio(uint32_t *host_mapped, const uint64_t *blk_off,
                              uint32_t blocks, const uint64_t *in_lens,

@@ -56,9 +56,9 @@ def cctx(request, built):
     parity test of the encoder runs through all of them.  "lanes" and
     "lanes_segmented" encode every block at its final position
     (lane_direct_encode); "lanes_overlap" and "both" go through the scratch
-    slots and k_compact.  "small_tables*": every block of at most 4 / 8 KiB
-    goes to the window kernels with 8 / 16 KiB tables (k_match_spans_4k /
-    _8k) however few there are, the larger blocks to the window kernel as
+    slots and k_compact.  "small_tables*": every block of at most 8 KiB
+    goes to the window kernel with 16 KiB tables (k_match_spans_8k) however
+    few there are, the larger blocks to the window kernel as
     match finder or to the lane kernel (both skip the other classes' blocks)
     - the configurations above switch those kernels off, so that they keep
     testing the kernels they name on blocks of every size."""

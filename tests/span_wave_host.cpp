@@ -246,7 +246,8 @@ extern "C" uint32_t span_wave_compress(const uint8_t *src, uint32_t n,
         return o.bad ? 0x80000001u : d;
     }
     // the table the kernel instance for this block length has room for
-    // (k_match_spans_4k / _8k / the 64 KiB kernels): every index below is
+    // (k_match_spans_8k / the 64 KiB kernels; 4 096 for the 20-table variant
+    // that was measured and dropped): every index below is
     // checked against what the reference would allocate (tsize) AND against
     // that room
     const uint32_t room = n <= 4096 ? 4096 : (n <= 8192 ? 8192 : 16384);

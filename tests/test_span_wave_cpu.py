@@ -117,8 +117,9 @@ def test_fast_walk_equals_the_exact_walk_on_random_windows(tmp_path):
 
 
 def test_small_block_tables_at_every_length(span):
-    """The small-block window kernels (k_match_spans_4k / _8k) give a block of
-    n <= 4 096 / 8 192 bytes a table of that many entries at most: the host
+    """The small-block window kernel (k_match_spans_8k) gives a block of
+    n <= 8 192 bytes a table of that many entries at most (the model also
+    checks 4 096 for n <= 4 096): the host
     model allocates exactly that room and checks every index, the table must
     be what the reference sizes for n (src/compress.rs:491-518: the power of
     two at or above n, 256 .. 16 384), and the stream the oracle's - every
