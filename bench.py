@@ -241,7 +241,7 @@ def run_extras(args, local_rank, dev, rank, world):
         g3 = args.extras_gib or 64.0
         g5 = args.extras_gib or 32.0
         plan = (f"sweep:4,cfg3:{g3:g},cfg5:{g5:g},files:2,stream:2,cfg4:8,"
-                "pcie:4,adapters:4,tiny:1,budget:8")
+                "pcie:4,adapters:4,tiny:1,budget:8,seam:100")
         cmd = [sys.executable, str(ROOT / "bench_configs.py"), "--plan", plan]
         try:
             p = subprocess.run(cmd, capture_output=True, text=True,

@@ -447,6 +447,65 @@ def tiny(args, ctx, dev):
     return res
 
 
+def seam(args, ctx, dev):
+    """The reference-side view of the native seam (snappy-cpp/src/lib.rs:13-88,
+    the `cpp` group of bench/src/bench.rs:117-153): tests/seam_consumer.c - a C
+    program against snappy-c.h, linked with -lsnappy - built once against a
+    directory whose libsnappy.so is a symlink to libsnapmi.so and once against
+    Google's libsnappy 1.1.8, one call per file, 1 and 16 callers at once.
+    MB/s of uncompressed bytes, [compress, uncompress]; args.gib = milliseconds
+    per file, direction and thread count."""
+    import oracle_lib as O
+    import os
+    import subprocess
+    import tempfile
+    hdr = "/opt/conda/include"
+    if not os.path.exists(f"{hdr}/snappy-c.h"):
+        return {"error": "no snappy-c.h in this image"}
+    ms = max(20.0, float(args.gib))
+    with tempfile.TemporaryDirectory() as d:
+        lib = ROOT / "rust-snappy_amd" / "libsnapmi.so"
+        os.symlink(lib, f"{d}/libsnappy.so")
+        ins = f"{d}/in"
+        os.mkdir(ins)
+        for name, data in O.corpus_round():
+            open(f"{ins}/{name}.in", "wb").write(data)
+            open(f"{ins}/{name}.snappy", "wb").write(O.compress(data))
+        src = str(ROOT / "tests" / "seam_consumer.c")
+        builds = {"snapmi": [f"-L{d}", f"-Wl,-rpath,{d}",
+                             f"-Wl,-rpath,{lib.parent}"]}
+        if os.path.exists("/opt/conda/lib/libsnappy.so"):
+            builds["libsnappy_1_1_8"] = ["-L/opt/conda/lib",
+                                         "-Wl,-rpath,/opt/conda/lib"]
+        res = {"config": "one call per bench input through snappy-c.h "
+                         "(tests/seam_consumer.c, -lsnappy)",
+               "unit": "MB/s uncompressed [compress, uncompress]",
+               "ms_per_leg": ms}
+        for key, flags in builds.items():
+            exe = f"{d}/consumer_{key}"
+            subprocess.check_call(["gcc", "-O2", "-I", hdr, "-o", exe, src]
+                                  + flags + ["-lsnappy", "-lpthread"])
+            p = subprocess.run([exe, "check", ins], capture_output=True,
+                               text=True, timeout=120)
+            if p.returncode != 0:
+                return {"error": f"{key}: check failed: "
+                                 + (p.stdout + p.stderr)[-200:]}
+            rows = {}
+            for threads in (1, 16):
+                p = subprocess.run([exe, "bench", ins, str(threads), str(ms)],
+                                   capture_output=True, text=True,
+                                   timeout=300)
+                if p.returncode != 0:
+                    return {"error": f"{key}: bench with {threads} callers: "
+                                     + (p.stdout + p.stderr)[-200:]}
+                for line in p.stdout.splitlines():
+                    name, n, t, c, u = line.split()
+                    rows.setdefault(name, {})[f"callers_{t}"] = [
+                        float(c), float(u)]
+            res[key] = rows
+        return res
+
+
 def _host_corpus(gib):
     """The corpus round tiled into pinned host memory (snapmi_host_alloc)."""
     import oracle_lib as O
@@ -811,7 +870,7 @@ def main():
         ctx.set_option(name, int(value))
     table = {"cfg3": cfg3, "cfg5": cfg5, "files": files, "pcie": pcie,
              "adapters": adapters, "stream": stream, "cfg4": cfg4,
-             "tiny": tiny, "sweep": sweep, "budget": budget}
+             "tiny": tiny, "sweep": sweep, "budget": budget, "seam": seam}
     if args.plan:
         for item in args.plan.split(","):
             name, gib = item.split(":")

@@ -14,6 +14,9 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <deque>
+#include <chrono>
+#include <thread>
 #include <vector>
 
 #include "snapmi.h"
@@ -1952,10 +1955,22 @@ int snapmi_raw_decompress(snapmi_ctx *ctx, const uint8_t *input,
 // libsnappy C API (snappy-c.h), as bound by the reference's snappy-cpp
 // crate.  The reference's wrappers are stateless and may be called from any
 // number of threads at once (snappy-cpp/src/lib.rs:13-64), so these calls
-// check a context out of a small process-wide pool on device SNAPMI_DEVICE
-// (default 0): contexts are created on demand, up to SNAPMI_SEAM_CONTEXTS
-// (default 8); T callers run on T HIP streams, further callers wait for a
-// context to come back.
+// share a small process-wide pool of contexts on device SNAPMI_DEVICE
+// (default 0; created on demand, up to SNAPMI_SEAM_CONTEXTS, default 8).
+//
+// Round 5: concurrent calls are COMBINED.  One call is ~1.5 ms of a lone
+// wavefront per block whatever else the GPU does, so eight callers on eight
+// streams got 3.3-3.8x the rate of one (round 4) - but a batch of sixteen such
+// streams takes about as long as one.  A caller stages its input in pinned
+// memory of its own thread, queues a request and either finds it done by
+// another caller or becomes a leader: it takes a context, waits a few
+// microseconds for requests that are just arriving, takes every queued
+// request of its kind and runs them as ONE snapmi_compress_batch /
+// snapmi_decompress_batch - per-request copies in, one launch, per-request
+// copies out, one wait.  Every caller then moves its own bytes from its
+// pinned buffer to the buffer it was given.  Results and errors are per
+// stream, exactly those of the batch call.  Inputs of more than kPinStage
+// bytes go one by one, as before.
 // ----------------------------------------------------------------------
 namespace {
 struct SeamPool {
@@ -1965,9 +1980,12 @@ struct SeamPool {
     size_t created = 0, cap = 0;
     bool broken = false; // a context could not be created: do not retry
 
-    snapmi_ctx *checkout()
+    // (mu held) a context if one is idle or may still be created; *wait =
+    // whether one will come back
+    snapmi_ctx *checkout_locked(std::unique_lock<std::mutex> &lock,
+                                bool block, bool *none)
     {
-        std::unique_lock<std::mutex> lock(mu);
+        *none = false;
         if (cap == 0) {
             cap = 8;
             if (const char *e = getenv("SNAPMI_SEAM_CONTEXTS"))
@@ -1986,18 +2004,28 @@ struct SeamPool {
                 if (const char *e = getenv("SNAPMI_DEVICE"))
                     dev = atoi(e);
                 snapmi_ctx *c = nullptr;
-                if (snapmi_ctx_create(dev, nullptr, &c) == SNAPMI_OK)
-                    return c;
+                const bool ok = snapmi_ctx_create(dev, nullptr, &c) == SNAPMI_OK;
                 lock.lock();
+                if (ok)
+                    return c;
                 created--;
                 broken = true; // (snapmi_ctx_create has printed why)
                 cv.notify_all();
+            }
+            if (created == 0) {
+                *none = true; // no context and none can be made
                 return nullptr;
             }
-            if (created == 0)
-                return nullptr; // no context and none can be made
+            if (!block)
+                return nullptr;
             cv.wait(lock);
         }
+    }
+    snapmi_ctx *checkout()
+    {
+        std::unique_lock<std::mutex> lock(mu);
+        bool none;
+        return checkout_locked(lock, true, &none);
     }
     void give_back(snapmi_ctx *c)
     {
@@ -2005,7 +2033,7 @@ struct SeamPool {
             std::lock_guard<std::mutex> lock(mu);
             idle.push_back(c);
         }
-        cv.notify_one();
+        cv.notify_all();
     }
 };
 SeamPool g_pool;
@@ -2019,6 +2047,297 @@ struct SeamLease {
             g_pool.give_back(ctx);
     }
 };
+
+// pinned staging of the calling thread (grow-only, freed with the thread)
+struct ThreadPin {
+    void *p = nullptr;
+    size_t cap = 0;
+    bool reserve(size_t bytes)
+    {
+        if (bytes <= cap)
+            return true;
+        if (p)
+            (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            p = nullptr;
+            return false;
+        }
+        cap = want;
+        return true;
+    }
+    ~ThreadPin()
+    {
+        if (p)
+            (void)hipHostFree(p); // (may fail while the process leaves)
+    }
+};
+thread_local ThreadPin tl_pin_in, tl_pin_out;
+
+struct SeamReq {
+    bool compress;
+    size_t in_len, out_cap; // the caller's
+    size_t dev_out;         // bytes the device may write = bytes coming back
+    const uint8_t *pin_in;  // the caller's pinned copy of its input
+    uint8_t *pin_out;       // ... and room for dev_out bytes of result
+    int state;              // 0 queued, 1 taken by a leader, 2 done
+    int rc;
+    size_t written;
+    snapmi_error err;
+};
+
+// one batch of requests of one kind on `ctx` (no lock held)
+void seam_execute(snapmi_ctx *ctx, const std::vector<SeamReq *> &batch)
+{
+    const size_t n = batch.size();
+    const bool compress = batch[0]->compress;
+    auto fail_all = [&](int rc) {
+        for (SeamReq *r : batch) {
+            r->rc = rc;
+            r->written = 0;
+            memset(&r->err, 0, sizeof r->err);
+            r->err.kind = rc;
+        }
+    };
+    if (hipSetDevice(ctx->device) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail_all(SNAPMI_E_DEVICE);
+    }
+    // device slabs: inputs and outputs back to back, 16-byte aligned
+    std::vector<size_t> in_off(n), out_off(n);
+    size_t in_total = 0, out_total = 0;
+    for (size_t i = 0; i < n; i++) {
+        in_off[i] = in_total;
+        in_total += (batch[i]->in_len + 16 + 15) & ~(size_t)15;
+        out_off[i] = out_total;
+        out_total += (batch[i]->dev_out + 64 + 15) & ~(size_t)15;
+    }
+    // descriptors, structure of arrays: in_ptrs, in_lens, out_ptrs, out_caps,
+    // out_lens (8 bytes each), errs (32)
+    const size_t desc_bytes = n * (5 * 8 + sizeof(snapmi_error));
+    int rc;
+    if ((rc = reserve(ctx, ctx->st_in, in_total + 16)) ||
+        (rc = reserve(ctx, ctx->st_out, out_total + 64)) ||
+        (rc = reserve(ctx, ctx->st_desc, desc_bytes)) ||
+        (rc = pin_reserve(ctx, &ctx->pin_desc, &ctx->pin_desc_cap,
+                          2 * desc_bytes)))
+        return fail_all(rc);
+    uint8_t *hd = (uint8_t *)ctx->pin_desc, *hback = hd + desc_bytes;
+    uint8_t *dd = (uint8_t *)ctx->st_desc.p;
+    uint64_t *h_in_ptrs = (uint64_t *)hd, *h_in_lens = h_in_ptrs + n,
+             *h_out_ptrs = h_in_lens + n, *h_out_caps = h_out_ptrs + n;
+    memset(hd, 0, desc_bytes);
+    for (size_t i = 0; i < n; i++) {
+        h_in_ptrs[i] = (uint64_t)(uintptr_t)((uint8_t *)ctx->st_in.p + in_off[i]);
+        h_in_lens[i] = batch[i]->in_len;
+        h_out_ptrs[i] =
+            (uint64_t)(uintptr_t)((uint8_t *)ctx->st_out.p + out_off[i]);
+        h_out_caps[i] = batch[i]->out_cap; // the caller's is what is checked
+    }
+    hipStream_t s = ctx->stream;
+    bool ok = true;
+    for (size_t i = 0; i < n && ok; i++)
+        if (batch[i]->in_len)
+            ok = hipMemcpyAsync((uint8_t *)ctx->st_in.p + in_off[i],
+                                batch[i]->pin_in, batch[i]->in_len,
+                                hipMemcpyHostToDevice, s) == hipSuccess;
+    ok = ok && hipMemcpyAsync(dd, hd, desc_bytes, hipMemcpyHostToDevice, s) ==
+                   hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(s);
+        return fail_all(SNAPMI_E_DEVICE);
+    }
+    const void *const *d_in_ptrs = (const void *const *)dd;
+    const uint64_t *d_in_lens = (const uint64_t *)(dd + 8 * n);
+    void *const *d_out_ptrs = (void *const *)(dd + 16 * n);
+    const uint64_t *d_out_caps = (const uint64_t *)(dd + 24 * n);
+    uint64_t *d_out_lens = (uint64_t *)(dd + 32 * n);
+    snapmi_error *d_errs = (snapmi_error *)(dd + 40 * n);
+    if (compress)
+        rc = snapmi_compress_batch(ctx, d_in_ptrs, d_in_lens, h_in_lens,
+                                   d_out_ptrs, d_out_caps, d_out_lens, d_errs,
+                                   n);
+    else
+        rc = snapmi_decompress_batch(ctx, d_in_ptrs, d_in_lens, d_out_ptrs,
+                                     d_out_caps, d_out_lens, d_errs, n);
+    if (rc) {
+        (void)hipStreamSynchronize(s);
+        return fail_all(rc);
+    }
+    ok = hipMemcpyAsync(hback, dd, desc_bytes, hipMemcpyDeviceToHost, s) ==
+         hipSuccess;
+    // the results come along in the same round trip: as much as the kernels
+    // can have written (the lengths are not known to the host yet)
+    for (size_t i = 0; i < n && ok; i++)
+        if (batch[i]->dev_out)
+            ok = hipMemcpyAsync(batch[i]->pin_out,
+                                (uint8_t *)ctx->st_out.p + out_off[i],
+                                batch[i]->dev_out, hipMemcpyDeviceToHost,
+                                s) == hipSuccess;
+    if (hipStreamSynchronize(s) != hipSuccess || !ok) {
+        (void)hipGetLastError();
+        return fail_all(SNAPMI_E_DEVICE);
+    }
+    (void)release_batch_scratch(ctx);
+    const uint64_t *b_out_lens = (const uint64_t *)(hback + 32 * n);
+    const snapmi_error *b_errs = (const snapmi_error *)(hback + 40 * n);
+    for (size_t i = 0; i < n; i++) {
+        SeamReq *r = batch[i];
+        r->err = b_errs[i];
+        r->rc = b_errs[i].kind;
+        r->written = b_errs[i].kind == SNAPMI_OK ? (size_t)b_out_lens[i] : 0;
+        if (r->written > r->dev_out) { // cannot be: the device checks the caps
+            r->rc = SNAPMI_E_DEVICE;
+            r->written = 0;
+        }
+    }
+}
+
+struct SeamCombiner {
+    std::deque<SeamReq *> q; // under g_pool.mu
+    static constexpr size_t kMaxBatch = 1024;
+    static constexpr size_t kMaxBytes = (size_t)1 << 30;
+
+    void run(SeamReq *r)
+    {
+        std::unique_lock<std::mutex> lock(g_pool.mu);
+        r->state = 0;
+        q.push_back(r);
+        for (;;) {
+            if (r->state == 2)
+                return;
+            if (r->state == 0) {
+                bool none = false;
+                snapmi_ctx *ctx = g_pool.checkout_locked(lock, false, &none);
+                if (r->state != 0) { // (the lock was dropped meanwhile)
+                    if (ctx) {
+                        g_pool.idle.push_back(ctx);
+                        g_pool.cv.notify_all();
+                    }
+                    continue;
+                }
+                if (none) { // no device: only this request fails here
+                    for (auto it = q.begin(); it != q.end(); ++it)
+                        if (*it == r) {
+                            q.erase(it);
+                            break;
+                        }
+                    r->rc = SNAPMI_E_DEVICE;
+                    r->written = 0;
+                    r->state = 2;
+                    return;
+                }
+                if (ctx) {
+                    lead(lock, ctx, r);
+                    continue;
+                }
+            }
+            g_pool.cv.wait(lock);
+        }
+    }
+    // (mu held on entry and exit) gather, run, hand out
+    void lead(std::unique_lock<std::mutex> &lock, snapmi_ctx *ctx, SeamReq *r)
+    {
+        // requests that are arriving right now join: until the queue has not
+        // grown for ~8 us, 50 us at most (a call is ~1 500 us of GPU time)
+        {
+            size_t seen = q.size();
+            lock.unlock();
+            const auto t0 = std::chrono::steady_clock::now();
+            auto t_grow = t0;
+            for (;;) {
+                std::this_thread::yield();
+                const auto now = std::chrono::steady_clock::now();
+                lock.lock();
+                const size_t have = q.size();
+                lock.unlock();
+                if (have != seen) {
+                    seen = have;
+                    t_grow = now;
+                }
+                if (now - t_grow > std::chrono::microseconds(8) ||
+                    now - t0 > std::chrono::microseconds(50))
+                    break;
+            }
+            lock.lock();
+        }
+        if (r->state != 0) { // another leader took it during the window
+            g_pool.idle.push_back(ctx);
+            g_pool.cv.notify_all();
+            return;
+        }
+        std::vector<SeamReq *> batch;
+        size_t bytes = 0;
+        for (auto it = q.begin(); it != q.end();) {
+            SeamReq *x = *it;
+            const size_t cost = x->in_len + x->dev_out;
+            if (x->compress == r->compress &&
+                (x == r || (batch.size() < kMaxBatch - 1 &&
+                            bytes + cost <= kMaxBytes))) {
+                x->state = 1;
+                bytes += cost;
+                batch.push_back(x);
+                it = q.erase(it);
+            } else {
+                ++it;
+            }
+        }
+        lock.unlock();
+        seam_execute(ctx, batch);
+        lock.lock();
+        for (SeamReq *x : batch)
+            x->state = 2;
+        g_pool.idle.push_back(ctx);
+        g_pool.cv.notify_all();
+    }
+};
+SeamCombiner g_seam;
+
+// one seam call: through the combiner, or alone when the input is large
+int seam_call(bool compress, const uint8_t *input, size_t input_len,
+              uint8_t *output, size_t output_cap, size_t dev_out,
+              size_t *written, const char *what)
+{
+    *written = 0;
+    if (input_len > kPinStage || dev_out > kPinStage ||
+        !tl_pin_in.reserve(input_len + 16) ||
+        !tl_pin_out.reserve(dev_out + 64)) {
+        SeamLease lease;
+        snapmi_ctx *ctx = lease.ctx;
+        if (!ctx) // (snapmi_ctx_create has printed why)
+            return SNAPMI_E_DEVICE;
+        snapmi_error err;
+        const int rc = run_one(ctx, compress, input, input_len, output,
+                               output_cap, written, &err);
+        if (rc >= SNAPMI_E_DEVICE)
+            fprintf(stderr, "snapmi: %s: %s\n", what, snapmi_last_error(ctx));
+        return rc;
+    }
+    if (input_len)
+        memcpy(tl_pin_in.p, input, input_len);
+    SeamReq r;
+    r.compress = compress;
+    r.in_len = input_len;
+    r.out_cap = output_cap;
+    r.dev_out = dev_out;
+    r.pin_in = (const uint8_t *)tl_pin_in.p;
+    r.pin_out = (uint8_t *)tl_pin_out.p;
+    r.rc = SNAPMI_E_DEVICE;
+    r.written = 0;
+    g_seam.run(&r);
+    if (r.rc == SNAPMI_OK && r.written) {
+        memcpy(output, r.pin_out, r.written);
+        *written = r.written;
+    }
+    if (r.rc >= SNAPMI_E_DEVICE)
+        fprintf(stderr, "snapmi: %s: device failure (no CPU fallback)\n",
+                what);
+    return r.rc;
+}
 } // namespace
 
 size_t snappy_max_compressed_length(size_t source_length)
@@ -2047,24 +2366,17 @@ snappy_status snappy_compress(const char *input, size_t input_length,
         return SNAPPY_INVALID_INPUT;
     if (*compressed_length < snappy_max_compressed_length(input_length))
         return SNAPPY_BUFFER_TOO_SMALL;
-    SeamLease lease;
-    snapmi_ctx *ctx = lease.ctx;
-    if (!ctx) // (snapmi_ctx_create has printed why)
-        return SNAPPY_INVALID_INPUT;
     size_t written = 0;
-    snapmi_error err;
-    int rc = snapmi_raw_compress(ctx, (const uint8_t *)input, input_length,
-                                 (uint8_t *)compressed, *compressed_length,
-                                 &written, &err);
+    size_t dev_out = snapmi_max_compress_len(input_length);
+    if (dev_out == 0 || dev_out > *compressed_length)
+        dev_out = *compressed_length;
+    const int rc = seam_call(true, (const uint8_t *)input, input_length,
+                             (uint8_t *)compressed, *compressed_length,
+                             dev_out, &written, "snappy_compress");
     if (rc == SNAPMI_BUFFER_TOO_SMALL)
         return SNAPPY_BUFFER_TOO_SMALL;
-    if (rc >= SNAPMI_E_DEVICE) {
-        // snappy_status has no "device" value: the failure is printed and
-        // reported as the one status a caller cannot mistake for success
-        fprintf(stderr, "snapmi: snappy_compress: %s\n",
-                snapmi_last_error(ctx));
-        return SNAPPY_INVALID_INPUT;
-    }
+    // (snappy_status has no "device" value: such a failure is printed and
+    // reported as the one status a caller cannot mistake for success)
     if (rc != SNAPMI_OK)
         return SNAPPY_INVALID_INPUT;
     *compressed_length = written;
@@ -2083,20 +2395,11 @@ snappy_status snappy_uncompress(const char *compressed,
         return SNAPPY_INVALID_INPUT;
     if (*uncompressed_length < need)
         return SNAPPY_BUFFER_TOO_SMALL;
-    SeamLease lease;
-    snapmi_ctx *ctx = lease.ctx;
-    if (!ctx)
-        return SNAPPY_INVALID_INPUT;
     size_t written = 0;
-    snapmi_error err;
-    int rc = snapmi_raw_decompress(ctx, (const uint8_t *)compressed,
-                                   compressed_length, (uint8_t *)uncompressed,
-                                   *uncompressed_length, &written, &err);
-    if (rc >= SNAPMI_E_DEVICE) {
-        fprintf(stderr, "snapmi: snappy_uncompress: %s\n",
-                snapmi_last_error(ctx));
-        return SNAPPY_INVALID_INPUT;
-    }
+    const int rc = seam_call(false, (const uint8_t *)compressed,
+                             compressed_length, (uint8_t *)uncompressed,
+                             *uncompressed_length, need, &written,
+                             "snappy_uncompress");
     if (rc != SNAPMI_OK)
         return SNAPPY_INVALID_INPUT;
     *uncompressed_length = written;
