@@ -1956,7 +1956,7 @@ int snapmi_raw_decompress(snapmi_ctx *ctx, const uint8_t *input,
 // crate.  The reference's wrappers are stateless and may be called from any
 // number of threads at once (snappy-cpp/src/lib.rs:13-64), so these calls
 // share a small process-wide pool of contexts on device SNAPMI_DEVICE
-// (default 0; created on demand, up to SNAPMI_SEAM_CONTEXTS, default 8).
+// (default 0; created on demand, up to SNAPMI_SEAM_CONTEXTS, default 2).
 //
 // Round 5: concurrent calls are COMBINED.  One call is ~1.5 ms of a lone
 // wavefront per block whatever else the GPU does, so eight callers on eight
@@ -1987,7 +1987,11 @@ struct SeamPool {
     {
         *none = false;
         if (cap == 0) {
-            cap = 8;
+            // (two: one batch runs while the next one gathers - with more
+            // contexts the callers spread over more, smaller batches: 16
+            // callers on alice29.txt 1 240 / 1 060 / 740 MB/s with 2 / 4 / 8,
+            // profiles/r5_seam_sweep.txt)
+            cap = 2;
             if (const char *e = getenv("SNAPMI_SEAM_CONTEXTS"))
                 cap = (size_t)(atoi(e) < 1 ? 1 : atoi(e));
         }
