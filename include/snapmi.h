@@ -160,7 +160,7 @@ const char *snapmi_version(void);
  *                          1 KiB on); 0: they are one-block streams of the
  *                          block kernels
  *   "lane_min_blocks"      batches with at least this many 64 KiB blocks use
- *                          the lane-per-block kernel (default 8192)
+ *                          the lane-per-block kernel (default 20480 = 1.25 GiB)
  *   "lane_speculate"       1 (default): a lane-kernel launch of at most 24 576
  *                          blocks (1.5 GiB) also fetches, in a probe's round,
  *                          the table entry of the probe that follows a miss -

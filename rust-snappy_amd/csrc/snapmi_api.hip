@@ -242,7 +242,8 @@ void snapmi_ctx_destroy(snapmi_ctx *ctx)
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
     host_pipe_destroy(ctx);
-    for (void *p : {ctx->pin_in, ctx->pin_out, ctx->pin_desc, ctx->pin_bl})
+    for (void *p : {ctx->pin_in, ctx->pin_out, ctx->pin_desc, ctx->pin_bl,
+                    ctx->pin_bl2})
         if (p)
             (void)hipHostFree(p);
     if (ctx->h_mail)
@@ -1223,6 +1224,9 @@ int launch_decompress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
         // at once, in both launches)
         hipLaunchKernelGGL(k_decompress_tiny,
                            dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, s, a);
+        // ... and those of under 512 bytes in and out, 32 per wavefront
+        hipLaunchKernelGGL(k_decompress_small,
+                           dim3((uint32_t)((n + 31) / 32)), dim3(64), 0, s, a);
     }
     HIP_TRY(ctx, hipGetLastError());
     if (side)
@@ -1279,6 +1283,25 @@ constexpr uint32_t kBatchLongMaxL = 4096;
                             hipGetErrorString(_e));                           \
     } while (0)
 
+// pinned host staging of a context (grow-only): pageable copies go through
+// the runtime's own staging buffer one at a time, process-wide - eight
+// threads calling snappy_compress would queue there
+static int pin_reserve(snapmi_ctx *ctx, void **p, size_t *cap, size_t bytes)
+{
+    if (bytes <= *cap)
+        return SNAPMI_OK;
+    if (*p) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipHostFree(*p));
+        *p = nullptr;
+        *cap = 0;
+    }
+    const size_t want = bytes + bytes / 4 + 4096;
+    HIP_TRY(ctx, hipHostMalloc(p, want, hipHostMallocDefault));
+    *cap = want;
+    return SNAPMI_OK;
+}
+
 static int decompress_batch_long(snapmi_ctx *ctx,
                                  const void *const *d_in_ptrs,
                                  const uint64_t *d_in_lens,
@@ -1331,11 +1354,19 @@ static int decompress_batch_long(snapmi_ctx *ctx,
     const LongItem *items = (const LongItem *)((const uint8_t *)ctx->pin_bl + 16);
 
     // ---- geometry, scratch, descriptors ----------------------------------
-    std::vector<StreamArgs> descs(L);
     // first workgroup of every stream, per kernel: scan, super, super3,
     // spread3, spread2, cuts, pieces
     enum { kPScan, kPSuper, kPSuper3, kPSpread3, kPSpread2, kPCuts, kPPieces, kPre };
-    std::vector<uint32_t> pre((size_t)kPre * (L + 1));
+    // (descriptors and prefixes are written into pinned memory of the
+    // context: their copy to the device needs no wait - the next call's
+    // synchronisation behind k_long_plan comes before they are written again)
+    const size_t desc_bytes0 = (size_t)L * sizeof(StreamArgs);
+    const size_t pre_count = (size_t)kPre * (L + 1);
+    if ((rc = pin_reserve(ctx, &ctx->pin_bl2, &ctx->pin_bl2_cap,
+                          desc_bytes0 + pre_count * sizeof(uint32_t) + 64)))
+        return rc;
+    StreamArgs *const descs = (StreamArgs *)ctx->pin_bl2;
+    uint32_t *const pre = (uint32_t *)((uint8_t *)ctx->pin_bl2 + desc_bytes0);
     size_t rows = 0, blocks = 0, cuts = 0, pieces = 0;
     for (uint32_t j = 0; j < L; j++) {
         StreamArgs &a = descs[j];
@@ -1381,8 +1412,8 @@ static int decompress_batch_long(snapmi_ctx *ctx,
                            blocks * 16 + cuts * 16;
     const size_t d_stride = 8 + 8 + 8 + 8 + 8 + sizeof(snapmi_error) + 1;
     const size_t d_bytes = pieces * d_stride + 64;
-    const size_t desc_bytes = (size_t)L * sizeof(StreamArgs);
-    const size_t pre_bytes = pre.size() * sizeof(uint32_t);
+    const size_t desc_bytes = desc_bytes0;
+    const size_t pre_bytes = pre_count * sizeof(uint32_t);
     if ((rc = reserve(ctx, ctx->sd_tables, t_bytes)) ||
         (rc = reserve(ctx, ctx->sd_desc, d_bytes)) ||
         (rc = reserve(ctx, ctx->bl_descs, desc_bytes + pre_bytes + 64)))
@@ -1435,14 +1466,9 @@ static int decompress_batch_long(snapmi_ctx *ctx,
             a.c_mode = c_mode + k0;
             k0 += a.kmax;
         }
-        // (pageable staging is fine here: two small copies; the vectors live
-        // until the synchronisation hipMemcpyAsync from pageable memory makes)
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->bl_descs.p, descs.data(), desc_bytes,
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->bl_descs.p, descs,
+                                    desc_bytes + pre_bytes,
                                     hipMemcpyHostToDevice, s));
-        HIP_TRY(ctx, hipMemcpyAsync((uint8_t *)ctx->bl_descs.p + desc_bytes,
-                                    pre.data(), pre_bytes,
-                                    hipMemcpyHostToDevice, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));
         HIP_TRY(ctx, hipMemsetAsync(e_all, 0xFF, blocks * 16, s));
         HIP_TRY(ctx, hipMemsetAsync(modes2, 3, n, s));
         const StreamArgs *dd = (const StreamArgs *)ctx->bl_descs.p;
@@ -1807,25 +1833,6 @@ struct OneDesc {
 // staging (one host memcpy each way, no pageable device copy)
 constexpr size_t kPinStage = 8u << 20;
 
-
-// pinned host staging of a context (grow-only): pageable copies go through
-// the runtime's own staging buffer one at a time, process-wide - eight
-// threads calling snappy_compress would queue there
-int pin_reserve(snapmi_ctx *ctx, void **p, size_t *cap, size_t bytes)
-{
-    if (bytes <= *cap)
-        return SNAPMI_OK;
-    if (*p) {
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        HIP_TRY(ctx, hipHostFree(*p));
-        *p = nullptr;
-        *cap = 0;
-    }
-    const size_t want = bytes + bytes / 4 + 4096;
-    HIP_TRY(ctx, hipHostMalloc(p, want, hipHostMallocDefault));
-    *cap = want;
-    return SNAPMI_OK;
-}
 
 int run_one(snapmi_ctx *ctx, bool compress, const uint8_t *input,
             size_t input_len, uint8_t *output, size_t output_cap,

@@ -158,6 +158,8 @@ struct snapmi_ctx {
     snapmi::DevBuf bl_modes, bl_list, bl_descs, bl_order;
     void *pin_bl = nullptr;
     size_t pin_bl_cap = 0;
+    void *pin_bl2 = nullptr; // descriptors of the long streams of a batch
+    size_t pin_bl2_cap = 0;
     // frame layer scratch (snapmi_frame.hip)
     snapmi::DevBuf fr_tables, fr_desc, fr_meta, fr_scan, fr_slots, fr_chunk_off;
     bool fr_tables_ready = false;
@@ -167,7 +169,10 @@ struct snapmi_ctx {
     uint64_t frame_walk_segment = 32ull << 20; // >= 128 KiB (test knob)
     int num_cus = 0;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    uint32_t lane_min_blocks = 8192; // measured crossover ~0.5 GiB
+    // measured crossover (profiles/r5_crossover.txt): the corpus round 1.7
+    // GiB, alice29.txt 1.15, html 0.55 - 8 192 until the window kernel got
+    // its lane-parallel walk in round 5
+    uint32_t lane_min_blocks = 20480;
     // blocks per lane-kernel launch: bounds the token scratch (34 GB here)
     uint32_t lane_segment_blocks = 262144;
     uint32_t lane_waves_per_cu = 6; // 24 KiB of LDS per wave

@@ -326,36 +326,49 @@ __global__ __launch_bounds__(256) void k_decompress_len(DecompressArgs a)
 }
 
 // Streams of fewer than kTiny = 2^kTinyLog2 compressed bytes are decoded one
-// per LANE (k_decompress_tiny below); the sort puts them last, and the plan
-// leaves the number of streams in front of them in bucket_pos[64].
+// per LANE (k_decompress_tiny below), streams of under kSmallDec bytes whose
+// output is no larger on half the lanes of a wavefront (k_decompress_small,
+// round 5); the sort puts both classes last, and the plan leaves the number
+// of streams in front of them in bucket_pos[64] and [65].
 constexpr uint32_t kTinyLog2 = 8;
+constexpr uint32_t kSmallDecLog2 = 9;
+constexpr uint32_t kSmallDec = 1u << kSmallDecLog2;
+// sort classes, descending in the dispatch order: kFirstWide + floor(log2
+// (compressed length)) - 8 for the wavefront decoder, kSmallClass, then
+// floor(log2(length)) of the tiny ones
+constexpr uint32_t kSmallClass = kTinyLog2;
+constexpr uint32_t kFirstWide = kTinyLog2 + 1;
 
 // The size class a stream is sorted by: floor(log2(compressed length)) -
 // except that a raw stream of under kTiny bytes whose header promises MORE
 // than kTiny bytes of output (a run of zeros: 200 bytes of copies are 4 KiB)
-// (or a piece of a long stream with as much) is put with the first class of
-// the wavefront decoder.  The lane-per-stream
-// kernel keeps its output in LDS, kTiny bytes per lane; what does not fit
-// would be left to one lane moving bytes through global memory.
+// (or a piece of a long stream with as much) is not the lane-per-stream
+// kernel's: it keeps its output in LDS, kTiny bytes per lane; what does not
+// fit would be left to one lane moving bytes through global memory.  Such a
+// stream, and any of 256 .. 511 compressed bytes, whose output is at most
+// kSmallDec bytes is k_decompress_small's; the rest goes with the first class
+// of the wavefront decoder.
 __device__ __forceinline__ uint32_t plan_class(const DecompressArgs &a,
                                                uint32_t i)
 {
     const uint64_t len = a.in_lens[i];
     if (a.modes && a.modes[i] == 3) // not this launch's: behind everything
         return 0;
-    uint32_t bk = len ? 63 - (uint32_t)__builtin_clzll(len) : 0;
-    if (len && bk < kTinyLog2) {
-        const uint32_t mode = a.modes ? a.modes[i] : 0;
-        uint64_t dl = 0;
-        if (mode == 2) // a piece of a long stream: its output is out_caps
-            dl = a.out_caps[i];
-        else if (mode == 0 &&
-                 read_varint((gcptr)a.in_ptrs[i], len, &dl) == 0)
-            dl = 0; // no header: the lane-per-stream kernel reports it
-        if (dl > (1u << kTinyLog2))
-            bk = kTinyLog2;
-    }
-    return bk;
+    const uint32_t bk = len ? 63 - (uint32_t)__builtin_clzll(len) : 0;
+    if (len == 0 || bk > kSmallDecLog2 - 1)
+        return len ? (bk < 62 ? bk + 1 : 63) : 0;
+    const uint32_t mode = a.modes ? a.modes[i] : 0;
+    uint64_t dl = 0;
+    bool header = true;
+    if (mode == 2) // a piece of a long stream: its output is out_caps
+        dl = a.out_caps[i];
+    else if (mode == 0 && read_varint((gcptr)a.in_ptrs[i], len, &dl) == 0)
+        header = false; // the lane-per-stream kernel reports it
+    if (bk < kTinyLog2 && (!header || dl <= (1u << kTinyLog2)))
+        return bk;
+    if (mode == 0 && header && dl <= kSmallDec)
+        return kSmallClass;
+    return kFirstWide;
 }
 
 // ---------------------------------------------------------------------
@@ -381,8 +394,10 @@ __global__ __launch_bounds__(1024) void k_plan_decompress(DecompressArgs a)
     if (threadIdx.x == 0) {
         uint32_t run = 0;
         for (uint32_t k = 0; k < 64; k++) {
-            if (k == 64 - kTinyLog2) // streams of kTiny bytes and more
+            if (k == 64 - kFirstWide) // the wavefront decoder's streams
                 a.bucket_pos[64] = run;
+            if (k == 64 - kSmallClass) // ... and k_decompress_small's
+                a.bucket_pos[65] = run;
             const uint32_t c = hist[k];
             hist[k] = run;
             run += c;
@@ -423,8 +438,10 @@ __global__ __launch_bounds__(64) void k_plan_decompress_b(DecompressArgs a)
     if (threadIdx.x == 0) {
         uint32_t run = 0;
         for (uint32_t k = 0; k < 64; k++) {
-            if (k == 64 - kTinyLog2)
+            if (k == 64 - kFirstWide)
                 a.bucket_pos[64] = run;
+            if (k == 64 - kSmallClass)
+                a.bucket_pos[65] = run;
             const uint32_t c = a.bucket_pos[k];
             a.bucket_pos[k] = run;
             run += c;
@@ -1685,23 +1702,26 @@ __global__ __launch_bounds__(64) void k_decompress_sequential(DecompressArgs a)
 // Tiny streams (fewer than kTiny compressed bytes), one per LANE.  A stream
 // whose output is tiny as well (the usual case) is staged in LDS - input and
 // output dword-interleaved across the lanes, so that lane l's byte k is at
-// ((k >> 2) * 64 + l) * 4 + (k & 3) and the lanes of an access fall on
+// ((k >> 2) * kLanes + l) * 4 + (k & 3) and the lanes of an access fall on
 // different banks - decoded there with the reference's loop, and stored with
 // 16-byte accesses: four LDS latencies per byte moved instead of two HBM
 // round trips.  The others run the same loop on global memory.
-__global__ __launch_bounds__(64) void k_decompress_tiny(DecompressArgs a)
+// k_decompress_small (round 5) is the same body with 512 bytes of input and of
+// output per lane on 32 lanes of a wavefront, for the streams between the
+// tiny ones and the wavefront decoder's (400-byte pages decoded at 106 GiB/s
+// a wavefront each, between 290 and 170 for their neighbours).
+template <uint32_t kLog2, uint32_t kLanes>
+__device__ __forceinline__ void decompress_lane_streams(
+    const DecompressArgs &a, const uint64_t first, const uint64_t end)
 {
-    constexpr uint32_t kT = 1u << kTinyLog2;
-    __shared__ __attribute__((aligned(16))) uint32_t tin[kT / 4 * kWave];
-    __shared__ __attribute__((aligned(16))) uint32_t tout[kT / 4 * kWave];
-    if (a.gate && uni64(*a.gate) != a.gate_value)
-        return;
+    constexpr uint32_t kT = 1u << kLog2;
+    __shared__ __attribute__((aligned(16))) uint32_t tin[kT / 4 * kLanes];
+    __shared__ __attribute__((aligned(16))) uint32_t tout[kT / 4 * kLanes];
     const uint32_t lane = threadIdx.x;
-    const uint32_t n_big = uni(a.bucket_pos[64]);
-    const uint64_t i = n_big + (uint64_t)blockIdx.x * kWave + lane;
-    if ((uint64_t)n_big + (uint64_t)blockIdx.x * kWave >= a.n_streams)
+    if (first + (uint64_t)blockIdx.x * kLanes >= end)
         return;
-    if (i >= a.n_streams)
+    const uint64_t i = first + (uint64_t)blockIdx.x * kLanes + lane;
+    if (lane >= kLanes || i >= end)
         return;
     const uint64_t st = a.order[i];
     gcptr in = (gcptr)a.in_ptrs[st];
@@ -1722,7 +1742,9 @@ __global__ __launch_bounds__(64) void k_decompress_tiny(DecompressArgs a)
     typedef __attribute__((address_space(3))) uint32_t l_u32t;
     l_u8 *const bin = (l_u8 *)(l_u32t *)tin;
     l_u8 *const bout = (l_u8 *)(l_u32t *)tout;
-    auto at = [lane](uint32_t k) { return ((k >> 2) * kWave + lane) * 4 + (k & 3); };
+    auto at = [lane](uint32_t k) {
+        return ((k >> 2) * kLanes + lane) * 4 + (k & 3);
+    };
     // stage the elements: whole dwords (reads stay inside the stream: the
     // last partial dword bytewise)
     const uint32_t slen = in_len - hdr;
@@ -1798,6 +1820,22 @@ __global__ __launch_bounds__(64) void k_decompress_tiny(DecompressArgs a)
     }
     set_error(a.errs, st, SNAPMI_OK, 0, 0, 0);
     a.out_lens[st] = dlen;
+}
+
+__global__ __launch_bounds__(64) void k_decompress_tiny(DecompressArgs a)
+{
+    if (a.gate && uni64(*a.gate) != a.gate_value)
+        return;
+    decompress_lane_streams<kTinyLog2, kWave>(a, uni(a.bucket_pos[65]),
+                                               a.n_streams);
+}
+
+__global__ __launch_bounds__(64) void k_decompress_small(DecompressArgs a)
+{
+    if (a.gate && uni64(*a.gate) != a.gate_value)
+        return;
+    decompress_lane_streams<kSmallDecLog2, 32>(a, uni(a.bucket_pos[64]),
+                                               uni(a.bucket_pos[65]));
 }
 
 // ---------------------------------------------------------------------

@@ -225,6 +225,7 @@ __global__ void k_decompress_streams3(DecompressArgs a);
 __global__ void k_decompress_streams2(DecompressArgs a);
 __global__ void k_decompress_sequential(DecompressArgs a);
 __global__ void k_decompress_tiny(DecompressArgs a);
+__global__ void k_decompress_small(DecompressArgs a); // ... under 512 bytes, 32 per wavefront
 // streams per workgroup of k_decompress_streams3_many (batches of more than
 // snapmi_ctx::decode_many_min streams)
 constexpr uint32_t kManyStreams = 16;

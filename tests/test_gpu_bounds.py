@@ -506,3 +506,67 @@ def test_host_frame_calls_keep_to_their_buffers(ctx):
     del vin, vout, wi, wo
     for b in (hin, hout, fin, fout):
         b.close()
+
+
+@pytest.mark.parametrize("count", [1, 4000])
+def test_small_streams_decoded_32_per_wavefront(ctx, count):
+    """k_decompress_small (round 5): raw streams of under 512 compressed bytes
+    whose output is at most 512 bytes, decoded one per lane on half the lanes
+    of a wavefront with input and output in LDS - every length around the
+    class limits (255 / 256 / 511 / 512 bytes in, 256 / 257 / 512 / 513 out),
+    text, runs, incompressible bytes and foreign elements, next to tiny and
+    larger streams in one batch, between guard bands; then the same streams
+    broken, truncated and with buffers one byte short, against the oracle's
+    errors."""
+    import foreign
+    rng = random.Random(17 + count)
+    txt = (O.CORPUS / "alice29.txt").read_bytes()
+    jpg = (O.CORPUS / "fireworks.jpeg").read_bytes()
+    datas = []
+    for n in list(range(240, 530, 3)) + [255, 256, 257, 511, 512, 513, 600]:
+        o = rng.randrange(len(txt) - 1000)
+        datas += [txt[o:o + n], jpg[100:100 + n], bytes(n),
+                  (txt[o:o + 7] * 80)[:n]]
+    comps = [O.compress(d) for d in datas]
+    # foreign elements in that size class: copy-4, 4-byte literal lengths
+    for seed in range(40):
+        c, w = foreign.build(100 + seed, rng.randrange(200, 520))
+        comps.append(c)
+        datas.append(w)
+    # ... and enough of them to fill many wavefronts
+    while len(comps) < count:
+        k = rng.randrange(len(datas))
+        comps.append(comps[k])
+        datas.append(datas[k])
+    classes = sum(1 for c, d in zip(comps, datas)
+                  if len(c) < 512 and len(d) <= 512
+                  and not (len(c) < 256 and len(d) <= 256))
+    assert classes > 100
+    caps = [len(d) for d in datas]
+    for aligned in (True, False):
+        dst, lens, errs = decode_guarded(ctx, comps, caps, 31, aligned,
+                                         in_aligned=aligned)
+        for i, d in enumerate(datas):
+            assert errs[i][0] == 0, (i, errs[i])
+            assert dst.bytes(i, lens[i]) == d, i
+    # broken streams of the class, short buffers
+    muts, mcaps = [], []
+    for c, d in list(zip(comps, datas))[:400]:
+        b = bytearray(c)
+        r = rng.random()
+        if r < 0.5 and len(b) > 3:
+            for _ in range(rng.randrange(1, 4)):
+                b[rng.randrange(len(b))] = rng.randrange(256)
+        elif r < 0.75 and len(b) > 2:
+            b = b[:rng.randrange(1, len(b))]
+        muts.append(bytes(b))
+        try:
+            cap = min(O.decompress_len(bytes(b)), 1 << 16)
+        except O.SnapError:
+            cap = 600
+        if rng.random() < 0.2 and cap:
+            cap -= 1
+        mcaps.append(cap)
+    dst, lens, errs = decode_guarded(ctx, muts, mcaps, 33, False)
+    ok, bad = check_against_oracle(muts, mcaps, dst, lens, errs)
+    assert ok > 20 and bad > 100
