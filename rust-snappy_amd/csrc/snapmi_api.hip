@@ -409,6 +409,9 @@ int snapmi_ctx_set_test_option(snapmi_ctx *ctx, const char *name,
     } else if (strcmp(name, "lane_epoch_preset") == 0 && value >= -1 &&
              value <= 0xFFFF)
         ctx->lane_epoch_preset = value;
+    else if (strcmp(name, "stream_seg_log2") == 0 &&
+             (value == 0 || value == 10 || value == 12))
+        ctx->stream_seg_log2 = (uint32_t)value; // 0: by size
     else if (strcmp(name, "lds_order_ok") == 0 && value >= 0 && value <= 1)
         ctx->lds_order_ok = ctx->lds_order_hw && value != 0; // can only lower
     else
@@ -1283,6 +1286,19 @@ constexpr uint32_t kBatchLongMaxL = 4096;
                             hipGetErrorString(_e));                           \
     } while (0)
 
+// Segment size of the scan of long streams (k_stream_scan and the levels
+// above it): 4 KiB when there is enough of them to fill the chip with walks
+// (one 2 GiB stream: 2.0 ms of scan at 280 GiB/s), 1 KiB below that - the
+// scan of a few hundred KiB is then a wait for the longest walk of ONE
+// wavefront, ~1 200 hops of ~630 cycles in a 4 KiB segment (0.5 ms whatever
+// the size), and a quarter of that with four times the lanes.
+static uint32_t stream_seg_log2(const snapmi_ctx *ctx, uint64_t long_bytes)
+{
+    if (ctx->stream_seg_log2)
+        return ctx->stream_seg_log2;
+    return long_bytes < ((uint64_t)256 << 20) ? 10u : 12u;
+}
+
 // pinned host staging of a context (grow-only): pageable copies go through
 // the runtime's own staging buffer one at a time, process-wide - eight
 // threads calling snappy_compress would queue there
@@ -1368,9 +1384,15 @@ static int decompress_batch_long(snapmi_ctx *ctx,
     StreamArgs *const descs = (StreamArgs *)ctx->pin_bl2;
     uint32_t *const pre = (uint32_t *)((uint8_t *)ctx->pin_bl2 + desc_bytes0);
     size_t rows = 0, blocks = 0, cuts = 0, pieces = 0;
+    uint64_t long_bytes = 0;
+    for (uint32_t j = 0; j < L; j++)
+        long_bytes += items[j].in_len;
+    const uint32_t seg_log2 = stream_seg_log2(ctx, long_bytes);
+    const uint64_t seg = 1ull << seg_log2;
     for (uint32_t j = 0; j < L; j++) {
         StreamArgs &a = descs[j];
         memset(&a, 0, sizeof a);
+        a.seg_log2 = seg_log2;
         a.in = (const uint8_t *)items[j].in;
         a.in_len = items[j].in_len;
         a.out = (uint8_t *)items[j].out;
@@ -1378,7 +1400,7 @@ static int decompress_batch_long(snapmi_ctx *ctx,
         a.out_len = (unsigned long long *)(d_out_lens + items[j].idx);
         a.err = d_errs ? d_errs + items[j].idx : nullptr;
         a.fb_mode = modes2 + items[j].idx;
-        a.nseg = (uint32_t)((a.in_len + kSeg - 1) / kSeg + 1);
+        a.nseg = (uint32_t)((a.in_len + seg - 1) / seg + 1);
         a.nsuper = (a.nseg + kSegPerSuper - 1) / kSegPerSuper;
         a.nsuper3 = (a.nsuper + kSegPerSuper - 1) / kSegPerSuper;
         a.kmax = (uint32_t)(items[j].dlen / kStreamChunk + 2);
@@ -1616,7 +1638,9 @@ int snapmi_decompress_stream(snapmi_ctx *ctx, const void *d_in,
     if (in_len < (1ull << 40) && in_len * 22 < bound)
         bound = in_len * 22;
     const uint64_t kmax64 = bound / kStreamChunk + 2;
-    const uint64_t nseg64 = (in_len + kSeg - 1) / kSeg + 1;
+    const uint32_t seg_log2 = stream_seg_log2(ctx, in_len);
+    const uint64_t seg = 1ull << seg_log2;
+    const uint64_t nseg64 = (in_len + seg - 1) / seg + 1;
     if (kmax64 > 0x3FFFFFFFu || nseg64 > 0x3FFFFFFFu)
         return fail_ctx(ctx, SNAPMI_E_ARGUMENT, "decompress_stream: too long");
     StreamArgs a;
@@ -1627,6 +1651,7 @@ int snapmi_decompress_stream(snapmi_ctx *ctx, const void *d_in,
     a.out_len = (unsigned long long *)d_out_len;
     a.err = d_err;
     a.nseg = (uint32_t)nseg64;
+    a.seg_log2 = seg_log2;
     a.nsuper = (a.nseg + kSegPerSuper - 1) / kSegPerSuper;
     a.nsuper3 = (a.nsuper + kSegPerSuper - 1) / kSegPerSuper;
     a.kmax = (uint32_t)kmax64;

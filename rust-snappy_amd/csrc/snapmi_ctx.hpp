@@ -159,6 +159,9 @@ struct snapmi_ctx {
     void *pin_bl = nullptr;
     size_t pin_bl_cap = 0;
     void *pin_bl2 = nullptr; // descriptors of the long streams of a batch
+    // segment size of the long-stream scan: 0 = by size (1 KiB under 256 MiB
+    // of long streams, 4 KiB from there), 10 / 12 forced (test option)
+    uint32_t stream_seg_log2 = 0;
     size_t pin_bl2_cap = 0;
     // frame layer scratch (snapmi_frame.hip)
     snapmi::DevBuf fr_tables, fr_desc, fr_meta, fr_scan, fr_slots, fr_chunk_off;

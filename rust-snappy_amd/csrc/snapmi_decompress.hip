@@ -1903,12 +1903,13 @@ __device__ __forceinline__ bool elem_step(gcptr in, uint64_t in_len,
     return true;
 }
 
-// level 1 = 4 KiB segments, 2 = 256 KiB, 3 = 16 MiB
-template <int L> __device__ __forceinline__ uint64_t level_bytes()
+// level 1 = segments (4 KiB; 1 KiB for short streams: StreamArgs::seg_log2),
+// 2 = 64 of them, 3 = 64 of those
+static_assert(kSegPerSuper == 64, "level_bytes shifts by 6 per level");
+template <int L>
+__device__ __forceinline__ uint64_t level_bytes(const StreamArgs &a)
 {
-    return L == 1 ? (uint64_t)kSeg
-                  : (L == 2 ? (uint64_t)kSeg * kSegPerSuper
-                            : (uint64_t)kSeg * kSegPerSuper * kSegPerSuper);
+    return 1ull << (a.seg_log2 + 6 * (L - 1));
 }
 template <int L>
 __device__ __forceinline__ su64x2 *level_table(const StreamArgs &a)
@@ -1934,8 +1935,8 @@ template <>
 __device__ __forceinline__ bool reach_end<1>(const StreamArgs &a, uint64_t &p,
                                              uint64_t &out)
 {
-    const uint64_t seg = p / kSeg;
-    const uint64_t o = p - seg * kSeg;
+    const uint64_t seg = p >> a.seg_log2;
+    const uint64_t o = p - (seg << a.seg_log2);
     if (o < kEntry) {
         const su64x2 e = level_table<1>(a)[seg * kEntry + o];
         if (e.x == kNone)
@@ -1944,7 +1945,7 @@ __device__ __forceinline__ bool reach_end<1>(const StreamArgs &a, uint64_t &p,
         out += e.y;
         return true;
     }
-    uint64_t end = (seg + 1) * kSeg;
+    uint64_t end = (seg + 1) << a.seg_log2;
     if (end > a.in_len)
         end = a.in_len;
     while (p < end)
@@ -1956,7 +1957,7 @@ template <int L>
 __device__ __forceinline__ bool reach_end(const StreamArgs &a, uint64_t &p,
                                           uint64_t &out)
 {
-    const uint64_t B = level_bytes<L>(), Bc = level_bytes<L - 1>();
+    const uint64_t B = level_bytes<L>(a), Bc = level_bytes<L - 1>(a);
     const uint64_t blk = p / B;
     uint64_t end = (blk + 1) * B;
     if (end > a.in_len)
@@ -1987,7 +1988,7 @@ __device__ __forceinline__ void build_level(const StreamArgs &a, uint32_t wg)
     __shared__ su64x2 tab[kSegPerSuper * kEntry]; // 16 KiB
     if (a.meta[2])
         return;
-    const uint64_t B = level_bytes<L>(), Bc = level_bytes<L - 1>();
+    const uint64_t B = level_bytes<L>(a), Bc = level_bytes<L - 1>(a);
     const uint64_t blk = wg;
     uint64_t end = (blk + 1) * B;
     if (end > a.in_len)
@@ -2023,7 +2024,7 @@ __device__ __forceinline__ void spread_level(const StreamArgs &a, uint32_t wg)
     if (a.meta[2])
         return;
     const uint64_t blk = (uint64_t)wg * blockDim.x + threadIdx.x;
-    const uint64_t B = level_bytes<L>(), Bc = level_bytes<L - 1>();
+    const uint64_t B = level_bytes<L>(a), Bc = level_bytes<L - 1>(a);
     if (blk * B >= a.in_len)
         return;
     const su64x2 e = level_entry<L>(a)[blk];
@@ -2120,6 +2121,7 @@ struct HopShared {
     gcptr in;    // the stream
     uint64_t in_len;
     uint64_t wbase;  // stream offset of the wavefront's first segment
+    uint32_t seg;    // segment size of this call (a power of two)
     uint32_t mis;    // (in + wbase) mod kHopLine: the window's lines are aligned
     uint32_t lastR;  // end of the stream from wbase, at most 2^31
     uint64_t lastP;  // the same + mis, exact
@@ -2145,7 +2147,7 @@ struct Hopper {
     // segment boundary, or the end of the stream)
     __device__ __forceinline__ bool more(const HopShared &h) const
     {
-        return R < h.lastR && (R < endR || (R & (kSeg - 1)) >= kEntry);
+        return R < h.lastR && (R < endR || (R & (h.seg - 1)) >= kEntry);
     }
     __device__ __forceinline__ void start(const HopShared &h, uint32_t r,
                                           uint32_t o, uint32_t e, uint32_t st,
@@ -2183,7 +2185,7 @@ struct Hopper {
             const uint64_t end = h.wbase + endR;
             bool ok = true;
             while (ok && q < h.in_len &&
-                   (q < end || (q & (kSeg - 1)) >= kEntry)) {
+                   (q < end || (q & (h.seg - 1)) >= kEntry)) {
                 if (q >= end && ++over > kScanOverrun) {
                     ok = false;
                     break;
@@ -2296,6 +2298,7 @@ __device__ __forceinline__ void hop_pool(const HopShared &h, uint32_t npool,
             const uint32_t lo = w.L0 * kHopLine - h.mis, span = w.nl * kHopLine;
             const uint32_t endR = w.endR, stopOut = w.stopOut;
             const uint32_t capR = w.stopR < h.lastR ? w.stopR : h.lastR;
+            const uint32_t segm = h.seg - kEntry; // landing zone: none set
 #ifndef SNAPMI_HOP_UNROLL
 #define SNAPMI_HOP_UNROLL SNAPMI_HOP_ITERS
 #endif
@@ -2326,7 +2329,7 @@ __device__ __forceinline__ void hop_pool(const HopShared &h, uint32_t npool,
                     fail = fail || over > kScanOverrun || R > h.lastR;
                     run = run && !slow && !fail && R < capR &&
                           out < stopOut &&
-                          (R < endR || (R & (kSeg - kEntry)) != 0);
+                          (R < endR || (R & segm) != 0);
                 }
             }
             w.R = R;
@@ -2393,7 +2396,9 @@ __device__ __forceinline__ void stream_scan(const StreamArgs &a, const uint32_t 
     h.in = (gcptr)a.in;
     h.in_len = a.in_len;
     const uint64_t seg0 = (uint64_t)wg * 64;
-    h.wbase = seg0 * kSeg;
+    const uint32_t sl2 = a.seg_log2; // (the wavefront's 64 segments: < 2^31)
+    h.seg = 1u << sl2;
+    h.wbase = seg0 << sl2;
     h.mis = (uint32_t)((uintptr_t)a.in + h.wbase) & (kHopLine - 1);
     // the grid covers nseg + 1 sentinel: its last workgroup can begin behind
     // the input (lastR = 0 then: every walk is invalid and reads nothing)
@@ -2405,16 +2410,17 @@ __device__ __forceinline__ void stream_scan(const StreamArgs &a, const uint32_t 
     hop_lut(lutbuf);
     su64x2 *const table = level_table<1>(a) + seg0 * kEntry;
     const uint32_t lastR = h.lastR;
-    auto seg_end = [lastR](uint32_t sl) {
-        return (sl + 1) * kSeg < lastR ? (sl + 1) * kSeg : lastR;
+    auto seg_end = [lastR, sl2](uint32_t sl) {
+        return ((sl + 1) << sl2) < lastR ? ((sl + 1) << sl2) : lastR;
     };
 
     // ---- phase A: every entry, kHopMid bytes far --------------------------
     hop_pool(
         h, nloc * kEntry,
         [&](uint32_t it, Hopper &w) {
-            const uint32_t sl = it / kEntry, r0 = sl * kSeg + it % kEntry;
-            w.start(h, r0, 0, seg_end(sl), sl * kSeg + kHopMid, r0 < lastR);
+            const uint32_t sl = it / kEntry,
+                           r0 = (sl << sl2) + it % kEntry;
+            w.start(h, r0, 0, seg_end(sl), (sl << sl2) + kHopMid, r0 < lastR);
         },
         [&](uint32_t it, Hopper &w) {
             const bool paused = !w.fail && !w.punt && w.more(h);
@@ -2455,8 +2461,8 @@ __device__ __forceinline__ void stream_scan(const StreamArgs &a, const uint32_t 
     // resolved from the last segment down.
     for (uint32_t i = lane; i < 64; i += 64)
         trunkL[i] = 0xFF;
-    auto next_stop = [nloc](uint32_t sl) {
-        return sl + 1 < nloc ? (sl + 1) * kSeg + kHopMid : kHopNone;
+    auto next_stop = [nloc, sl2](uint32_t sl) {
+        return sl + 1 < nloc ? ((sl + 1) << sl2) + kHopMid : kHopNone;
     };
     hop_pool(
         h, nloc + ntodo,
@@ -2472,7 +2478,7 @@ __device__ __forceinline__ void stream_scan(const StreamArgs &a, const uint32_t 
         [&](uint32_t it, Hopper &w) {
             uint32_t link = 0xFF;
             if (!w.fail && !w.punt && w.more(h)) { // stands at a stop
-                const uint32_t t = w.R / kSeg;
+                const uint32_t t = w.R >> sl2;
                 if (t < nloc && midR[t * kEntry] == w.R) {
                     link = t;
                 } else {
@@ -2531,7 +2537,7 @@ __device__ __forceinline__ void stream_chain(const StreamArgs &a, const uint32_t
     uint64_t p = a.meta[0], out = 0;
     bool ok = true;
     while (ok && p < a.in_len) {
-        level_entry<3>(a)[p / level_bytes<3>()] = (su64x2){p, out};
+        level_entry<3>(a)[p / level_bytes<3>(a)] = (su64x2){p, out};
         ok = reach_end<3>(a, p, out);
     }
     // the elements must end with the stream and produce the announced
@@ -2568,7 +2574,9 @@ __device__ __forceinline__ void stream_cuts(const StreamArgs &a, const uint32_t 
     h.lut = (l_u16x *)lutbuf;
     h.in = (gcptr)a.in;
     h.in_len = a.in_len;
-    h.wbase = seg0 * kSeg;
+    const uint32_t sl2 = a.seg_log2;
+    h.seg = 1u << sl2;
+    h.wbase = seg0 << sl2;
     h.mis = (uint32_t)((uintptr_t)a.in + h.wbase) & (kHopLine - 1);
     const uint64_t left = a.in_len > h.wbase ? a.in_len - h.wbase : 0;
     h.lastR = left < (1ull << 31) ? (uint32_t)left : 1u << 31;
@@ -2580,7 +2588,7 @@ __device__ __forceinline__ void stream_cuts(const StreamArgs &a, const uint32_t 
     for (uint32_t j = 0; j < kCutSegs; j += 64) {
         const uint64_t seg = seg0 + j + lane;
         bool has = false;
-        if (seg * kSeg < a.in_len) {
+        if ((seg << sl2) < a.in_len) {
             const su64x2 e = level_entry<1>(a)[seg];
             if (e.x != kNone) {
                 uint64_t np = e.x, nout = e.y;
@@ -2615,7 +2623,7 @@ __device__ __forceinline__ void stream_cuts(const StreamArgs &a, const uint32_t 
             reach_end<1>(a, np, nout); // (true: it was, above)
             k = out0 / kStreamChunk + 1;
             const uint32_t endR =
-                (sl + 1) * kSeg < lastR ? (sl + 1) * kSeg : lastR;
+                ((sl + 1) << sl2) < lastR ? ((sl + 1) << sl2) : lastR;
             w.start(h, (uint32_t)(e.x - h.wbase), 0, endR, kHopNone, true);
             w.stopOut = (uint32_t)(k * kStreamChunk - out0);
             w.run = w.run && w.out < w.stopOut;

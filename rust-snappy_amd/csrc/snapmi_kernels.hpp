@@ -160,6 +160,10 @@ struct StreamArgs {
     unsigned long long *e1, *e2, *e3;
     unsigned long long *cuts;     // [(kmax + 1) * 2] (src, dst) of piece k
     uint32_t nseg, nsuper, nsuper3, kmax;
+    // log2 of the segment size of this call (12 = kSeg; 10 for streams that
+    // are short enough for the scan to be a wait for its longest walk: a
+    // quarter of the hops per lane, four times the lanes - round 5)
+    uint32_t seg_log2;
     // piece descriptors for k_decompress_streams
     const void **c_in;
     unsigned long long *c_inlen;

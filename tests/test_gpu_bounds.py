@@ -236,7 +236,8 @@ def test_sequential_decoder_keeps_to_its_buffers(built):
         c.close()
 
 
-def test_long_stream_paths_keep_to_their_buffers(ctx):
+@pytest.mark.parametrize("seg", [10, 12])
+def test_long_stream_paths_keep_to_their_buffers(ctx, seg):
     """snapmi_decompress_stream (scan, cuts, pieces) and the long streams of a
     batch (k_bstream_*): outputs of exactly the announced length between
     bands; inputs in allocations of exactly their size (the scan's last
@@ -245,6 +246,7 @@ def test_long_stream_paths_keep_to_their_buffers(ctx):
     behind them leaves the allocation."""
     import foreign
     from rust_snappy_amd import raw
+    ctx.set_test_option("stream_seg_log2", seg)
     rnd = O.corpus_round()
     rng = random.Random(4)
     big = b"".join(d for _, d in rnd)
@@ -263,7 +265,11 @@ def test_long_stream_paths_keep_to_their_buffers(ctx):
             assert pad >= 0
         raise AssertionError("no input of that compressed length")
 
+    # (the scan's last workgroup begins behind the input when the segment
+    # count is a multiple of 64: k * 256 KiB - 100 with 4 KiB segments,
+    # k * 64 KiB - 100 with 1 KiB)
     datas = [with_compressed_len(k * 262144 - 100) for k in (2, 3)]
+    datas += [with_compressed_len(k * 65536 - 100) for k in (7,)]
     datas += [with_compressed_len(2 * 262144 - 4095),
               with_compressed_len(2 * 262144 - 1),
               with_compressed_len(2 * 262144 + 1),
@@ -319,6 +325,7 @@ def test_long_stream_paths_keep_to_their_buffers(ctx):
             caps.append(1024)
     dst, lens, errs = decode_guarded(ctx, muts, caps, 13, False)
     check_against_oracle(muts, caps, dst, lens, errs)
+    ctx.set_test_option("stream_seg_log2", 0)
 
 
 def encode_guarded(ctx, datas, seed, aligned, caps=None):

@@ -466,12 +466,16 @@ def stream_decode(ctx, comp, cap):
                                                int(e["b"]), int(e["c"]))
 
 
-def test_long_stream_parallel_decode(ctx):
+@pytest.mark.parametrize("seg", [10, 12])
+def test_long_stream_parallel_decode(ctx, seg):
     """One raw stream on many wavefronts: equal to the original, for streams
     of this format's encoders (64 KiB blocks: pieces independent), for
     foreign streams (copies across pieces: sequential path), tiny and empty
     streams, and with the oracle's error on corrupted ones."""
     import foreign
+    # (both segment sizes of the scan: 1 KiB is what streams of this size get
+    # by themselves, 4 KiB what those of 256 MiB and more do)
+    ctx.set_test_option("stream_seg_log2", seg)
     rnd = O.corpus_round()
     big = b"".join(d for _, d in rnd) * 3            # 8.8 MB, 137 blocks
     cases = [big, rnd[2][1] * 5, bytes(300000), b"", b"a", rnd[0][1],
@@ -517,9 +521,11 @@ def test_long_stream_parallel_decode(ctx):
         raise AssertionError
     except O.SnapError as oe:
         assert (oe.kind, oe.a, oe.b, oe.c) == e
+    ctx.set_test_option("stream_seg_log2", 0)
 
 
-def test_long_stream_scan_shapes(ctx):
+@pytest.mark.parametrize("seg", [10, 12])
+def test_long_stream_scan_shapes(ctx, seg):
     """The structure k_stream_scan / k_stream_cuts work in (64 segments of
     4 KiB per scan wavefront, 512 per cuts wavefront, walks handed out from a
     pool, chains that join the next segment's trunk): streams whose segment
@@ -529,16 +535,19 @@ def test_long_stream_scan_shapes(ctx):
     round can hold), and literals with one, two and three length bytes at
     every alignment.  All must come from the parallel path."""
     from rust_snappy_amd import raw
+    ctx.set_test_option("stream_seg_log2", seg)
+    seg_bytes = 1 << seg
     rng = random.Random(77)
     text = b"".join(d for n, d in O.corpus_round() if "txt" in n or "html" in n)
 
     def with_segments(nseg):
         # a prefix of text x k whose stream is nseg segments long (bisection)
-        src = text * (nseg * 4096 * 3 // len(text) + 2)
+        src = text * (nseg * seg_bytes * 3 // len(text) + 2)
         lo, hi = 1, len(src)
         while lo < hi:
             mid = (lo + hi) // 2
-            if (len(O.compress(src[:mid])) + 4095) // 4096 < nseg:
+            if (len(O.compress(src[:mid])) + seg_bytes - 1) // seg_bytes \
+                    < nseg:
                 lo = mid + 1
             else:
                 hi = mid
@@ -568,9 +577,11 @@ def test_long_stream_scan_shapes(ctx):
         assert e[0] == 0, (i, e)
         assert got == data, (i, len(data), len(comp))
         assert raw.stream_decode_path(ctx) == 0, i
+    ctx.set_test_option("stream_seg_log2", 0)
 
 
-def test_batch_with_long_streams(ctx):
+@pytest.mark.parametrize("seg", [10, 12])
+def test_batch_with_long_streams(ctx, seg):
     """A small batch gives its long streams their pieces (k_long_plan,
     k_bstream_*): long and short streams side by side, long ones that are
     corrupt, truncated, lie in their header, come from a foreign encoder
@@ -617,6 +628,7 @@ def test_batch_with_long_streams(ctx):
     assert len(streams) < 200
     plain_ctx = R.raw.Context(0)
     plain_ctx.set_option("batch_long_streams", 0)
+    ctx.set_test_option("stream_seg_log2", seg)
     try:
         for c in (ctx, plain_ctx):
             got, errs = gpu_decompress(c, streams, caps)
@@ -628,6 +640,7 @@ def test_batch_with_long_streams(ctx):
                     assert (oe.kind, oe.a, oe.b, oe.c) == e, (i, e, oe)
     finally:
         plain_ctx.close()
+        ctx.set_test_option("stream_seg_log2", 0)
 
 
 def test_scalar_decompress_uses_long_stream_path(ctx):
