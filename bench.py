@@ -614,12 +614,15 @@ def main():
     k_comp_ms, k_dec_ms, t_comp, t_dec, compact_ms, plan_ms = [], [], 0.0, \
         0.0, [], []
     k_dom_ms = []
+    comp_kernel, dec_kernel = "k_match_both", "k_decompress_streams3"
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ta = time.perf_counter()
         tm = do_compress()
+        comp_kernel = ctx.last_kernel()
         tb = time.perf_counter()
         td = do_decompress()
+        dec_kernel = ctx.last_kernel()
         tc = time.perf_counter()
         k_comp_ms.append(tm["codec_ms"])
         k_dom_ms.append(tm["dominant_ms"])
@@ -715,7 +718,8 @@ def main():
         value = 2.0 * total_u * K / elapsed / GIB
         comp_gibs = total_u * K / t_comp / GIB
         dec_gibs = total_u * K / t_dec / GIB
-        # roofline of the dominant kernel (k_match_blocks): algorithmic
+        # roofline of the dominant kernel (k_match_both: the lane kernel and
+        # the window kernel on every CU; k_match_blocks below 6 GiB): algorithmic
         # bytes per launch = U read + C written ((1+rho) B per
         # uncompressed byte), over the HIP-event duration of that launch.
         kc = float(np.mean(k_comp_ms)) * 1e-3   # all compress-side kernels
@@ -727,10 +731,8 @@ def main():
         # direction (U + C) are charged to the dominant kernel's duration
         ach = alg / kdom / 1e9
         ach_d = alg / kd / 1e9
-        dom_name = ("k_match_blocks" if abs(kdom - kc) > 1e-9
-                    else "k_compress_spans")
-        dec_name = ("k_decompress_streams2" if os.environ.get(
-            "SNAPMI_DECODE_KERNEL") == "2" else "k_decompress_streams3")
+        # (the library says which kernels these were: snapmi_last_kernel)
+        dom_name, dec_name = comp_kernel, dec_kernel
         # roofline.traffic: measured by this command (two PMC child runs) -
         # or, if that is switched off or fails, quoted from the committed
         # profile of the same workload and labelled as such

@@ -119,6 +119,11 @@ void snapmi_host_free(void *p);
  * every candidate region of the last lane-table allocation (none when
  * lane_table_tries is 1) and the most device memory it held at once. */
 const char *snapmi_table_probe_log(const snapmi_ctx *ctx);
+/* Name of the dominant kernel of the last batch call - the one
+ * snapmi_timing.dominant_ms times: "k_match_both", "k_match_blocks",
+ * "k_match_spans", "k_compress_spans", "k_decompress_streams3" ... ("" before
+ * the first call).  For profiles: bench.py names its roofline by it. */
+const char *snapmi_last_kernel(const snapmi_ctx *ctx);
 /* hipStream_t the context launches on (for event timing by the caller). */
 void *snapmi_ctx_stream(const snapmi_ctx *ctx);
 /* "snapmi <version> gfx950" */

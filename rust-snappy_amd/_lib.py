@@ -48,6 +48,7 @@ SYMBOLS = [
     ("snapmi_ctx_destroy", None, [_P]),
     ("snapmi_last_error", C.c_char_p, [_P]),
     ("snapmi_table_probe_log", C.c_char_p, [_P]),
+    ("snapmi_last_kernel", C.c_char_p, [_P]),
     ("snapmi_host_alloc", _P, [_SZ]),
     ("snapmi_host_free", None, [_P]),
     ("snapmi_ctx_stream", _P, [_P]),

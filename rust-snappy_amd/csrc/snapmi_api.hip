@@ -315,6 +315,10 @@ int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value)
         ctx->lane_table_budget_pct = (uint32_t)value;
     else if (strcmp(name, "window_tokens") == 0 && value >= 0 && value <= 1)
         ctx->window_tokens = (int)value;
+    else if (strcmp(name, "lane_coresident") == 0 && value >= 0 && value <= 1)
+        ctx->lane_coresident = (int)value;
+    else if (strcmp(name, "lane_coresident_min_blocks") == 0 && value >= 1)
+        ctx->lane_coresident_min_blocks = (uint64_t)value;
     else if (strcmp(name, "small_table_kernel") == 0 && value >= 0 &&
              value <= 1)
         ctx->small_table_kernel = (int)value;
@@ -440,6 +444,11 @@ void snapmi_host_free(void *p)
 const char *snapmi_table_probe_log(const snapmi_ctx *ctx)
 {
     return ctx ? ctx->probe_log.c_str() : "";
+}
+
+const char *snapmi_last_kernel(const snapmi_ctx *ctx)
+{
+    return ctx ? ctx->last_kernel : "";
 }
 
 const char *snapmi_last_error(const snapmi_ctx *ctx)
@@ -715,6 +724,11 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                          c * 100 >= u * ctx->match_spans_ratio_pct;
         }
     }
+    // both match finders on every CU (k_match_both): launches that fill the
+    // chip with lanes anyway
+    const bool both_cores = lanes_mode && !waves_mode && !span_match &&
+                            ctx->lds_order_ok && ctx->lane_coresident &&
+                            nb_big >= ctx->lane_coresident_min_blocks;
     if (lanes_mode && span_match) {
         if ((rc = reserve(ctx, ctx->tokens, (size_t)seg_blocks * kMaxTokens *
                                                 sizeof(uint64_t))) ||
@@ -731,6 +745,10 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
             waves = need ? need : 1;
         if (ctx->lane_max_waves && waves > ctx->lane_max_waves)
             waves = ctx->lane_max_waves;
+        // k_match_both: three lane wavefronts on every CU, beside two of
+        // the window kernel
+        if (both_cores)
+            waves = (uint64_t)ctx->num_cus * kBothLaneWaves;
         const uint32_t lanes = (uint32_t)waves * 64;
         if (lanes > ctx->n_lanes) { // tables must start zeroed (epoch 0)
             // The tables are spread over more memory than they fill: HBM
@@ -1054,7 +1072,10 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                         dim3((uint32_t)(want < (uint64_t)ctx->num_cus
                                             ? want : ctx->num_cus)),
                         dim3(kCompressWaves * 64), 0, s, a);
-                } else
+                } else if (both_cores)
+                    hipLaunchKernelGGL(k_match_both, dim3(ctx->num_cus),
+                                       dim3(kBothWaves * 64), 0, s, a);
+                else
                 hipLaunchKernelGGL(spec ? k_match_blocks_spec : k_match_blocks,
                                    dim3(a.n_lanes / 64), dim3(64), 0, s, a);
                 if (use_small) {
@@ -1091,7 +1112,10 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                             dim3((uint32_t)(want < (uint64_t)ctx->num_cus
                                                 ? want : ctx->num_cus)),
                             dim3(kCompressWaves * 64), 0, s, a);
-                    } else
+                    } else if (both_cores)
+                        hipLaunchKernelGGL(k_match_both, dim3(ctx->num_cus),
+                                           dim3(kBothWaves * 64), 0, s, a);
+                    else
                     hipLaunchKernelGGL(
                         spec ? k_match_blocks_spec : k_match_blocks,
                         dim3(a.n_lanes / 64), dim3(64), 0, s, a);
@@ -1141,6 +1165,12 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     HIP_TRY(ctx, hipGetLastError());
     ctx->timing_valid = true;
     ctx->timing_is_compress = true;
+    ctx->last_kernel =
+        !blocks ? "k_compress_tiny"
+        : !lanes_mode ? "k_compress_spans"
+        : span_match ? (use_small && nb_big == 0 ? "k_match_spans_8k"
+                                                 : "k_match_spans")
+        : both_cores ? "k_match_both" : "k_match_blocks";
     ctx->dominant_split = lanes_mode;
     ctx->codec_launches = blocks ? 1 : 0;
     return SNAPMI_OK;
@@ -1238,6 +1268,9 @@ int launch_decompress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     HIP_TRY(ctx, hipEventRecord(ctx->ev[3], s));
     ctx->timing_valid = true;
     ctx->timing_is_compress = false;
+    ctx->last_kernel = ctx->decode_kernel == 0   ? "k_decompress_sequential"
+                       : ctx->decode_kernel == 2 ? "k_decompress_streams2"
+                                                 : "k_decompress_streams3";
     ctx->dominant_split = false;
     ctx->codec_launches = 1;
     return SNAPMI_OK;

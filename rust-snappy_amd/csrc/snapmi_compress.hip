@@ -697,6 +697,22 @@ __device__ __noinline__ uint32_t next_front_ticket(uint32_t *ticket,
         t = atomicAdd(ticket, 1u);
     return uni(t);
 }
+// the two-ended ticket over the blocks [lo, hi) of a segment: the next block
+// from the BACK (the lane kernel counts the low word up from the front)
+__device__ __noinline__ uint32_t next_back_ticket(uint32_t *ticket,
+                                                  uint32_t lane, uint32_t lo,
+                                                  uint32_t hi)
+{
+    uint32_t blk = 0;
+    if (lane == 0) {
+        const unsigned long long old =
+            atomicAdd((unsigned long long *)ticket, 1ull << 32);
+        const uint32_t front = (uint32_t)old, back = (uint32_t)(old >> 32);
+        blk = hi > lo && (uint64_t)front + back < hi - lo ? hi - 1 - back
+                                                          : 0xFFFFFFFFu;
+    }
+    return uni(blk);
+}
 
 // ---------------------------------------------------------------------
 // Self-check run once per context (snapmi_ctx_create): k_compress_blocks
@@ -1913,22 +1929,26 @@ namespace {
 // off 2 048 .. 16 384 blocks.  A launch of 32 768 blocks and more is at the
 // random-access rate of HBM even with one block per lane, and the extra
 // table reads buy nothing there: the plain kernel.
+// one wavefront's LDS: the lanes' input windows (two 128-byte lines of a
+// lane's block) and token buffers (16 tokens = one 128-byte line: every store
+// of a lane is its own DRAM transaction, and those are what bounds the kernel)
+constexpr uint32_t kLaneRingWords = 64 * 64;
+constexpr uint32_t kLaneTokWords = 64 * 16;
+// lane: 0..63 of this wavefront; g: its lane id among all lanes of the launch
+// (its table, its epoch)
 template <bool kSpec>
-__device__ __forceinline__ void match_blocks(const CompressArgs &a)
+__device__ __forceinline__ void match_blocks(
+    const CompressArgs &a, const uint32_t lane, const uint32_t g,
+    __attribute__((address_space(3))) uint32_t *const ring,
+    __attribute__((address_space(3))) unsigned long long *const tokbuf)
 {
-    // per-lane input window: two 128-byte lines of the lane's block
-    __shared__ __attribute__((aligned(16))) uint32_t ring[64 * 64];
-    // per-lane token buffer: 16 tokens = one 128-byte line (every store of a
-    // lane is its own DRAM transaction, and those are what bounds the kernel)
-    __shared__ __attribute__((aligned(16))) unsigned long long tokbuf[64 * 16];
     typedef __attribute__((address_space(3))) unsigned long long l_u64;
-    l_u64 *const tbuf = (l_u64 *)tokbuf + threadIdx.x * 16;
+    l_u64 *const tbuf = tokbuf + lane * 16;
     typedef __attribute__((address_space(3))) uint32_t l_u32;
     typedef __attribute__((address_space(3))) u32x4 l_u32x4;
     typedef __attribute__((address_space(1))) u32x4 g_u32x4;
-    l_u32 *const win = (l_u32 *)ring + threadIdx.x * 64;
+    l_u32 *const win = ring + lane * 64;
 
-    const uint32_t g = blockIdx.x * 64 + threadIdx.x; // lane id in the grid
     typedef __attribute__((address_space(1))) unsigned long long g_u64;
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(1))) u64x2 g_entry;
@@ -1975,7 +1995,7 @@ __device__ __forceinline__ void match_blocks(const CompressArgs &a)
         unsigned long long tbase = 0;
         if (M_need) {
             const uint32_t leader = (uint32_t)__builtin_ctzll(M_need);
-            if (threadIdx.x == leader)
+            if (lane == leader)
                 tbase = atomicAdd((unsigned long long *)a.ticket,
                                   (unsigned long long)__builtin_popcountll(
                                       M_need));
@@ -2325,11 +2345,67 @@ __device__ __forceinline__ void match_blocks(const CompressArgs &a)
 
 __global__ __launch_bounds__(64) void k_match_blocks(CompressArgs a)
 {
-    match_blocks<false>(a);
+    __shared__ __attribute__((aligned(16))) uint32_t ring[kLaneRingWords];
+    __shared__ __attribute__((aligned(16)))
+    unsigned long long tokbuf[kLaneTokWords];
+    match_blocks<false>(
+        a, threadIdx.x, blockIdx.x * 64 + threadIdx.x,
+        (__attribute__((address_space(3))) uint32_t *)ring,
+        (__attribute__((address_space(3))) unsigned long long *)tokbuf);
 }
 __global__ __launch_bounds__(64) void k_match_blocks_spec(CompressArgs a)
 {
-    match_blocks<true>(a);
+    __shared__ __attribute__((aligned(16))) uint32_t ring[kLaneRingWords];
+    __shared__ __attribute__((aligned(16)))
+    unsigned long long tokbuf[kLaneTokWords];
+    match_blocks<true>(
+        a, threadIdx.x, blockIdx.x * 64 + threadIdx.x,
+        (__attribute__((address_space(3))) uint32_t *)ring,
+        (__attribute__((address_space(3))) unsigned long long *)tokbuf);
+}
+
+// Both match finders on every CU (round 5): three wavefronts of the lane
+// kernel - as many as reach the DRAM-transaction ceiling it is bound by
+// (tests/hw/sweep.sh: 3 waves per CU 123 ms, 6 waves 122) - and two of the
+// window kernel, which is bound by the instructions and latencies of a lone
+// wavefront and touches HBM for little more than its input, in one persistent
+// workgroup per CU: 3 x 24 KiB of lane windows and token lines + 2 x 32 KiB of
+// tables.  One two-ended ticket: the lanes take blocks from the front of the
+// segment, the windows from its back, until they meet; both write tokens for
+// k_encode_tokens.  (Round 4 split the CUs between the two kernels and gained
+// nothing; here the lanes keep every CU.)
+__global__ __launch_bounds__(kBothWaves * 64) void k_match_both(CompressArgs a)
+{
+    __shared__ __attribute__((aligned(16)))
+    uint32_t ring[kBothLaneWaves][kLaneRingWords];
+    __shared__ __attribute__((aligned(16)))
+    unsigned long long tokbuf[kBothLaneWaves][kLaneTokWords];
+    __shared__ __attribute__((aligned(16)))
+    uint16_t tables[kBothWaves - kBothLaneWaves][kMaxTable];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    if (wave < kBothLaneWaves) {
+        match_blocks<false>(
+            a, lane, (blockIdx.x * kBothLaneWaves + wave) * 64 + lane,
+            (__attribute__((address_space(3))) uint32_t *)&ring[wave][0],
+            (__attribute__((address_space(3))) unsigned long long *)
+                &tokbuf[wave][0]);
+        return;
+    }
+    const lptr16 table = (lptr16)&tables[wave - kBothLaneWaves][0];
+    const uint32_t tbase = (uint32_t)(uintptr_t)table;
+    uint32_t nblocks = a.blk_first[a.n_streams];
+    if (nblocks > a.host_blocks)
+        nblocks = a.host_blocks;
+    if (nblocks > a.blk_hi)
+        nblocks = a.blk_hi;
+    for (;;) {
+        const uint32_t b =
+            uni(next_back_ticket(a.ticket, lane, a.blk_lo, nblocks));
+        if (b == 0xFFFFFFFFu)
+            break;
+        compress_one_block_span<false, true>(a, b, lane, table, tbase);
+    }
 }
 
 // ---------------------------------------------------------------------

@@ -64,6 +64,15 @@ struct snapmi_ctx {
     // scratch).  Measured equal within 3 % either way on 64 MiB .. 1 GiB
     // (profiles/r5_span_sweep.txt), so the path without scratch is the default
     int window_tokens = 0;
+    // 1: lane-kernel launches of at least lane_coresident_min_blocks blocks
+    // run k_match_both - three lane wavefronts and two window wavefronts on
+    // every CU, one two-ended ticket
+    // (cfg2, 146 700 blocks: 115.6 -> 108.4 ms for the match finder; at 4 GiB
+    // a draw, below that the lanes have taken every block before a window
+    // wavefront has finished one: profiles/r5_coresident.txt)
+    int lane_coresident = 1;
+    uint64_t lane_coresident_min_blocks = 98304;
+    const char *last_kernel = "";
     // 1: blocks of at most 8 KiB go to the window kernel with 16 KiB tables
     // (k_match_spans_8k: 10 wavefronts per CU) when the batch has at least
     // small_table_min_blocks of them

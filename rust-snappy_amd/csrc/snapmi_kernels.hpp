@@ -62,6 +62,8 @@ struct CompressArgs {
 constexpr uint32_t kCompressWaves = 5;
 // ... of the window kernel for blocks of at most 8 KiB (16 KiB tables)
 constexpr uint32_t kSmallTableWaves = 10;
+// k_match_both: wavefronts per CU, and how many of them are the lane kernel's
+constexpr uint32_t kBothWaves = 6, kBothLaneWaves = 4;
 // token slots per block: at most 16385 tokens (every token but the last ends
 // in a copy of >= 4 bytes), rounded up to whole 128-byte groups of 16 so a
 // lane can write its tokens a full cache line at a time
@@ -117,6 +119,7 @@ __global__ void k_compress_small1k(CompressArgs a);  // [512, 1024)
 __global__ void k_compress_small2k(CompressArgs a);  // [1024, 2048)
 __global__ void k_match_blocks(CompressArgs a);
 __global__ void k_match_blocks_spec(CompressArgs a); // launches with blocks <= lanes
+__global__ void k_match_both(CompressArgs a); // 3 lane + 2 window wavefronts per CU
 __global__ void k_encode_tokens(CompressArgs a);
 __global__ void k_scan_sizes(CompressArgs a);
 __global__ void k_compact(CompressArgs a);

@@ -91,6 +91,10 @@ class Context:
         if rc:
             _raise(self, rc)
 
+    def last_kernel(self):
+        """snapmi_last_kernel: the dominant kernel of the last batch call."""
+        return _lib.load().snapmi_last_kernel(self._h).decode()
+
     def last_timing(self):
         t = _lib.SnapmiTiming()
         rc = _lib.load().snapmi_last_timing(self._h, C.byref(t))

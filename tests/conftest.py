@@ -47,7 +47,8 @@ def ctx(request, built):
 @pytest.fixture(scope="session",
                 params=["spans", "spans_lds", "waves", "waves_lds", "lanes",
                         "lanes_segmented", "lanes_overlap", "both",
-                        "spans_match", "small_tables", "small_tables_lanes"])
+                        "spans_match", "small_tables", "small_tables_lanes",
+                        "coresident"])
 def cctx(request, built):
     """A context per compressor kernel: the wavefront-per-block kernels (window
     steps and, as the cross-check, one copy per step; five tables per CU and
@@ -72,8 +73,12 @@ def cctx(request, built):
                                    "lanes_segmented": 1, "lanes_overlap": 1,
                                    "both": 2, "spans_match": 1,
                                    "small_tables": 1,
-                                   "small_tables_lanes": 1}[
+                                   "small_tables_lanes": 1, "coresident": 1}[
         request.param])
+    # three lane wavefronts and two window wavefronts per CU on one two-ended
+    # ticket (k_match_both), however few blocks there are
+    c.set_option("lane_coresident", 1 if request.param == "coresident" else 0)
+    c.set_option("lane_coresident_min_blocks", 1)
     small = request.param.startswith("small_tables")
     c.set_option("small_table_kernel", 1 if small else 0)
     c.set_option("small_table_min_blocks", 1)
