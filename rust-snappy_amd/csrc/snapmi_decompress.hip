@@ -2,37 +2,42 @@
 //
 // Semantics (element order, every bounds check, which error wins and with
 // which field values) follow the reference src/decompress.rs exactly.  The
-// reference walks one element at a time (tag dispatch loop, :130-148); here
-// one wavefront owns one raw stream (a raw stream has no block index --
-// reference src/compress.rs:128-153 -- so the stream is the parallel unit,
-// and a batch supplies thousands of them) and works in three wave-wide steps:
+// reference walks one element at a time (tag dispatch loop, :130-148).  A raw
+// stream has no block index (src/compress.rs:128-153), so the stream is the
+// parallel unit; a batch supplies thousands of them, sorted longest first
+// (k_plan_decompress*), and every size class has its kernel:
 //
-//   1. PARSE  every lane decodes "the element that would start at byte
-//      s+lane" of the compressed stream (tag, length, offset, encoded size);
-//      a scalar walk over those 64 speculative decodes (v_readlane, ~6 SALU
-//      per element) picks the real element starts; a DPP scan of their
-//      output lengths gives every element its output position; all of the
-//      reference's bounds checks are evaluated per element, in parallel.
-//   2. COMPACT  element records move to lanes 0..E-1 (ds_permute).
-//   3. EXPAND  the window's output is produced 64 bytes per pass, one lane
-//      per output byte: the lane finds its element (bit mask + v_mbcnt),
-//      fetches the record (ds_bpermute), and reads its source byte from the
-//      compressed stream (literal), from a 4 KiB LDS ring holding the most
-//      recent output (near back-references, no memory round trip), from
-//      another lane of the same pass (source inside this pass), or from HBM
-//      (far back-references).  Overlapping copies (offset < length) index
-//      the pattern with a per-lane modulo, so they never depend on
-//      themselves.  Stores are 64 contiguous bytes per pass.
+//   k_decompress_streams3 (+ _many)   one wavefront per stream, the default.
+//       decode_windows3 (third generation): 256 compressed bytes per window;
+//       the lanes look at tag bytes only to find the element starts (four
+//       rounds of pointer jumping per 64-byte group), the starts are
+//       compacted so that lane t holds the t-th ELEMENT of the window, which
+//       is then decoded, checked and placed (DPP scan) per lane; elements
+//       whose source is complete are copied in one lane-parallel step of
+//       whole 16-byte pieces (lane order of one DS instruction resolves the
+//       overlaps), far sources requested for the whole window at once; the
+//       elements that read the window's own output follow one by one, by
+//       the whole wave.  A 4 KiB ring of recent output lives in LDS, the
+//       ring goes to HBM 256 bytes at a time.  The last 337 bytes of a
+//       stream are decode_windows2's (second generation: 64-byte windows, an
+//       element per lane that sits on its first byte), which is also
+//       k_decompress_streams2, the cross-check of the test build.
+//   k_decompress_tiny / _small   streams of under 256 / 512 compressed bytes
+//       whose output is no larger: one per LANE (64 / 32 per wavefront),
+//       input and output staged in LDS, the reference's loop per lane.
+//   k_decompress_sequential   the reference's loop, one element at a time:
+//       what names every error (any failed check of the wide paths hands the
+//       stream over), and the fallback of a device that fails the LDS
+//       store-order self-check.
+//   k_stream_* / k_long_plan + k_bstream_*   ONE long stream on many
+//       wavefronts: (exit, produced) per segment and entry offset by walks
+//       that hop through LDS (scan), two levels above, one short sequential
+//       pass, the element boundaries at every 64 KiB of output (cuts), and
+//       the pieces between them through k_decompress_streams3; the same for
+//       the long streams of a small batch.
 //
-// A far back-reference may only read output whose stores have completed; one
-// watermark tracks that, and the wave drains its stores (workgroup-scope
-// fence = s_waitcnt vmcnt(0) on gfx950) at most once per ring length.
-//
-// Anything irregular -- a failed check, a literal longer than 64 bytes --
-// leaves the wide path: long literals are copied 1 KiB per instruction, and
-// on the first failed check the stream is finished by the sequential decoder
-// below, which is a direct restatement of the reference's loop and produces
-// the exact snap::Error variant and field values.
+// DESIGN.md section 4.2 has the history (byte-per-lane kernel of round 1,
+// gone; 354 -> 16 ms at cfg2) and what bounds each of them.
 #include "snapmi_device.hpp"
 #include "snapmi_kernels.hpp"
 
