@@ -257,8 +257,7 @@ void snapmi_ctx_destroy(snapmi_ctx *ctx)
                       &ctx->order, &ctx->fr_tables, &ctx->fr_desc,
                       &ctx->fr_meta, &ctx->fr_scan, &ctx->fr_slots,
                       &ctx->fr_chunk_off,
-                      &ctx->tokens, &ctx->ntok, &ctx->stream_bad,
-                      &ctx->lane_tables,
+                      &ctx->tokens, &ctx->ntok, &ctx->lane_tables,
                       &ctx->lane_epochs, &ctx->sd_tables, &ctx->sd_desc,
                       &ctx->bl_modes, &ctx->bl_list, &ctx->bl_descs,
                       &ctx->bl_order})
@@ -316,8 +315,6 @@ int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value)
         ctx->lane_table_budget_pct = (uint32_t)value;
     else if (strcmp(name, "window_tokens") == 0 && value >= 0 && value <= 1)
         ctx->window_tokens = (int)value;
-    else if (strcmp(name, "literal_kernel") == 0 && value >= 0 && value <= 1)
-        ctx->literal_kernel = (int)value;
     else if (strcmp(name, "lane_coresident") == 0 && value >= 0 && value <= 1)
         ctx->lane_coresident = (int)value;
     else if (strcmp(name, "lane_coresident_min_blocks") == 0 && value >= 1)
@@ -648,8 +645,6 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     a.small_limit = (uint32_t)small_stream_limit(ctx);
     a.cls_lo = 0;
     a.cls_hi = kMaxBlock;
-    a.n_bad = nullptr;
-    a.only_bad = 0;
     // Small batches are latency-bound: the wavefront kernel finishes a block
     // in ~2 ms, a lane needs tens of ms.  Large batches are throughput-bound
     // and go to the lane-per-block kernel.
@@ -734,12 +729,6 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     const bool both_cores = lanes_mode && !waves_mode && !span_match &&
                             ctx->lds_order_ok && ctx->lane_coresident &&
                             nb_big >= ctx->lane_coresident_min_blocks;
-    // k_literal_blocks in front of the window kernel: where the token path was
-    // chosen for data that does not compress (the hint, or match_kernel 1),
-    // blocks without a match are proved to be one literal and written at
-    // once; the window kernel and the encoder take what is left
-    const bool literal_first = lanes_mode && span_match && !win_tok &&
-                               !waves_mode && direct && ctx->literal_kernel;
     if (lanes_mode && span_match) {
         if ((rc = reserve(ctx, ctx->tokens, (size_t)seg_blocks * kMaxTokens *
                                                 sizeof(uint64_t))) ||
@@ -747,11 +736,6 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
             return rc;
         a.tokens = (unsigned long long *)ctx->tokens.p;
         a.ntok = (uint32_t *)ctx->ntok.p;
-        if (literal_first) {
-            if ((rc = reserve(ctx, ctx->stream_bad, 64)))
-                return rc;
-            a.n_bad = (uint32_t *)ctx->stream_bad.p;
-        }
     } else if (lanes_mode) {
         // waves of the lane-per-block match finder: a few per CU saturate
         // the random-access rate of HBM; never more lanes than blocks
@@ -1081,18 +1065,6 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                 } else if (span_match) {
                     const uint64_t mine =
                         use_small && nb_big < mid - lo ? nb_big : mid - lo;
-                    if (literal_first) {
-                        // thirty-two wavefronts per CU, a block each
-                        HIP_TRY(ctx, hipMemsetAsync(a.n_bad, 0, 64, s));
-                        const uint64_t wl = (mine + kLitWaves - 1) / kLitWaves;
-                        const uint64_t room = 8 * (uint64_t)ctx->num_cus;
-                        hipLaunchKernelGGL(
-                            k_literal_blocks,
-                            dim3((uint32_t)(wl < room ? wl : room)),
-                            dim3(kLitWaves * 64), 0, s, a);
-                        HIP_TRY(ctx, hipMemsetAsync(ctx->ticket.p, 0, 64, s));
-                        a.only_bad = 1;
-                    }
                     const uint64_t want =
                         (mine + kCompressWaves - 1) / kCompressWaves;
                     hipLaunchKernelGGL(
@@ -1100,7 +1072,6 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                         dim3((uint32_t)(want < (uint64_t)ctx->num_cus
                                             ? want : ctx->num_cus)),
                         dim3(kCompressWaves * 64), 0, s, a);
-                    a.only_bad = 0;
                 } else if (both_cores)
                     hipLaunchKernelGGL(k_match_both, dim3(ctx->num_cus),
                                        dim3(kBothWaves * 64), 0, s, a);

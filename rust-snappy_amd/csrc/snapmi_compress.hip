@@ -1124,9 +1124,6 @@ __device__ __forceinline__ void compress_one_block_span(
     __attribute__((address_space(3))) uint8_t *lblock = nullptr,
     const uint32_t tcap = kMaxTable)
 {
-    if (kTok && a.only_bad && uni(a.ntok[b]) != 0)
-        return; // k_literal_blocks has proved this block to be one literal
-
     // stream lookup: blk_first[st] <= b < blk_first[st + 1]
     uint32_t lo_s = 0, hi_s = a.n_streams;
     while (hi_s - lo_s > 1) {
@@ -1498,8 +1495,6 @@ __global__ __launch_bounds__(kCompressWaves * 64) void k_match_spans(
     uint16_t tables[kCompressWaves][kMaxTable];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = uni(threadIdx.x >> 6);
-    if (a.only_bad && uni(*a.n_bad) == 0)
-        return; // behind k_literal_blocks: nothing was left to do
     const lptr16 table = (lptr16)&tables[wave][0];
     const uint32_t tbase = (uint32_t)(uintptr_t)table;
     uint32_t nblocks = a.blk_first[a.n_streams];
@@ -1543,149 +1538,6 @@ __global__ __launch_bounds__(kSmallTableWaves * 64) void k_match_spans_8k(
         compress_one_block_span<false, true>(a, b, lane, table, tbase,
                                              nullptr, kEntries);
         b = a.blk_lo + uni(next_front_ticket(a.ticket, lane));
-    }
-}
-
-// ---------------------------------------------------------------------
-// k_literal_blocks (round 5): blocks that do not compress without the match
-// pass over them.
-//
-// A block without a single match is ONE literal, and that can be proved
-// without the reference's table: its probes (positions 1 + kDelta.d[i], ~266
-// of them in 64 KiB: src/compress.rs:204-216) all miss iff no probe's four
-// bytes equal the four bytes at its candidate - the latest earlier probe with
-// the same hash, or position 0 while the slot is still empty.  Which probes
-// have an earlier one with their hash says a BITMAP of the table's slots (2 KiB
-// of LDS where the table is 32: one lane-ordered ds_mskor_rtn per 64 probes);
-// the few that do (two per block of random bytes) look their predecessor up
-// among the probes' hashes, which stay in LDS.  So a wavefront needs 4.7 KiB,
-// thirty-two of them fit a CU, and a block costs them the ~270 dwords its
-// probes touch instead of a pass over all of it: the block gets its one token
-// (ntok 1) and k_encode_tokens copies it into place.  A block with a probe
-// that hits is left (ntok 0) to k_match_spans behind this kernel (only_bad):
-// exact for any data; run where the token path was chosen for data that did
-// not compress last time (match_kernel 2) or by option.  (A first version
-// also wrote the literal, at the place it has if the blocks in front of it
-// are literals too, and redid every stream with one block that is not - and
-// every tile of fireworks.jpeg has one: its first.)
-// ---------------------------------------------------------------------
-constexpr uint32_t kLitProbes = 448;   // >= the probes of a 64 KiB block
-__global__ __launch_bounds__(kLitWaves * 64)
-    __attribute__((amdgpu_waves_per_eu(8, 8))) void k_literal_blocks(
-        CompressArgs a)
-{
-    __shared__ __attribute__((aligned(16))) uint32_t bitmap_mem[kLitWaves][512];
-    __shared__ uint32_t vals_mem[kLitWaves][kLitProbes];
-    __shared__ uint16_t hash_mem[kLitWaves][kLitProbes];
-    typedef __attribute__((address_space(3))) uint32_t l_u32;
-    typedef __attribute__((address_space(3))) uint16_t l_u16;
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = uni(threadIdx.x >> 6);
-    l_u32 *const bitmap = (l_u32 *)&bitmap_mem[wave][0];
-    l_u32 *const vals = (l_u32 *)&vals_mem[wave][0];
-    l_u16 *const hashes = (l_u16 *)&hash_mem[wave][0];
-    const uint32_t bm_base = (uint32_t)(uintptr_t)bitmap;
-    uint32_t nblocks = a.blk_first[a.n_streams];
-    if (nblocks > a.host_blocks)
-        nblocks = a.host_blocks;
-    if (nblocks > a.blk_hi)
-        nblocks = a.blk_hi;
-    for (;;) {
-        const uint32_t b = a.blk_lo + uni(next_front_ticket(a.ticket, lane));
-        if (b >= nblocks)
-            return;
-        // stream lookup: blk_first[st] <= b < blk_first[st + 1]
-        uint32_t lo_s = 0, hi_s = a.n_streams;
-        while (hi_s - lo_s > 1) {
-            const uint32_t mid = (lo_s + hi_s) >> 1;
-            if (a.blk_first[mid] <= b)
-                lo_s = mid;
-            else
-                hi_s = mid;
-        }
-        const uint32_t st = lo_s;
-        const uint32_t first = a.blk_first[st];
-        const uint32_t k = b - first;
-        const uint64_t total = a.in_lens[st];
-        const uint64_t nb = (total + kMaxBlock - 1) / kMaxBlock;
-        if (first + nb > a.host_blocks)
-            continue; // rejected by k_plan_compress (E_ARGUMENT)
-        const uint64_t boff = (uint64_t)k * kMaxBlock;
-        gcptr src = (gcptr)a.in_ptrs[st] + boff;
-        const uint32_t n =
-            total - boff < kMaxBlock ? (uint32_t)(total - boff) : kMaxBlock;
-        bool hit = false;
-        if (n >= kMinNonLiteral) {
-            uint32_t shift = 32 - 8, tsize = 256;
-            while (tsize < kMaxTable && tsize < n) {
-                shift--;
-                tsize *= 2;
-            }
-            for (uint32_t i = lane; i < tsize / 32; i += kWave)
-                bitmap[i] = 0;
-            __builtin_amdgcn_wave_barrier();
-            const uint32_t s_limit = n - kInputMargin;
-            const uint32_t v0 = ld32u(src); // what an empty slot points at
-            for (uint32_t q = 0; q < kLitProbes && !hit; q += kWave) {
-                const uint32_t i = q + lane;
-                const uint32_t p = 1 + kDelta.d[i < 446 ? i : 446];
-                const uint32_t nextp = 1 + kDelta.d[i < 446 ? i + 1 : 447];
-                const bool valid = i < 446 && nextp <= s_limit;
-                const uint32_t v = valid ? ld32u(src + p) : 0;
-                const uint32_t h = hash32(v, shift);
-                bool seen = false;
-                if (valid) {
-                    const uint32_t bit = 1u << (h & 31);
-                    // (mask 0: an OR that returns the old word, the lanes of
-                    // one slot in ascending order - probe order)
-                    seen = (lds_mskor_rtn(bm_base + (h >> 5) * 4, 0, bit) &
-                            bit) != 0;
-                    vals[i] = v;
-                    hashes[i] = (uint16_t)h;
-                }
-                __builtin_amdgcn_wave_barrier();
-                // candidate 0: the slot was empty
-                hit = __builtin_amdgcn_ballot_w64(valid && !seen && v == v0) !=
-                      0;
-                // the probes with a predecessor: the latest earlier probe of
-                // their hash, and whether its four bytes are theirs
-                uint64_t M = __builtin_amdgcn_ballot_w64(seen);
-                while (M && !hit) {
-                    const uint32_t c = (uint32_t)__builtin_ctzll(M);
-                    M &= M - 1;
-                    const uint32_t ic = q + c;
-                    const uint32_t hc = rdlane(h, c), vc = rdlane(v, c);
-                    uint32_t best = 0; // index + 1 of the latest one
-                    for (uint32_t j = lane; j < ic; j += kWave)
-                        if (hashes[j] == (uint16_t)hc)
-                            best = j + 1;
-                    // wave maximum
-                    for (uint32_t w = 32; w; w >>= 1) {
-                        const uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute(
-                            (int)(((lane ^ w) & 63) << 2), (int)best);
-                        best = o > best ? o : best;
-                    }
-                    best = uni(best);
-                    hit = best != 0 && uni(vals[best - 1]) == vc;
-                }
-                if (__builtin_amdgcn_ballot_w64(!valid) != 0)
-                    break; // the schedule has reached the block's limit
-            }
-        }
-        if (lane == 0) {
-            if (hit) {
-                a.ntok[b] = 0; // k_match_spans' (only_bad)
-                atomicAdd(a.n_bad, 1u);
-            } else {
-                // one literal: src/compress.rs:417-474
-                typedef __attribute__((address_space(1))) unsigned long long
-                    g_u64;
-                ((g_u64 *)a.tokens)[(uint64_t)(b - a.tok_base) * kMaxTokens] =
-                    (unsigned long long)n;
-                a.ntok[b] = 1;
-                a.blk_size[b] = token_bytes(n, 0, 0);
-            }
-        }
     }
 }
 

@@ -49,7 +49,6 @@ struct snapmi_ctx {
     snapmi::DevBuf blk_first, slot_first, blk_size, blk_off, slots, plan_part;
     // lane-per-block match finder: tokens, token counts, HBM hash tables
     snapmi::DevBuf tokens, ntok, lane_tables, lane_epochs;
-    snapmi::DevBuf stream_bad; // k_literal_blocks: the count of blocks it left
     uint32_t n_lanes = 0;
     uint64_t lane_stride = 0;      // 16-byte entries between two lanes' tables
     bool lane_table_spread = true; // spread the tables over free memory
@@ -65,9 +64,6 @@ struct snapmi_ctx {
     // scratch).  Measured equal within 3 % either way on 64 MiB .. 1 GiB
     // (profiles/r5_span_sweep.txt), so the path without scratch is the default
     int window_tokens = 0;
-    // 1: where the window kernel is the token path's match finder for data
-    // that does not compress (match_kernel), k_literal_blocks runs first
-    int literal_kernel = 1;
     // 1: lane-kernel launches of at least lane_coresident_min_blocks blocks
     // run k_match_both - three lane wavefronts and two window wavefronts on
     // every CU, one two-ended ticket

@@ -55,12 +55,6 @@ struct CompressArgs {
     // are as small as the reference makes them for such blocks
     // (src/compress.rs:491-518), twice as many per CU.
     uint32_t cls_lo, cls_hi;
-    // k_literal_blocks (round 5) leaves ntok[b] = 1 and the token of the
-    // blocks it proved to be one literal, ntok[b] = 0 for the others and their
-    // count in *n_bad; only_bad: this launch of k_match_spans takes the
-    // blocks with ntok 0 alone (and leaves at once when there are none)
-    uint32_t *n_bad;
-    uint32_t only_bad;
 };
 
 // wavefronts (= hash tables) per persistent compress workgroup: 5 x 32 KiB
@@ -70,8 +64,6 @@ constexpr uint32_t kCompressWaves = 5;
 constexpr uint32_t kSmallTableWaves = 10;
 // k_match_both: wavefronts per CU, and how many of them are the lane kernel's
 constexpr uint32_t kBothWaves = 6, kBothLaneWaves = 4;
-// k_literal_blocks: wavefronts per workgroup (4.7 KiB of LDS each)
-constexpr uint32_t kLitWaves = 4;
 // token slots per block: at most 16385 tokens (every token but the last ends
 // in a copy of >= 4 bytes), rounded up to whole 128-byte groups of 16 so a
 // lane can write its tokens a full cache line at a time
@@ -127,8 +119,7 @@ __global__ void k_compress_small1k(CompressArgs a);  // [512, 1024)
 __global__ void k_compress_small2k(CompressArgs a);  // [1024, 2048)
 __global__ void k_match_blocks(CompressArgs a);
 __global__ void k_match_blocks_spec(CompressArgs a); // launches with blocks <= lanes
-__global__ void k_match_both(CompressArgs a); // 4 lane + 2 window wavefronts per CU
-__global__ void k_literal_blocks(CompressArgs a); // blocks without a match: proved and copied
+__global__ void k_match_both(CompressArgs a); // 3 lane + 2 window wavefronts per CU
 __global__ void k_encode_tokens(CompressArgs a);
 __global__ void k_scan_sizes(CompressArgs a);
 __global__ void k_compact(CompressArgs a);

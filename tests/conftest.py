@@ -48,7 +48,7 @@ def ctx(request, built):
                 params=["spans", "spans_lds", "waves", "waves_lds", "lanes",
                         "lanes_segmented", "lanes_overlap", "both",
                         "spans_match", "small_tables", "small_tables_lanes",
-                        "coresident", "literal_first"])
+                        "coresident"])
 def cctx(request, built):
     """A context per compressor kernel: the wavefront-per-block kernels (window
     steps and, as the cross-check, one copy per step; five tables per CU and
@@ -73,8 +73,7 @@ def cctx(request, built):
                                    "lanes_segmented": 1, "lanes_overlap": 1,
                                    "both": 2, "spans_match": 1,
                                    "small_tables": 1,
-                                   "small_tables_lanes": 1, "coresident": 1,
-                                   "literal_first": 1}[
+                                   "small_tables_lanes": 1, "coresident": 1}[
         request.param])
     # three lane wavefronts and two window wavefronts per CU on one two-ended
     # ticket (k_match_both), however few blocks there are
@@ -86,13 +85,7 @@ def cctx(request, built):
     # the token path's match finder: the lane kernel in the "lanes*"
     # configurations whatever the last batch compressed to (the default picks
     # by that), the window kernel (k_match_spans) in "spans_match"
-    c.set_option("match_kernel",
-                 1 if request.param in ("spans_match", "literal_first") else 0)
-    # k_literal_blocks in front of the window kernel: blocks without a match
-    # are proved to be one literal and written at once, every stream with a
-    # block that has one goes on to k_match_spans + k_encode_tokens
-    # ("spans_match" keeps the window kernel alone)
-    c.set_option("literal_kernel", 1 if request.param == "literal_first" else 0)
+    c.set_option("match_kernel", 1 if request.param == "spans_match" else 0)
     # spans / waves: five tables per CU, input from L2; *_lds: one block per
     # CU, table and input block in LDS (the kernel of the smallest batches).
     # spans*: a window of 63 positions per step (k_compress_spans, the
