@@ -97,6 +97,12 @@ typedef struct snapmi_error {
     uint64_t a, b, c;
 } snapmi_error;
 
+/* impl fmt::Display for snap::Error (reference src/error.rs:249-335): the
+ * text the reference prints for this error - "snappy: corrupt input (expected
+ * copy write of length 11; remaining dst: 4)" - into buf (NUL-terminated,
+ * truncated to cap).  Returns the length the whole text has.  Host code. */
+size_t snapmi_error_string(const snapmi_error *err, char *buf, size_t cap);
+
 /* ------------------------------------------------------------------ */
 /* Context: one HIP device + stream + device scratch.  Maps to          */
 /* snap::raw::Encoder (exclusive &mut self, owns its scratch table --   */

@@ -49,6 +49,7 @@ SYMBOLS = [
     ("snapmi_last_error", C.c_char_p, [_P]),
     ("snapmi_table_probe_log", C.c_char_p, [_P]),
     ("snapmi_last_kernel", C.c_char_p, [_P]),
+    ("snapmi_error_string", _SZ, [_ERRP, C.c_char_p, _SZ]),
     ("snapmi_host_alloc", _P, [_SZ]),
     ("snapmi_host_free", None, [_P]),
     ("snapmi_ctx_stream", _P, [_P]),

@@ -446,6 +446,121 @@ const char *snapmi_table_probe_log(const snapmi_ctx *ctx)
     return ctx ? ctx->probe_log.c_str() : "";
 }
 
+size_t snapmi_error_string(const snapmi_error *e, char *buf, size_t cap)
+{
+    // reference src/error.rs:249-335, variant by variant
+    char tmp[256];
+    const unsigned long long a = e ? e->a : 0, b = e ? e->b : 0,
+                             c = e ? e->c : 0;
+    int n = 0;
+    switch (e ? e->kind : -1) {
+    case SNAPMI_TOO_BIG:
+        n = snprintf(tmp, sizeof tmp,
+                     "snappy: input buffer (size = %llu) is larger than "
+                     "allowed (size = %llu)", a, b);
+        break;
+    case SNAPMI_BUFFER_TOO_SMALL:
+        n = snprintf(tmp, sizeof tmp,
+                     "snappy: output buffer (size = %llu) is smaller than "
+                     "required (size = %llu)", a, b);
+        break;
+    case SNAPMI_EMPTY:
+        n = snprintf(tmp, sizeof tmp, "snappy: corrupt input (empty)");
+        break;
+    case SNAPMI_HEADER:
+        n = snprintf(tmp, sizeof tmp,
+                     "snappy: corrupt input (invalid header)");
+        break;
+    case SNAPMI_HEADER_MISMATCH:
+        n = snprintf(tmp, sizeof tmp,
+                     "snappy: corrupt input (header mismatch; expected %llu "
+                     "decompressed bytes but got %llu)", a, b);
+        break;
+    case SNAPMI_LITERAL:
+        n = snprintf(tmp, sizeof tmp,
+                     "snappy: corrupt input (expected literal read of length "
+                     "%llu; remaining src: %llu; remaining dst: %llu)", a, b,
+                     c);
+        break;
+    case SNAPMI_COPY_READ:
+        n = snprintf(tmp, sizeof tmp,
+                     "snappy: corrupt input (expected copy read of length "
+                     "%llu; remaining src: %llu)", a, b);
+        break;
+    case SNAPMI_COPY_WRITE:
+        n = snprintf(tmp, sizeof tmp,
+                     "snappy: corrupt input (expected copy write of length "
+                     "%llu; remaining dst: %llu)", a, b);
+        break;
+    case SNAPMI_OFFSET:
+        n = snprintf(tmp, sizeof tmp,
+                     "snappy: corrupt input (expected valid offset but got "
+                     "offset %llu; dst position: %llu)", a, b);
+        break;
+    case SNAPMI_STREAM_HEADER:
+        n = snprintf(tmp, sizeof tmp,
+                     "snappy: corrupt input (expected stream header but got "
+                     "unexpected chunk type byte %llu)", a);
+        break;
+    case SNAPMI_STREAM_HEADER_MISMATCH: {
+        // (six bytes, little-endian in `a`; std::ascii::escape_default)
+        char esc[6 * 4 + 1];
+        int k = 0;
+        for (int i = 0; i < 6; i++) {
+            const unsigned ch = (unsigned)(a >> (8 * i)) & 0xFF;
+            if (ch == 9 || ch == 10 || ch == 13) {
+                esc[k++] = '\\';
+                esc[k++] = ch == 9 ? 't' : (ch == 10 ? 'n' : 'r');
+            } else if (ch == 39 || ch == 34 || ch == 92) {
+                esc[k++] = '\\';
+                esc[k++] = (char)ch;
+            } else if (ch >= 0x20 && ch <= 0x7E) {
+                esc[k++] = (char)ch;
+            } else {
+                k += snprintf(esc + k, 5, "\\x%02x", ch);
+            }
+        }
+        esc[k] = 0;
+        n = snprintf(tmp, sizeof tmp,
+                     "snappy: corrupt input (expected sNaPpY stream header "
+                     "but got %s)", esc);
+        break;
+    }
+    case SNAPMI_UNSUPPORTED_CHUNK_TYPE:
+        n = snprintf(tmp, sizeof tmp,
+                     "snappy: corrupt input (unsupported chunk type: %llu)",
+                     a);
+        break;
+    case SNAPMI_UNSUPPORTED_CHUNK_LENGTH:
+        n = snprintf(tmp, sizeof tmp,
+                     b ? "snappy: corrupt input (invalid stream header "
+                         "length: %llu)"
+                       : "snappy: corrupt input (unsupported chunk length: "
+                         "%llu)", a);
+        break;
+    case SNAPMI_CHECKSUM:
+        n = snprintf(tmp, sizeof tmp,
+                     "snappy: corrupt input (bad checksum; expected: %llu, "
+                     "got: %llu)", a, b);
+        break;
+    case SNAPMI_E_UNEXPECTED_EOF: // (io::ErrorKind::UnexpectedEof)
+        n = snprintf(tmp, sizeof tmp, "unexpected end of file");
+        break;
+    case SNAPMI_OK:
+        n = snprintf(tmp, sizeof tmp, "ok");
+        break;
+    default:
+        n = snprintf(tmp, sizeof tmp, "snapmi: device or argument error %d",
+                     e ? e->kind : -1);
+    }
+    if (buf && cap) {
+        const size_t m = (size_t)n < cap - 1 ? (size_t)n : cap - 1;
+        memcpy(buf, tmp, m);
+        buf[m] = 0;
+    }
+    return (size_t)n;
+}
+
 const char *snapmi_last_kernel(const snapmi_ctx *ctx)
 {
     return ctx ? ctx->last_kernel : "";

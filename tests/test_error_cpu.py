@@ -45,8 +45,19 @@ def test_display_is_the_references_text():
         (E(14, 1, 2),
          "snappy: corrupt input (bad checksum; expected: 1, got: 2)"),
     ]
+    import ctypes as C
+    from rust_snappy_amd import _lib
+    L = _lib.load()
     for e, want in cases:
         assert str(e) == want, (e.variant, str(e))
+        # ... and the C ABI's snapmi_error_string (what tools/szip prints)
+        rec = _lib.SnapmiError(e.kind, 0, *e.abc)
+        buf = C.create_string_buffer(256)
+        n = L.snapmi_error_string(C.byref(rec), buf, 256)
+        assert buf.value.decode() == want and n == len(want), buf.value
+        short = C.create_string_buffer(10)
+        assert L.snapmi_error_string(C.byref(rec), short, 10) == len(want)
+        assert short.value.decode() == want[:9]
 
 
 def test_debug_form_and_equality():

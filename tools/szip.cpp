@@ -120,19 +120,6 @@ template <class T> class Queue {
     }
 };
 
-const char *kind_name(int k)
-{
-    static const char *names[] = {
-        "Ok", "TooBig", "BufferTooSmall", "Empty", "Header", "HeaderMismatch",
-        "Literal", "CopyRead", "CopyWrite", "Offset", "StreamHeader",
-        "StreamHeaderMismatch", "UnsupportedChunkType",
-        "UnsupportedChunkLength", "Checksum"};
-    if (k >= 0 && k <= 14)
-        return names[k];
-    return k == SNAPMI_E_UNEXPECTED_EOF ? "UnexpectedEof"
-                                        : (k >= 100 ? "Device" : "?");
-}
-
 size_t read_full(FILE *f, uint8_t *p, size_t n)
 {
     size_t got = 0;
@@ -182,10 +169,12 @@ int run_stream(const Options &opt, FILE *src, FILE *dst, const char *name)
             if (rc == SNAPMI_OK)
                 fwrite(out.data(), 1, n, dst);
         }
-        if (rc != SNAPMI_OK)
-            fprintf(stderr, "szip: %s: %s { %llu, %llu, %llu }\n", name,
-                    kind_name(rc), (unsigned long long)e.a,
-                    (unsigned long long)e.b, (unsigned long long)e.c);
+        if (rc != SNAPMI_OK) { // the reference's text (src/error.rs:249-335)
+            char text[256];
+            e.kind = rc;
+            snapmi_error_string(&e, text, sizeof text);
+            fprintf(stderr, "szip: %s: %s\n", name, text);
+        }
         snapmi_ctx_destroy(ctx);
         return rc != SNAPMI_OK;
     }
@@ -277,13 +266,13 @@ int run_stream(const Options &opt, FILE *src, FILE *dst, const char *name)
                         if (k->rc >= 100)
                             fprintf(stderr, "szip: %s: %s\n", name,
                                     k->msg.c_str());
-                        else
-                            fprintf(stderr,
-                                    "szip: %s: %s { %llu, %llu, %llu }\n",
-                                    name, kind_name(k->rc),
-                                    (unsigned long long)k->err.a,
-                                    (unsigned long long)k->err.b,
-                                    (unsigned long long)k->err.c);
+                        else {
+                            char text[256];
+                            snapmi_error e = k->err;
+                            e.kind = k->rc;
+                            snapmi_error_string(&e, text, sizeof text);
+                            fprintf(stderr, "szip: %s: %s\n", name, text);
+                        }
                         failed = true;
                     }
                 }
