@@ -543,8 +543,10 @@ size_t snapmi_error_string(const snapmi_error *e, char *buf, size_t cap)
                      "snappy: corrupt input (bad checksum; expected: %llu, "
                      "got: %llu)", a, b);
         break;
-    case SNAPMI_E_UNEXPECTED_EOF: // (io::ErrorKind::UnexpectedEof)
-        n = snprintf(tmp, sizeof tmp, "unexpected end of file");
+    case SNAPMI_E_UNEXPECTED_EOF:
+        // (not a snap::Error: the io::Error of read_exact that the
+        // reference's reader passes on, src/read.rs:105-172 - std's text)
+        n = snprintf(tmp, sizeof tmp, "failed to fill whole buffer");
         break;
     case SNAPMI_OK:
         n = snprintf(tmp, sizeof tmp, "ok");
