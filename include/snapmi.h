@@ -187,7 +187,8 @@ const char *snapmi_version(void);
  *                          tables - and, while a placement is being chosen,
  *                          its candidates together - may hold (default 33,
  *                          1..90).  A host that owns the GPU raises it: the
- *                          tables then spread further (bench.py: 75)
+ *                          tables then spread further (it buys nothing
+ *                          measurable: bench.py runs on the default)
  *   "lane_table_tries"     placements of the lane tables that are timed
  *                          (k_probe_tables, 3 ms each) before the fastest is
  *                          kept - at most this many (default 10), fewer when
