@@ -756,7 +756,8 @@ def main():
                     :200]
         if not traffic_measured:
             pmc_name = None
-            for cand in ("r4_pmc_traffic.json", "r3_pmc_traffic.json"):
+            for cand in ("r5_pmc_traffic.json", "r4_pmc_traffic.json",
+                         "r3_pmc_traffic.json"):
                 if (ROOT / "profiles" / cand).exists():
                     pmc_name = cand
                     break
