@@ -63,7 +63,12 @@ constexpr uint32_t kCompressWaves = 5;
 // ... of the window kernel for blocks of at most 8 KiB (16 KiB tables)
 constexpr uint32_t kSmallTableWaves = 10;
 // k_match_both: wavefronts per CU, and how many of them are the lane kernel's
-constexpr uint32_t kBothWaves = 6, kBothLaneWaves = 4;
+#ifndef SNAPMI_BOTH_WAVES
+#define SNAPMI_BOTH_WAVES 6
+#define SNAPMI_BOTH_LANE_WAVES 4
+#endif
+constexpr uint32_t kBothWaves = SNAPMI_BOTH_WAVES,
+                   kBothLaneWaves = SNAPMI_BOTH_LANE_WAVES;
 // token slots per block: at most 16385 tokens (every token but the last ends
 // in a copy of >= 4 bytes), rounded up to whole 128-byte groups of 16 so a
 // lane can write its tokens a full cache line at a time

@@ -37,9 +37,10 @@ def round_batch(gib):
     return src, comp, clens, pos
 
 
-for gib in (4.0, 8.0):
+for gib in (8.0,):
     src, comp, clens, n = round_batch(gib)
-    row = f"round {gib:4.1f} GiB:"
+    import os
+    row = f"{os.path.basename(os.environ.get('SNAPMI_LIB', 'default')):14s} round {gib:4.1f} GiB:"
     for label, on in (("lanes", 0), ("both", 1), ("lanes", 0), ("both", 1)):
         ctx = raw.Context(0)
         ctx.set_option("lane_coresident", on)
