@@ -431,6 +431,12 @@ __device__ __forceinline__ void compress_one_block(
 
     // stream lookup: blk_first[st] <= b < blk_first[st + 1]
     uint32_t lo = 0, hi = a.n_streams;
+    // (a batch of one-block streams - pages, frame chunks: block b IS
+    // stream b, and two loads say so instead of log2(n) dependent ones)
+    if (b < a.n_streams && a.blk_first[b] == b && a.blk_first[b + 1] > b) {
+        lo = b;
+        hi = b + 1;
+    }
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
         if (a.blk_first[mid] <= b)
@@ -1126,6 +1132,12 @@ __device__ __forceinline__ void compress_one_block_span(
 {
     // stream lookup: blk_first[st] <= b < blk_first[st + 1]
     uint32_t lo_s = 0, hi_s = a.n_streams;
+    // (a batch of one-block streams - pages, frame chunks: block b IS
+    // stream b, and two loads say so instead of log2(n) dependent ones)
+    if (b < a.n_streams && a.blk_first[b] == b && a.blk_first[b + 1] > b) {
+        lo_s = b;
+        hi_s = b + 1;
+    }
     while (hi_s - lo_s > 1) {
         const uint32_t mid = (lo_s + hi_s) >> 1;
         if (a.blk_first[mid] <= b)
@@ -2015,6 +2027,12 @@ __device__ __forceinline__ void match_blocks(
             } else {
                 // stream lookup: blk_first[st] <= b < blk_first[st + 1]
                 uint32_t lo = 0, hi_st = a.n_streams;
+                // (a batch of one-block streams - pages, frame chunks: block b IS
+                // stream b, and two loads say so instead of log2(n) dependent ones)
+                if (b < a.n_streams && a.blk_first[b] == b && a.blk_first[b + 1] > b) {
+                    lo = b;
+                    hi_st = b + 1;
+                }
                 while (hi_st - lo > 1) {
                     const uint32_t mid = (lo + hi_st) >> 1;
                     if (a.blk_first[mid] <= b)
@@ -2426,6 +2444,12 @@ __global__ __launch_bounds__(64) void k_encode_tokens(CompressArgs a)
     if (a.ntok[b] == 0xFFFFFFFFu)
         return; // this block was encoded by k_compress_blocks
     uint32_t lo = 0, hi = a.n_streams;
+    // (a batch of one-block streams - pages, frame chunks: block b IS
+    // stream b, and two loads say so instead of log2(n) dependent ones)
+    if (b < a.n_streams && a.blk_first[b] == b && a.blk_first[b + 1] > b) {
+        lo = b;
+        hi = b + 1;
+    }
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
         if (a.blk_first[mid] <= b)
@@ -2820,6 +2844,12 @@ __global__ __launch_bounds__(256) void k_compact(CompressArgs a)
     if (b >= nblocks)
         return;
     uint32_t lo = 0, hi = a.n_streams;
+    // (a batch of one-block streams - pages, frame chunks: block b IS
+    // stream b, and two loads say so instead of log2(n) dependent ones)
+    if (b < a.n_streams && a.blk_first[b] == b && a.blk_first[b + 1] > b) {
+        lo = b;
+        hi = b + 1;
+    }
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
         if (a.blk_first[mid] <= b)
