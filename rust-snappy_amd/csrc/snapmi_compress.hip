@@ -1121,6 +1121,10 @@ struct WaveDev {
         const uint64_t x = mask & ((1ull << t) - 1);
         return x ? 63u - (u32)__builtin_clzll(x) : 64u;
     }
+    __device__ __forceinline__ u32 shr_lo(uint64_t mask, u32 i) const
+    {
+        return (u32)(mask >> i);
+    }
 };
 
 template <bool kLds, bool kTok = false>
@@ -1363,12 +1367,12 @@ __device__ __forceinline__ void compress_one_block_span(
             st.next_emit = sink.emit;
             // the fast walk (snapmi_span.hpp): the scalar unit follows the
             // chain of copies, the lanes derive everything else at once
-            bool fast = span_fast_ok(st, hits, n);
+            const WaveDev w{lane};
+            bool fast = span_fast_ok_w(w, st, hits, n);
             TICK(13);
             if (fast) {
                 // the lane-parallel walk (span_par_walk): the copies of the
                 // step by pointer jumping, everything else per lane
-                const WaveDev w{lane};
                 uint64_t vh;
                 uint32_t lit;
                 rc = span_par_walk(w, st, hits, ln.mv, old, cbit, sink.emit,

@@ -241,6 +241,7 @@ SNAPMI_LANE_FN bool span_fast_ok(const SpanState &st, const uint64_t hits,
 //   bit(mask, i)         bit i (per lane, 0..63) of a uniform mask
 //   next_bit(mask, t)    lowest set bit >= t (per lane, 0..63) or 64
 //   prev_bit(mask, t)    highest set bit < t (per lane, 0..63) or 64
+//   shr_lo(mask, i)      the low 32 bits of mask >> i (per lane, 0..63)
 //   count_cut()          a hook for the host test's statistics
 // snapmi_compress.hip instantiates it over the hardware, tests/
 // span_wave_host.cpp over arrays of 64 - the same text - and
@@ -252,6 +253,24 @@ SNAPMI_LANE_FN bool span_fast_ok(const SpanState &st, const uint64_t hits,
 #else
 #define SNAPMI_WAVE_FN inline
 #endif
+
+// span_fast_ok with its one expensive test - 32 lanes in a row without a hit,
+// ten 64-bit scalar shifts and ANDs - done by the lanes: lane L of 1..32 looks
+// at the 32 bits from its own (one 64-bit shift per lane, one ballot).
+template <class W>
+SNAPMI_WAVE_FN bool span_fast_ok_w(const W &w, const SpanState &st,
+                                   const uint64_t hits, const uint32_t n)
+{
+    typedef typename W::u32 u32;
+    const u32 lane = w.lane();
+    const uint64_t run32 = w.ballot(
+        w.band(w.band(w.ge(lane, u32(1)), w.lt(lane, u32(33))),
+               w.eq(w.shr_lo(hits, lane), u32(0))));
+    const uint64_t h1 = hits >> 1;
+    const uint32_t lead = h1 ? (uint32_t)__builtin_ctzll(h1) : 64;
+    const bool run_ok = (st.chain != 0) | (st.q + lead < kSpanRun);
+    return (st.s + 93 <= n) & (run32 == 0) & run_ok;
+}
 
 // hits (lanes 1..63, at least one: span_fast_ok) as for span_walk;
 // m, old, cbit: this lane's match length, exchanged entry and C bit.
@@ -281,9 +300,12 @@ span_par_walk(const W &w, SpanState &st, const uint64_t hits,
     // The copies of the step: the orbit of the first hit under J.  The scalar
     // unit hops through it - a v_readlane per copy whose wait states hold the
     // mask update and the exit test, ~20 cycles a hop, 9 hops on text - which
-    // beats four rounds of doubling over ds_bpermute (R |= R[frontier]: exact
-    // too, built first, 4 x ~140 cycles of LDS round trips for a lone
-    // wavefront).  At most 16 copies of 4 bytes or more fit a window.
+    // equals four rounds of doubling over ds_bpermute (R |= R[frontier]:
+    // exact too, built first) on text and beats them by 5 % where the windows
+    // hold fewer copies (HTML, URLs); for the small-block kernel, whose ten
+    // wavefronts per CU keep the scalar unit 70 % busy, the doubling rounds
+    // measured 2 % better at 8 KiB and nothing at 2-4 KiB: one method kept.
+    // At most 16 copies of 4 bytes or more fit a window.
     const u32 J = w.sel(go, nx, u32(64));
     uint64_t V = 0;
     uint32_t cur = 1 + (uint32_t)__builtin_ctzll(hits >> 1);

@@ -207,6 +207,16 @@ struct WaveHost {
         }
         return r;
     }
+    HV shr_lo(uint64_t mask, const HV &i) const
+    {
+        HV r;
+        for (int k = 0; k < 64; k++) {
+            if (i.v[k] > 63)
+                abort();
+            r.v[k] = (uint32_t)(mask >> i.v[k]);
+        }
+        return r;
+    }
     HV prev_bit(uint64_t mask, const HV &t) const
     {
         HV r;
@@ -219,6 +229,27 @@ struct WaveHost {
         return r;
     }
 };
+
+// span_par_walk (and span_fast_ok_w) over the host's wave
+uint32_t par_walk(SpanState &st, uint64_t hits, uint64_t cbits, const Lanes &ln,
+                  uint32_t &emit, uint64_t &vh, HV &lit, uint64_t &T,
+                  uint32_t &at, uint64_t &cuts, uint32_t n, bool *ok_w)
+{
+    WaveHost w;
+    HV m, old;
+    HB cb;
+    for (uint32_t l = 0; l < 64; l++) {
+        m.v[l] = ln.mv[l];
+        old.v[l] = ln.ov[l];
+        cb.v[l] = (cbits >> l) & 1;
+    }
+    if (ok_w)
+        *ok_w = span_fast_ok_w(w, st, hits, n);
+    const uint32_t rc =
+        span_par_walk(w, st, hits, m, old, cb, emit, vh, lit, T, at);
+    cuts = w.cuts;
+    return rc;
+}
 } // namespace
 
 // stats[0] window steps, [1] schedule steps, [2] cuts of fast steps, [3] long
@@ -343,20 +374,14 @@ extern "C" uint32_t span_wave_compress(const uint8_t *src, uint32_t n,
         // exact walk otherwise
         bool fast = span_fast_ok(st, hits, n);
         if (fast) {
-            WaveHost w;
-            HV m, old;
-            HB cb;
-            for (uint32_t l = 0; l < 64; l++) {
-                m.v[l] = ln.mv[l];
-                old.v[l] = ln.ov[l];
-                cb.v[l] = (cbits >> l) & 1;
-            }
-            uint64_t vh;
+            uint64_t vh, cuts = 0;
             HV lit;
             uint32_t emit = st.next_emit;
-            const uint32_t emit0 = emit;
-            rc = span_par_walk(w, st, hits, m, old, cb, emit, vh, lit, T, at);
-            (void)emit0;
+            bool ok_w = false;
+            rc = par_walk(st, hits, cbits, ln, emit, vh, lit, T, at, cuts, n,
+                          &ok_w);
+            if (!ok_w)
+                return 0x80000005u; // span_fast_ok_w disagrees
             stats[7]++;
             for (uint32_t l = 1; l < 64; l++) {
                 if (!((vh >> l) & 1))
@@ -366,10 +391,14 @@ extern "C" uint32_t span_wave_compress(const uint8_t *src, uint32_t n,
             }
             if (st.next_emit != emit)
                 return 0x80000003u;
-            stats[2] += w.cuts;
+            stats[2] += cuts;
         }
-        if (!fast)
+        if (!fast) {
+            WaveHost w0;
+            if (span_fast_ok_w(w0, st, hits, n))
+                return 0x80000005u;
             rc = span_walk(st, hits, cbits, s_limit, ln, sink, T, at);
+        }
         stats[5] += (uint64_t)__builtin_popcountll(T);
         stats[6] += sink.t.size() - tok0;
         for (uint32_t l = 0; l < 64; l++) {
@@ -475,19 +504,14 @@ extern "C" uint32_t span_walk_diff(uint32_t seed, uint32_t cases,
         uint32_t cutc = 0;
         {
             SpanState sc = st;
-            WaveHost w;
-            HV m, old;
-            HB cb;
-            for (uint32_t l = 0; l < 64; l++) {
-                m.v[l] = ln.mv[l];
-                old.v[l] = ln.ov[l];
-                cb.v[l] = (cbits >> l) & 1;
-            }
-            uint64_t vhc, Tc;
+            uint64_t vhc, Tc, cuts = 0;
             HV lit;
             uint32_t emitc = st.next_emit, atc = 0;
-            const uint32_t rcc = span_par_walk(w, sc, hits, m, old, cb, emitc,
-                                               vhc, lit, Tc, atc);
+            bool ok_w = false;
+            const uint32_t rcc = par_walk(sc, hits, cbits, ln, emitc, vhc, lit,
+                                          Tc, atc, cuts, n, &ok_w);
+            if (!ok_w)
+                return c;
             if (rcc != ra || Tc != Ta || sc.s != sa.s ||
                 sc.next_emit != sa.next_emit || emitc != sa.next_emit)
                 return c;
@@ -507,7 +531,7 @@ extern "C" uint32_t span_walk_diff(uint32_t seed, uint32_t cases,
             if (ra != kSpanLong &&
                 (sa.chain != sc.chain || (!sa.chain && sa.q != sc.q)))
                 return c;
-            cutc = (uint32_t)w.cuts;
+            cutc = (uint32_t)cuts;
         }
         seen[0]++;
         seen[1] += cutc;
