@@ -1,8 +1,9 @@
 """k_compress_spans (a window of 63 consecutive positions per wavefront step)
-on the CPU: tests/span_wave_host.cpp runs span_walk() of
-rust-snappy_amd/csrc/snapmi_span.hpp - the very text the kernel compiles - with
-the 64 lanes around it emulated in the order gfx950 applies the lanes of one DS
-instruction in, and the stream must be the oracle's: every length up to 300
+on the CPU: tests/span_wave_host.cpp runs the walks of
+rust-snappy_amd/csrc/snapmi_span.hpp - the very text the kernel compiles:
+span_walk() as it is, span_par_walk() and span_fast_ok_w() over arrays of 64
+lanes - with the 64 lanes around them emulated in the order gfx950 applies the
+lanes of one DS instruction in, and the stream must be the oracle's: every length up to 300
 over alphabets that make consecutive positions share table slots (runs, tiny
 alphabets: every C-bit case, cuts, deferred inserts), periodic data, blocks of
 every corpus file (long miss runs -> schedule steps, long matches), block-size
@@ -95,10 +96,12 @@ def test_span_steps_phrases_with_noise(span):
 
 
 def test_fast_walk_equals_the_exact_walk_on_random_windows(tmp_path):
-    """span_fast_* against span_walk on random per-lane results - hit
-    densities from sparse to every lane, match lengths of every class, C bits
-    with preds anywhere below, chain / run starts: inserted lanes, tokens and
-    the state left behind must be identical wherever the fast walk may run."""
+    """span_par_walk (the lane-parallel walk of round 5) against span_walk on
+    random per-lane results - hit densities from sparse to every lane, match
+    lengths of every class, C bits with preds anywhere below, chain / run
+    starts: inserted lanes, tokens and the state left behind must be identical
+    wherever the fast walk may run, and span_fast_ok_w must say so where
+    span_fast_ok does."""
     so = tmp_path / "span_wave_host.so"
     subprocess.check_call(
         ["g++", "-O2", "-shared", "-fPIC", "-std=c++17",
