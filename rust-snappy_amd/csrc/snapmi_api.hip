@@ -416,6 +416,10 @@ int snapmi_ctx_set_test_option(snapmi_ctx *ctx, const char *name,
     else if (strcmp(name, "stream_seg_log2") == 0 &&
              (value == 0 || value == 10 || value == 12))
         ctx->stream_seg_log2 = (uint32_t)value; // 0: by size
+    else if (strcmp(name, "stream_scan_segs") == 0 &&
+             (value == 0 || value == 8 || value == 16 || value == 32 ||
+              value == 64))
+        ctx->stream_scan_segs = (uint32_t)value; // 0: by size
     else if (strcmp(name, "lds_order_ok") == 0 && value >= 0 && value <= 1)
         ctx->lds_order_ok = ctx->lds_order_hw && value != 0; // can only lower
     else
@@ -1449,6 +1453,30 @@ static uint32_t stream_seg_log2(const snapmi_ctx *ctx, uint64_t long_bytes)
     return long_bytes < ((uint64_t)256 << 20) ? 10u : 12u;
 }
 
+// Segments per wavefront of k_stream_scan (StreamArgs::scan_segs) for a call
+// whose long streams hold `nseg` segments together: the kernel's full group of
+// 64 when that still makes kScanFill wavefronts, else halved until it does
+// (not below 8).  A scan wavefront of 64 segments of 1 KiB hands its 64 lanes
+// eight rounds of entry walks and then trunks of which the longest is three
+// to four times the average - ~1 100 hops of ~630 cycles, 280 us, whoever
+// else is on the chip - and 32 MiB of long streams are 506 such wavefronts,
+// two per CU.  Measured (profiles/r5_scan_groups.txt): 64 MiB of the corpus
+// round 1.359 -> 1.301 ms per call with 16 (8: 1.357 - the groups are a
+// second wave of workgroups then), one 126 MB stream as a batch of one 1.690
+// -> 1.585 with 32, Decoder::decompress of lcet10.txt 1.076 -> 0.993 with 8,
+// 256 MiB 1.622 with 64 and 1.702 with 32: hence 1 024.  (The cuts kernel's
+// 512 segments per wavefront were measured the same way: 64 .. 512 are equal,
+// its time is the one walk every lane has.)
+static uint32_t stream_scan_segs(const snapmi_ctx *ctx, uint64_t nseg)
+{
+    if (ctx->stream_scan_segs)
+        return ctx->stream_scan_segs;
+    uint32_t segs = kScanSegs;
+    while (segs > 8 && nseg / segs < kScanFill)
+        segs /= 2;
+    return segs;
+}
+
 // pinned host staging of a context (grow-only): pageable copies go through
 // the runtime's own staging buffer one at a time, process-wide - eight
 // threads calling snappy_compress would queue there
@@ -1539,10 +1567,12 @@ static int decompress_batch_long(snapmi_ctx *ctx,
         long_bytes += items[j].in_len;
     const uint32_t seg_log2 = stream_seg_log2(ctx, long_bytes);
     const uint64_t seg = 1ull << seg_log2;
+    const uint32_t scan_segs = stream_scan_segs(ctx, long_bytes / seg + L);
     for (uint32_t j = 0; j < L; j++) {
         StreamArgs &a = descs[j];
         memset(&a, 0, sizeof a);
         a.seg_log2 = seg_log2;
+        a.scan_segs = scan_segs;
         a.in = (const uint8_t *)items[j].in;
         a.in_len = items[j].in_len;
         a.out = (uint8_t *)items[j].out;
@@ -1556,7 +1586,7 @@ static int decompress_batch_long(snapmi_ctx *ctx,
         a.kmax = (uint32_t)(items[j].dlen / kStreamChunk + 2);
         uint32_t *pj = &pre[j];
         const size_t st = L + 1;
-        pj[kPScan * st] = (a.nseg + kWave - 1) / kWave;
+        pj[kPScan * st] = (a.nseg + scan_segs - 1) / scan_segs;
         pj[kPSuper * st] = a.nsuper;
         pj[kPSuper3 * st] = a.nsuper3;
         pj[kPSpread3 * st] = (a.nsuper3 + 63) / 64;
@@ -1802,6 +1832,7 @@ int snapmi_decompress_stream(snapmi_ctx *ctx, const void *d_in,
     a.err = d_err;
     a.nseg = (uint32_t)nseg64;
     a.seg_log2 = seg_log2;
+    a.scan_segs = stream_scan_segs(ctx, a.nseg);
     a.nsuper = (a.nseg + kSegPerSuper - 1) / kSegPerSuper;
     a.nsuper3 = (a.nsuper + kSegPerSuper - 1) / kSegPerSuper;
     a.kmax = (uint32_t)kmax64;
@@ -1870,8 +1901,9 @@ int snapmi_decompress_stream(snapmi_ctx *ctx, const void *d_in,
 
     hipLaunchKernelGGL(k_stream_head, dim3(1), dim3(1), 0, s, a);
     STREAM_CHECK(k_stream_head);
-    hipLaunchKernelGGL(k_stream_scan, dim3((a.nseg + kWave - 1) / kWave),
-                       dim3(64), 0, s, a); // 64 segments per wavefront
+    hipLaunchKernelGGL(k_stream_scan,
+                       dim3((a.nseg + a.scan_segs - 1) / a.scan_segs),
+                       dim3(64), 0, s, a);
     STREAM_CHECK(k_stream_scan);
     hipLaunchKernelGGL(k_stream_super, dim3(a.nsuper), dim3(kEntry), 0, s, a);
     STREAM_CHECK(k_stream_super);

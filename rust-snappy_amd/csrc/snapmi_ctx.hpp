@@ -171,6 +171,7 @@ struct snapmi_ctx {
     // segment size of the long-stream scan: 0 = by size (1 KiB under 256 MiB
     // of long streams, 4 KiB from there), 10 / 12 forced (test option)
     uint32_t stream_seg_log2 = 0;
+    uint32_t stream_scan_segs = 0; // test option: 0 = by size
     size_t pin_bl2_cap = 0;
     // frame layer scratch (snapmi_frame.hip)
     snapmi::DevBuf fr_tables, fr_desc, fr_meta, fr_scan, fr_slots, fr_chunk_off;

@@ -2400,8 +2400,9 @@ __device__ __forceinline__ void stream_scan(const StreamArgs &a, const uint32_t 
     h.lut = (l_u16x *)lutbuf;
     h.in = (gcptr)a.in;
     h.in_len = a.in_len;
-    const uint64_t seg0 = (uint64_t)wg * 64;
-    const uint32_t sl2 = a.seg_log2; // (the wavefront's 64 segments: < 2^31)
+    const uint32_t S = a.scan_segs; // segments of this wavefront: 8 .. 64
+    const uint64_t seg0 = (uint64_t)wg * S;
+    const uint32_t sl2 = a.seg_log2; // (the wavefront's S segments: < 2^31)
     h.seg = 1u << sl2;
     h.wbase = seg0 << sl2;
     h.mis = (uint32_t)((uintptr_t)a.in + h.wbase) & (kHopLine - 1);
@@ -2411,7 +2412,7 @@ __device__ __forceinline__ void stream_scan(const StreamArgs &a, const uint32_t 
     h.lastR = left < (1ull << 31) ? (uint32_t)left : 1u << 31;
     h.lastP = left + h.mis;
     const uint32_t nloc =
-        a.nseg - seg0 < 64 ? (uint32_t)(a.nseg - seg0) : 64u; // segments here
+        a.nseg - seg0 < S ? (uint32_t)(a.nseg - seg0) : S; // segments here
     hop_lut(lutbuf);
     su64x2 *const table = level_table<1>(a) + seg0 * kEntry;
     const uint32_t lastR = h.lastR;

@@ -146,6 +146,10 @@ constexpr uint32_t kSeg = 4096;           // bytes of compressed input
 constexpr uint32_t kEntry = 8;
 constexpr uint32_t kSegPerSuper = 64;
 constexpr uint32_t kCutSegs = 512;       // segments per wavefront of k_stream_cuts
+constexpr uint32_t kScanSegs = 64;       // segments per wavefront of k_stream_scan, at most
+// wavefronts a scan launch should have before its wavefronts own that many
+// segments each (StreamArgs::scan_segs)
+constexpr uint32_t kScanFill = 1024;
 constexpr uint32_t kStreamChunk = 65536;  // output bytes per piece: the
                                           // encoders' block size, so pieces
                                           // of their streams are independent
@@ -172,6 +176,12 @@ struct StreamArgs {
     // are short enough for the scan to be a wait for its longest walk: a
     // quarter of the hops per lane, four times the lanes - round 5)
     uint32_t seg_log2;
+    // segments a wavefront of k_stream_scan owns: kScanSegs when that still
+    // makes kScanFill wavefronts, fewer (a power of two from 8) when it does
+    // not - a scan wavefront is as slow as the chain of walks its lanes are
+    // handed, ~630 cycles a hop whoever else is on the chip
+    // (stream_scan_segs in snapmi_api.hip)
+    uint32_t scan_segs;
     // piece descriptors for k_decompress_streams
     const void **c_in;
     unsigned long long *c_inlen;

@@ -116,3 +116,23 @@ def cctx(request, built):
                  2 if request.param == "lanes_overlap" else 0)
     yield c
     c.close()
+
+
+# The long-stream scan's geometry (segment size, segments per scan wavefront)
+# follows the size of the call (stream_seg_log2 / stream_scan_segs in
+# snapmi_api.hip): 1 KiB and 8 for everything a test can afford.  The tests of
+# that path run in what large calls get, too: 4 KiB segments, full groups of
+# 64, and a group size in between.
+SCAN_GEOMETRIES = [pytest.param((10, 0), id="1k"),
+                   pytest.param((12, 0), id="4k"),
+                   pytest.param((10, 64), id="1k-64"),
+                   pytest.param((12, 16), id="4k-16")]
+
+
+def set_scan_geometry(ctx, geom):
+    """geom = (log2 of the segment size, segments per scan wavefront; 0 = by
+    size) or None (back to the library's own choice); returns the log2."""
+    seg, groups = geom if geom else (0, 0)
+    ctx.set_test_option("stream_seg_log2", seg)
+    ctx.set_test_option("stream_scan_segs", groups)
+    return seg

@@ -1,5 +1,8 @@
 """One size of bench.py's batch-size sweep (the corpus round tiled to <gib>):
-decompress ms, for kernel traces.  usage: sweep_one.py <gib>"""
+decompress ms, for kernel traces.  usage: sweep_one.py <gib>
+(SCAN_SEGS in the environment, with SNAPMI_TESTING=1: the test option
+stream_scan_segs)"""
+import os
 import sys
 from pathlib import Path
 
@@ -33,6 +36,8 @@ src = batch.StreamBatch(data, np.array(offs, dtype=np.int64),
 dst = batch.StreamBatch.empty(caps, dev)
 olens = torch.zeros(len(lens), dtype=torch.int64, device=dev)
 ctx = raw.Context(0)
+if os.environ.get("SCAN_SEGS"):
+    ctx.set_test_option("stream_scan_segs", int(os.environ["SCAN_SEGS"]))
 
 
 def dec():

@@ -17,6 +17,7 @@ import pytest
 import torch
 
 import kats
+from conftest import SCAN_GEOMETRIES, set_scan_geometry
 import oracle_lib as O
 
 pytestmark = pytest.mark.gpu
@@ -236,8 +237,8 @@ def test_sequential_decoder_keeps_to_its_buffers(built):
         c.close()
 
 
-@pytest.mark.parametrize("seg", [10, 12])
-def test_long_stream_paths_keep_to_their_buffers(ctx, seg):
+@pytest.mark.parametrize("geom", SCAN_GEOMETRIES)
+def test_long_stream_paths_keep_to_their_buffers(ctx, geom):
     """snapmi_decompress_stream (scan, cuts, pieces) and the long streams of a
     batch (k_bstream_*): outputs of exactly the announced length between
     bands; inputs in allocations of exactly their size (the scan's last
@@ -246,7 +247,7 @@ def test_long_stream_paths_keep_to_their_buffers(ctx, seg):
     behind them leaves the allocation."""
     import foreign
     from rust_snappy_amd import raw
-    ctx.set_test_option("stream_seg_log2", seg)
+    seg = set_scan_geometry(ctx, geom)
     rnd = O.corpus_round()
     rng = random.Random(4)
     big = b"".join(d for _, d in rnd)
@@ -325,7 +326,7 @@ def test_long_stream_paths_keep_to_their_buffers(ctx, seg):
             caps.append(1024)
     dst, lens, errs = decode_guarded(ctx, muts, caps, 13, False)
     check_against_oracle(muts, caps, dst, lens, errs)
-    ctx.set_test_option("stream_seg_log2", 0)
+    set_scan_geometry(ctx, None)
 
 
 def encode_guarded(ctx, datas, seed, aligned, caps=None):

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import kats
-from conftest import ROOT
+from conftest import ROOT, SCAN_GEOMETRIES, set_scan_geometry
 import oracle_lib as O
 
 pytestmark = pytest.mark.gpu
@@ -325,7 +325,7 @@ def test_hw_lds_atomic_lane_order(ctx):
     lanes of one DS atomic in ascending lane order.  Checked on the hardware
     the tests run on (tests/hw/lds_atomic_order.hip)."""
     import subprocess
-    from conftest import ROOT
+    from conftest import ROOT, SCAN_GEOMETRIES, set_scan_geometry
     exe = ROOT / "tests" / "hw" / "lds_atomic_order"
     assert exe.exists(), "run __graft_entry__.build() first"
     out = subprocess.run([str(exe)], capture_output=True, text=True,
@@ -338,7 +338,7 @@ def test_hw_lds_unaligned_access(built):
     at arbitrary byte addresses of its LDS ring with single DS instructions;
     checked bytewise on the hardware (tests/hw/lds_unaligned.hip)."""
     import subprocess
-    from conftest import ROOT
+    from conftest import ROOT, SCAN_GEOMETRIES, set_scan_geometry
     exe = ROOT / "tests" / "hw" / "lds_unaligned"
     assert exe.exists(), "run __graft_entry__.build() first"
     out = subprocess.run([str(exe)], capture_output=True, text=True,
@@ -353,7 +353,7 @@ def test_hw_lds_store_lane_order(built):
     ascending order (tests/hw/lds_write_order.hip; also self-checked at
     context creation, which falls back to the byte-per-lane decoder)."""
     import subprocess
-    from conftest import ROOT
+    from conftest import ROOT, SCAN_GEOMETRIES, set_scan_geometry
     exe = ROOT / "tests" / "hw" / "lds_write_order"
     assert exe.exists(), "run __graft_entry__.build() first"
     out = subprocess.run([str(exe)], capture_output=True, text=True,
@@ -466,8 +466,8 @@ def stream_decode(ctx, comp, cap):
                                                int(e["b"]), int(e["c"]))
 
 
-@pytest.mark.parametrize("seg", [10, 12])
-def test_long_stream_parallel_decode(ctx, seg):
+@pytest.mark.parametrize("geom", SCAN_GEOMETRIES)
+def test_long_stream_parallel_decode(ctx, geom):
     """One raw stream on many wavefronts: equal to the original, for streams
     of this format's encoders (64 KiB blocks: pieces independent), for
     foreign streams (copies across pieces: sequential path), tiny and empty
@@ -475,7 +475,7 @@ def test_long_stream_parallel_decode(ctx, seg):
     import foreign
     # (both segment sizes of the scan: 1 KiB is what streams of this size get
     # by themselves, 4 KiB what those of 256 MiB and more do)
-    ctx.set_test_option("stream_seg_log2", seg)
+    seg = set_scan_geometry(ctx, geom)
     rnd = O.corpus_round()
     big = b"".join(d for _, d in rnd) * 3            # 8.8 MB, 137 blocks
     cases = [big, rnd[2][1] * 5, bytes(300000), b"", b"a", rnd[0][1],
@@ -521,13 +521,13 @@ def test_long_stream_parallel_decode(ctx, seg):
         raise AssertionError
     except O.SnapError as oe:
         assert (oe.kind, oe.a, oe.b, oe.c) == e
-    ctx.set_test_option("stream_seg_log2", 0)
+    set_scan_geometry(ctx, None)
 
 
-@pytest.mark.parametrize("seg", [10, 12])
-def test_long_stream_scan_shapes(ctx, seg):
-    """The structure k_stream_scan / k_stream_cuts work in (64 segments of
-    4 KiB per scan wavefront, 512 per cuts wavefront, walks handed out from a
+@pytest.mark.parametrize("geom", SCAN_GEOMETRIES)
+def test_long_stream_scan_shapes(ctx, geom):
+    """The structure k_stream_scan / k_stream_cuts work in (8 .. 64 segments
+    of 1 or 4 KiB per scan wavefront, 512 per cuts wavefront, walks handed out from a
     pool, chains that join the next segment's trunk): streams whose segment
     count sits at and around those boundaries, streams where chains run
     through the bytes of long literals (they never join: one walk each),
@@ -535,7 +535,7 @@ def test_long_stream_scan_shapes(ctx, seg):
     round can hold), and literals with one, two and three length bytes at
     every alignment.  All must come from the parallel path."""
     from rust_snappy_amd import raw
-    ctx.set_test_option("stream_seg_log2", seg)
+    seg = set_scan_geometry(ctx, geom)
     seg_bytes = 1 << seg
     rng = random.Random(77)
     text = b"".join(d for n, d in O.corpus_round() if "txt" in n or "html" in n)
@@ -553,8 +553,8 @@ def test_long_stream_scan_shapes(ctx, seg):
                 hi = mid
         return src[:lo]
 
-    cases = [with_segments(k) for k in (1, 2, 63, 64, 65, 128, 129, 511, 512,
-                                        513, 1025)]
+    cases = [with_segments(k) for k in (1, 2, 7, 8, 9, 15, 16, 17, 63, 64, 65,
+                                        128, 129, 511, 512, 513, 1025)]
     noise = lambda n: bytes(rng.randrange(256) for _ in range(n))  # noqa: E731
     mixed = bytearray()
     for n in (200_000, 70_000, 61, 62, 300, 65_536, 65_537, 4096, 100_000):
@@ -577,11 +577,11 @@ def test_long_stream_scan_shapes(ctx, seg):
         assert e[0] == 0, (i, e)
         assert got == data, (i, len(data), len(comp))
         assert raw.stream_decode_path(ctx) == 0, i
-    ctx.set_test_option("stream_seg_log2", 0)
+    set_scan_geometry(ctx, None)
 
 
-@pytest.mark.parametrize("seg", [10, 12])
-def test_batch_with_long_streams(ctx, seg):
+@pytest.mark.parametrize("geom", SCAN_GEOMETRIES)
+def test_batch_with_long_streams(ctx, geom):
     """A small batch gives its long streams their pieces (k_long_plan,
     k_bstream_*): long and short streams side by side, long ones that are
     corrupt, truncated, lie in their header, come from a foreign encoder
@@ -628,7 +628,7 @@ def test_batch_with_long_streams(ctx, seg):
     assert len(streams) < 200
     plain_ctx = R.raw.Context(0)
     plain_ctx.set_option("batch_long_streams", 0)
-    ctx.set_test_option("stream_seg_log2", seg)
+    seg = set_scan_geometry(ctx, geom)
     try:
         for c in (ctx, plain_ctx):
             got, errs = gpu_decompress(c, streams, caps)
@@ -640,7 +640,7 @@ def test_batch_with_long_streams(ctx, seg):
                     assert (oe.kind, oe.a, oe.b, oe.c) == e, (i, e, oe)
     finally:
         plain_ctx.close()
-        ctx.set_test_option("stream_seg_log2", 0)
+        set_scan_geometry(ctx, None)
 
 
 def test_scalar_decompress_uses_long_stream_path(ctx):
