@@ -181,18 +181,26 @@ const char *snapmi_version(void);
  *                          16 GiB of input; bounds the token scratch)
  *   "lane_table_spread"    1 (default): the lane kernel's hash tables are
  *                          spread over up to 4x their size (HBM sustains more
- *                          random accesses that way); 0: packed (25 GB)
+ *                          random accesses that way); 0: packed (17-25 GB)
  *   "lane_table_budget_pct"  percent of the device memory that is free when
  *                          a context first needs its lane tables that the
  *                          tables - and, while a placement is being chosen,
  *                          its candidates together - may hold (default 33,
- *                          1..90).  A host that owns the GPU raises it: the
- *                          tables then spread further (it buys nothing
- *                          measurable: bench.py runs on the default)
+ *                          1..90)
+ *   "lane_table_high"      1 (default): a candidate region is allocated while
+ *                          a filler holds the rest of the free device memory,
+ *                          and the filler is freed at once - the tables then
+ *                          lie at the far end of the device's memory, where
+ *                          HBM sustains 30 % more random accesses than in
+ *                          its first ~190 GiB (profiles/r5_table_high.txt:
+ *                          what a fresh process gets otherwise is the slow
+ *                          kind).  For the duration of two hipMallocs the
+ *                          context holds more than its budget; 0: never
  *   "lane_table_tries"     placements of the lane tables that are timed
  *                          (k_probe_tables, 3 ms each) before the fastest is
  *                          kept - at most this many (default 10), fewer when
- *                          three of them probe within 2 % of each other
+ *                          one probes at the fast kind's rate, or three
+ *                          within 2 % of each other with a slower kind seen
  *                          (where the tables lie decides 10-25 %
  *                          of the match finder's speed).  1: no probing, one
  *                          region of the whole budget

@@ -52,6 +52,7 @@ struct snapmi_ctx {
     uint32_t n_lanes = 0;
     uint64_t lane_stride = 0;      // 16-byte entries between two lanes' tables
     bool lane_table_spread = true; // spread the tables over free memory
+    bool lane_table_high = true;   // first candidate behind a filler (snapmi_api.hip)
     // SNAPMI_COMPRESS=waves|lanes|both: 0 = wavefront kernel only, 1 = lane
     // kernel on large batches and the wavefront kernel on small ones
     // (default), 2 = on large batches both kernels at once, sharing one
@@ -198,6 +199,7 @@ struct snapmi_ctx {
     // placement is chosen, their candidates) may hold: the GPU may be shared
     uint32_t lane_table_budget_pct = 33;
     bool lane_table_probe = false; // experiment knob: probe even with 1 try
+    uint32_t lane_table_stride_kib = 0; // experiment knob: bytes between tables
     std::string probe_log;          // k_probe_tables ms of every candidate
     // test knob: every lane's table epoch is set to this value before the
     // next lane-kernel launch (-1 = leave the epochs alone); lets a test
