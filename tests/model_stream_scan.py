@@ -1,11 +1,13 @@
 """k_stream_scan (rust-snappy_amd/csrc/snapmi_decompress.hip) as a model: the
-level-1 table of snapmi_decompress_stream - for every 4 KiB segment and every
+level-1 table of snapmi_decompress_stream - for every segment (SEG: 4 KiB, or
+1 KiB for the streams of a small call - StreamArgs::seg_log2) and every
 entry offset o < 8, where the chain that starts at byte o leaves the segment
 (the first element start at or behind the segment's end within 8 bytes of a
 segment boundary, or the end of the stream) and what it has produced.
 
 naive_table() is the definition (rounds 1-3: one walk per entry).  pooled_table()
-is what the kernel of round 4 does per wavefront of 64 segments: phase A walks
+is what the kernel of round 4 does per wavefront of `group` segments (64; 8 ..
+32 where a call has few of them - StreamArgs::scan_segs): phase A walks
 every entry 128 bytes far; entries that stand where entry 0 of their segment
 stands share its trunk; a walk that overruns its segment stands 128 bytes into
 the next one and, if that is where that segment's trunk started, is that trunk
@@ -71,11 +73,11 @@ def naive_table(comp):
     return tab
 
 
-def pooled_table(comp, stats=None):
+def pooled_table(comp, stats=None, group=64):
     nseg = (len(comp) + SEG - 1) // SEG
     tab = {}
-    for w0 in range(0, nseg, 64):
-        nloc = min(64, nseg - w0)
+    for w0 in range(0, nseg, group):
+        nloc = min(group, nseg - w0)
         mid = {}                                  # (sl, o) -> (pos, out) | None
         # ---- phase A
         for sl in range(nloc):
