@@ -192,9 +192,8 @@ const char *snapmi_version(void);
  *                          and the filler is freed at once - the tables then
  *                          lie at the far end of the device's memory, where
  *                          HBM sustains 30 % more random accesses than in
- *                          its first ~190 GiB (profiles/r5_table_high.txt:
- *                          what a fresh process gets otherwise is the slow
- *                          kind).  For the duration of two hipMallocs the
+ *                          its first 176 GiB (profiles/r5_zone_map.txt; what
+ *                          a fresh process gets otherwise is the slow part).  For the duration of two hipMallocs the
  *                          context holds more than its budget; 0: never
  *   "lane_table_tries"     placements of the lane tables that are timed
  *                          (k_probe_tables, 3 ms each) before the fastest is
