@@ -5,7 +5,8 @@
 //   A. one allocation of nearly all free memory, the window moved through it
 //      in steps of 16 GiB;
 //   B. sixteen-GiB allocations made one after the other and all kept, each
-//      probed as it comes (the order hipMalloc hands memory out in).
+//      probed as it comes (the order hipMalloc hands memory out in);
+//   C. streaming by the same offsets: a device-to-device copy of 8 GiB.
 // build: hipcc --offload-arch=gfx950 -O2 -o tests/hw/zone_map tests/hw/zone_map.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -65,6 +66,26 @@ int main()
         for (int rep = 0; rep < 2; rep++) {
             for (size_t off = 0; off + W <= big; off += W)
                 printf("  +%3zu GiB %.2f", off / G, run((char *)p + off, out));
+            printf("\n");
+        }
+        // C. streaming: a device-to-device copy of 8 GiB inside each window
+        printf("C. the same allocation, hipMemcpyDtoD of 8 GiB inside each window: GB/s (read + write)\n");
+        for (int rep = 0; rep < 2; rep++) {
+            for (size_t off = 0; off + W <= big; off += W) {
+                hipEvent_t a, b;
+                hipEventCreate(&a);
+                hipEventCreate(&b);
+                hipEventRecord(a);
+                hipMemcpyAsync((char *)p + off + 8 * G, (char *)p + off, 8 * G,
+                               hipMemcpyDeviceToDevice, 0);
+                hipEventRecord(b);
+                hipEventSynchronize(b);
+                float ms = 0;
+                hipEventElapsedTime(&ms, a, b);
+                printf("  +%3zu GiB %.0f", off / G, 2.0 * 8 * G / (ms * 1e-3) / 1e9);
+                hipEventDestroy(a);
+                hipEventDestroy(b);
+            }
             printf("\n");
         }
         hipFree(p);
