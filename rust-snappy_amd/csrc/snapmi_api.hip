@@ -889,7 +889,7 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
             size_t stride = tbytes;
             // (only worth it for a launch that fills the chip: a small
             // batch gets a handful of tables and no measurable placement)
-            const uint32_t tries =
+            uint32_t tries =
                 lanes >= 16384 && ctx->lane_table_tries
                     ? ctx->lane_table_tries : 1;
             size_t budget = 0; // bytes this context may hold while it chooses
@@ -931,6 +931,13 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
             // with k_probe_tables (the kernel's own access pattern: dependent
             // random 16-byte read + write per lane), and the fastest is kept.
             const size_t bytes = (size_t)lanes * stride;
+            // (a budget under three regions of tables packed densely: two
+            // alive at a time - the last loser goes before the next candidate
+            // comes; under two: the one region, unprobed)
+            const bool keep_loser =
+                !ctx->lane_table_spread || 3 * bytes <= budget;
+            if (ctx->lane_table_spread && 2 * bytes > budget)
+                tries = 1;
             // (an error on the way out frees what was allocated here)
             struct Regions {
                 void *best = nullptr, *loser = nullptr, *cand = nullptr;
@@ -948,13 +955,20 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
             size_t held_peak = 0;
             // what the probe takes when the region is of the fast kind: 768
             // dependent read + write pairs per lane at 2.6e10 pairs/s
-            // (tests/hw/random_rw16.hip), and 8 % on top
+            // (tests/hw/random_rw16.hip), and 3 % on top (the fast part's
+            // windows probe at 1.94-2.07 ms, profiles/r5_zone_map.txt, and
+            // the launch follows: 111.5 ms at 1.92-1.94, 116-118 at 2.03-2.05)
             const float fast_ms =
-                (float)((double)lanes * 768 / 2.6e10 * 1e3 * 1.08);
+                (float)((double)lanes * 768 / 2.6e10 * 1e3 * 1.03);
             for (uint32_t t = 0; t < tries; t++) {
                 void *&cand = rg.cand;
                 void *&best = rg.best, *&loser = rg.loser;
                 cand = nullptr;
+                if (loser && !keep_loser) {
+                    void *gone = loser;
+                    loser = nullptr;
+                    HIP_TRY(ctx, hipFree(gone));
+                }
                 // WHICH regions are the fast kind was found in round 5
                 // (tests/hw/table_high.py, profiles/r5_table_high.txt): those
                 // behind the first ~190 GiB of the device's memory - a region
@@ -969,8 +983,16 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                 // fast kind nine times in ten; the next lie in front of it.
                 void *filler = nullptr;
                 // (a launch that fills the chip: a handful of tables has no
-                // measurable placement)
+                // measurable placement.  One context of a process at a time;
+                // a GiB stays free beside the region - with 8 GiB the region
+                // is pieced together from what is free elsewhere, too, and
+                // the first candidate probes at 2.19-2.45 ms every other time,
+                // profiles/r5_table_budget.txt)
+                static std::mutex place_mu;
+                std::unique_lock<std::mutex> place_lock(place_mu,
+                                                        std::defer_lock);
                 if (ctx->lane_table_high && lanes >= 16384) {
+                    place_lock.lock();
                     size_t free_b = 0, total_b = 0;
                     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
                         const size_t spare = bytes + ((size_t)1 << 30);
@@ -1007,6 +1029,8 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                     if (!got) // (not behind the filler: the plain way)
                         got = region();
                 }
+                if (place_lock.owns_lock())
+                    place_lock.unlock();
                 if (!got)
                     break; // no room for another candidate: keep the best
                 {
