@@ -179,9 +179,11 @@ const char *snapmi_version(void);
  *                          latency is what is waited for; 0: never
  *   "lane_segment_blocks"  blocks per lane-kernel launch (default 262144 =
  *                          16 GiB of input; bounds the token scratch)
- *   "lane_table_spread"    1 (default): the lane kernel's hash tables are
- *                          spread over up to 4x their size (HBM sustains more
- *                          random accesses that way); 0: packed (17-25 GB)
+ *   "lane_table_spread"    1 (default): without lane_table_high, the lane
+ *                          kernel's hash tables are spread over up to 4x
+ *                          their size (a region that straddles the two parts
+ *                          of the device's memory averages over them); with
+ *                          it, and with 0, they are packed (17-25 GB)
  *   "lane_table_budget_pct"  percent of the device memory that is free when
  *                          a context first needs its lane tables that the
  *                          tables - and, while a placement is being chosen,

@@ -908,6 +908,12 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                     stride = 4 * tbytes;
                 if (stride < tbytes)
                     stride = tbytes;
+                // (in the fast part of the memory - lane_table_high - packed
+                // tables probe like tables a MiB apart, 1.91-1.95 ms both,
+                // profiles/r5_table_high.txt: the spreading of round 2
+                // averaged over the two parts, and costs 13-52 GB)
+                if (ctx->lane_table_high && lanes >= 16384)
+                    stride = tbytes;
             }
             if (ctx->lane_table_stride_kib) // test option
                 stride = (size_t)ctx->lane_table_stride_kib << 10;
