@@ -538,10 +538,6 @@ def main():
     # the free memory.  Rounds 2-3 quoted the headline at 75 %; measured in
     # round 4 - extras.budget - 75, 33 and 15 % give the same rate)
     ctx = raw.Context(local_rank)
-    if over:
-        # (N ranks on ONE device: no rank may hold the device's free memory,
-        # however briefly, while the others allocate)
-        ctx.set_option("lane_table_high", 0)
     d_round = torch.from_numpy(host_round).to(dev)
     data = d_round.repeat(rounds)
     offs = (np.arange(rounds, dtype=np.int64)[:, None] * round_stride

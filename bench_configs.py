@@ -307,11 +307,14 @@ def files(args, ctx, dev):
             "files": rows}
 
 
-def round_tiles(ctx, dev, gib, steps):
+def round_tiles(ctx, dev, gib, steps, diag=None):
     """The 12-stream zflat/uflat round tiled to `gib` as independent raw
     streams (bench.py's workload at another size): compress and decompress
     seconds per pass, round 0 compared with the oracle's bytes, the round
-    trip with the input."""
+    trip with the input.  `diag` (a dict) gets what explains a row from the
+    outside: the first compress call on this context at this size on its own
+    (it allocates, and places the lane tables), the placement's log, every
+    timed call's kernel ms, hipMemGetInfo's free bytes around it all."""
     import oracle_lib as O
     from rust_snappy_amd import batch, raw
     rnd = O.corpus_round()
@@ -345,15 +348,34 @@ def round_tiles(ctx, dev, gib, steps):
         raw.decompress_batch(ctx, comp.d_ptrs, clens, back.d_ptrs,
                              back.d_lens, blens, None)
 
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(dev)[0]
+    t0 = time.perf_counter()
     enc()
     ctx.synchronize()
+    first_ms = (time.perf_counter() - t0) * 1e3
     cl = clens.cpu().numpy()
     for j, (_, d) in enumerate(rnd):
         assert comp.stream_bytes(j, int(cl[j])) == O.compress(d), j
         k = n - 12 + j
         assert comp.stream_bytes(k, int(cl[k])) == O.compress(d), k
-    te = time_it(enc, steps, ctx)
+    calls = []
+
+    def enc_logged():
+        t0 = time.perf_counter()
+        enc()
+        ctx.synchronize()
+        calls.append(round((time.perf_counter() - t0) * 1e3, 2))
+    te = time_it(enc_logged if diag is not None else enc, steps, ctx)
     td = time_it(dec, steps, ctx)
+    if diag is not None:
+        diag.update({
+            "first_call_ms": round(first_ms, 1),
+            "call_ms": calls,            # the warm call, then the timed ones
+            "kernel": ctx.last_kernel(),
+            "placement": ctx.table_probe_log(),
+            "free_gib_before": round(free0 / GIB, 1),
+            "free_gib_after": round(torch.cuda.mem_get_info(dev)[0] / GIB, 1)})
     for j, (_, d) in enumerate(rnd):
         assert back.stream_bytes(n - 12 + j) == d, j
     ub = rounds * int(r_lens.sum())
@@ -374,12 +396,14 @@ def sweep(args, ctx, dev):
                        ("4GiB", 4.0)):
         if gib > args.gib:
             continue
-        ub, cb, n, te, td = round_tiles(own, dev, gib, max(args.steps, 3))
+        diag = {}
+        ub, cb, n, te, td = round_tiles(own, dev, gib, max(args.steps, 3),
+                                        diag)
         rows[label] = {"gib": round(ub / GIB, 4), "streams": n,
                        "compress_gibs": round(ub / GIB / te, 2),
                        "decompress_gibs": round(ub / GIB / td, 2),
                        "compress_ms": round(te * 1e3, 3),
-                       "decompress_ms": round(td * 1e3, 3)}
+                       "decompress_ms": round(td * 1e3, 3), **diag}
     own.close()
     torch.cuda.empty_cache()
     return {"config": "bench.py's workload (12-stream round, independent raw "
@@ -398,8 +422,10 @@ def budget(args, ctx, dev):
         c = raw.Context(ctx.device)
         c.set_option("lane_table_budget_pct", pct)
         free0 = torch.cuda.mem_get_info(dev)[0]
-        ub, cb, n, te, td = round_tiles(c, dev, args.gib, max(args.steps, 3))
-        log = _lib.load().snapmi_table_probe_log(c._h).decode()
+        diag = {}
+        ub, cb, n, te, td = round_tiles(c, dev, args.gib, max(args.steps, 3),
+                                        diag)
+        log = c.table_probe_log()
         held = None
         if "held at most" in log:
             held = int(log.split("held at most")[1].split()[0])
@@ -408,11 +434,36 @@ def budget(args, ctx, dev):
         rows[f"pct{pct}"] = {"compress_gibs": round(ub / GIB / te, 2),
                              "compress_ms": round(te * 1e3, 2),
                              "context_bytes": int(free0 - free1),
-                             "held_at_most_during_placement": held}
+                             "held_at_most_during_placement": held,
+                             "first_call_ms": diag["first_call_ms"],
+                             "call_ms": diag["call_ms"],
+                             "placement": diag["placement"]}
         c.close()
         torch.cuda.empty_cache()
+    # ... and the explicit opt-in: snapmi_ctx_prepare(TOP_OF_MEMORY) before
+    # the first batch (holds the whole device for a moment, include/snapmi.h)
+    c = raw.Context(ctx.device)
+    rounds = max(1, int(round(args.gib * GIB / 2928571)))
+    free0 = torch.cuda.mem_get_info(dev)[0]
+    t0 = time.perf_counter()
+    c.prepare(50 * rounds, top_of_memory=True)     # 50 blocks per round
+    prep_ms = (time.perf_counter() - t0) * 1e3
+    diag = {}
+    ub, cb, n, te, td = round_tiles(c, dev, args.gib, max(args.steps, 3), diag)
+    torch.cuda.empty_cache()
+    free1 = torch.cuda.mem_get_info(dev)[0]
+    rows["prepared_top_of_memory"] = {
+        "compress_gibs": round(ub / GIB / te, 2),
+        "compress_ms": round(te * 1e3, 2),
+        "context_bytes": int(free0 - free1),
+        "prepare_ms": round(prep_ms, 1),
+        "first_call_ms": diag["first_call_ms"], "call_ms": diag["call_ms"],
+        "placement": diag["placement"]}
+    c.close()
+    torch.cuda.empty_cache()
     return {"config": f"lane_table_budget_pct 75 / 33 / 15 at {args.gib:g} "
-                      "GiB of bench.py's workload", "budgets": rows}
+                      "GiB of bench.py's workload, and snapmi_ctx_prepare("
+                      "SNAPMI_PREPARE_TOP_OF_MEMORY)", "budgets": rows}
 
 
 def tiny(args, ctx, dev):

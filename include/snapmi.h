@@ -34,6 +34,17 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* Every function declared here (and nothing else) is exported by
+ * libsnapmi.so: the library is built with -fvisibility=hidden and the export
+ * list rust-snappy_amd/csrc/snapmi.map, which csrc/gen_exports.py writes
+ * from the SNAPMI_API lines of this header (tests/test_abi_cpu.py compares
+ * `nm -D` of the built library with it, name for name). */
+#if defined(__GNUC__)
+#define SNAPMI_API __attribute__((visibility("default")))
+#else
+#define SNAPMI_API
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -50,20 +61,20 @@ typedef enum {
 
 /* replaces snappy_compress (snappy-cpp/src/lib.rs:67-72).
  * *compressed_length: in = capacity, out = bytes written. */
-snappy_status snappy_compress(const char *input, size_t input_length,
+SNAPMI_API snappy_status snappy_compress(const char *input, size_t input_length,
                               char *compressed, size_t *compressed_length);
 /* replaces snappy_uncompress (snappy-cpp/src/lib.rs:74-79) */
-snappy_status snappy_uncompress(const char *compressed,
+SNAPMI_API snappy_status snappy_uncompress(const char *compressed,
                                 size_t compressed_length, char *uncompressed,
                                 size_t *uncompressed_length);
 /* replaces snappy_max_compressed_length (snappy-cpp/src/lib.rs:81) */
-size_t snappy_max_compressed_length(size_t source_length);
+SNAPMI_API size_t snappy_max_compressed_length(size_t source_length);
 /* replaces snappy_uncompressed_length (snappy-cpp/src/lib.rs:83-87) */
-snappy_status snappy_uncompressed_length(const char *compressed,
+SNAPMI_API snappy_status snappy_uncompressed_length(const char *compressed,
                                          size_t compressed_length,
                                          size_t *result);
 /* snappy-c.h:120-122; not bound by the reference, kept for completeness */
-snappy_status snappy_validate_compressed_buffer(const char *compressed,
+SNAPMI_API snappy_status snappy_validate_compressed_buffer(const char *compressed,
                                                 size_t compressed_length);
 
 /* ------------------------------------------------------------------ */
@@ -101,7 +112,7 @@ typedef struct snapmi_error {
  * text the reference prints for this error - "snappy: corrupt input (expected
  * copy write of length 11; remaining dst: 4)" - into buf (NUL-terminated,
  * truncated to cap).  Returns the length the whole text has.  Host code. */
-size_t snapmi_error_string(const snapmi_error *err, char *buf, size_t cap);
+SNAPMI_API size_t snapmi_error_string(const snapmi_error *err, char *buf, size_t cap);
 
 /* ------------------------------------------------------------------ */
 /* Context: one HIP device + stream + device scratch.  Maps to          */
@@ -112,28 +123,30 @@ typedef struct snapmi_ctx snapmi_ctx;
 
 /* device: HIP ordinal.  hip_stream: a hipStream_t the kernels are
  * launched on, or NULL for a stream owned by the context. */
-int snapmi_ctx_create(int device, void *hip_stream, snapmi_ctx **out);
-void snapmi_ctx_destroy(snapmi_ctx *ctx);
+SNAPMI_API int snapmi_ctx_create(int device, void *hip_stream, snapmi_ctx **out);
+SNAPMI_API void snapmi_ctx_destroy(snapmi_ctx *ctx);
 /* Message for the last SNAPMI_E_DEVICE / SNAPMI_E_ARGUMENT on this ctx. */
-const char *snapmi_last_error(const snapmi_ctx *ctx);
+SNAPMI_API const char *snapmi_last_error(const snapmi_ctx *ctx);
 /* Page-locked host memory for the host-buffer entry points (their H2D / D2H
  * copies run at PCIe speed from such buffers, at about a third of it from
  * pageable memory).  NULL when it cannot be had. */
-void *snapmi_host_alloc(size_t bytes);
-void snapmi_host_free(void *p);
-/* "ms ms ... | held at most B of budget B": the placement probe's time for
- * every candidate region of the last lane-table allocation (none when
- * lane_table_tries is 1) and the most device memory it held at once. */
-const char *snapmi_table_probe_log(const snapmi_ctx *ctx);
+SNAPMI_API void *snapmi_host_alloc(size_t bytes);
+SNAPMI_API void snapmi_host_free(void *p);
+/* "ms(stride) ms(stride) ... | held at most B of budget B | kept S KiB apart,
+ * L lanes, B bytes | placement T ms | free B -> B": the placement probe's
+ * time for every candidate region of the last lane-table allocation (none
+ * when lane_table_tries is 1), the most device memory it held at once, what
+ * it kept, how long it took and hipMemGetInfo's free bytes around it. */
+SNAPMI_API const char *snapmi_table_probe_log(const snapmi_ctx *ctx);
 /* Name of the dominant kernel of the last batch call - the one
  * snapmi_timing.dominant_ms times: "k_match_both", "k_match_blocks",
  * "k_match_spans", "k_compress_spans", "k_decompress_streams3" ... ("" before
  * the first call).  For profiles: bench.py names its roofline by it. */
-const char *snapmi_last_kernel(const snapmi_ctx *ctx);
+SNAPMI_API const char *snapmi_last_kernel(const snapmi_ctx *ctx);
 /* hipStream_t the context launches on (for event timing by the caller). */
-void *snapmi_ctx_stream(const snapmi_ctx *ctx);
+SNAPMI_API void *snapmi_ctx_stream(const snapmi_ctx *ctx);
 /* "snapmi <version> gfx950" */
-const char *snapmi_version(void);
+SNAPMI_API const char *snapmi_version(void);
 /*
  * Options (results never depend on them, only speed and memory):
  *   "compress_mode"        0 wavefront-per-block kernel only (k_compress_spans:
@@ -179,32 +192,24 @@ const char *snapmi_version(void);
  *                          latency is what is waited for; 0: never
  *   "lane_segment_blocks"  blocks per lane-kernel launch (default 262144 =
  *                          16 GiB of input; bounds the token scratch)
- *   "lane_table_spread"    1 (default): without lane_table_high, the lane
- *                          kernel's hash tables are spread over up to 4x
- *                          their size (a region that straddles the two parts
- *                          of the device's memory averages over them); with
- *                          it, and with 0, they are packed (17-25 GB)
+ *   "lane_table_spread"    1 (default): the lane kernel's hash tables are
+ *                          spread over up to 4x their size, as far as the
+ *                          budget below allows (HBM sustains up to 30 % more
+ *                          random accesses on tables that are not packed
+ *                          into the memory a process is handed first,
+ *                          DESIGN 4.1); 0: packed (17-25 GB)
  *   "lane_table_budget_pct"  percent of the device memory that is free when
  *                          a context first needs its lane tables that the
  *                          tables - and, while a placement is being chosen,
  *                          its candidates together - may hold (default 33,
- *                          1..90)
- *   "lane_table_high"      1 (default): a candidate region is allocated while
- *                          a filler holds the rest of the free device memory,
- *                          and the filler is freed at once - the tables then
- *                          lie at the far end of the device's memory, where
- *                          HBM sustains 30 % more random accesses than in
- *                          its first 176 GiB (profiles/r5_zone_map.txt; what
- *                          a fresh process gets otherwise is the slow part).  For the duration of two hipMallocs the
- *                          context holds more than its budget; 0: never
+ *                          1..90).  No call holds more at any moment, except
+ *                          snapmi_ctx_prepare with SNAPMI_PREPARE_TOP_OF_MEMORY
  *   "lane_table_tries"     placements of the lane tables that are timed
  *                          (k_probe_tables, 3 ms each) before the fastest is
- *                          kept - at most this many (default 10), fewer when
- *                          one probes at the fast kind's rate, or three
- *                          within 2 % of each other with a slower kind seen
- *                          (where the tables lie decides 10-25 %
- *                          of the match finder's speed).  1: no probing, one
- *                          region of the whole budget
+ *                          kept - at most this many (default 2: spread, then
+ *                          packed behind that), fewer when one probes at the
+ *                          fast rate or the budget has no room for another.
+ *                          1: no probing, one region
  *   "release_scratch"      1: the compressor's per-batch scratch (token
  *                          arrays of the lane kernel: 128 KiB per block of a
  *                          launch, up to 34 GB) is freed by
@@ -238,7 +243,30 @@ const char *snapmi_version(void);
  * snapmi_test.h (snapmi_ctx_set_test_option).
  * Returns SNAPMI_E_ARGUMENT for an unknown name.
  */
-int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value);
+SNAPMI_API int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value);
+
+/* Allocates and places, NOW, the device memory a batch of `blocks` 64 KiB
+ * blocks (input bytes / 65 536, rounded up per stream) would make the first
+ * snapmi_compress_batch allocate: the lane kernel's hash tables (256 KiB per
+ * lane in flight, 17-26 GB for a batch that fills the chip; nothing for a
+ * batch of fewer than lane_min_blocks blocks).  Optional - a compress call
+ * does the same on demand, within lane_table_budget_pct.
+ * flags:
+ *   SNAPMI_PREPARE_TOP_OF_MEMORY  place the tables at the far end of the
+ *     device's memory, where HBM sustains 30 % more random accesses than in
+ *     the part a process is handed first (cfg2: 72 instead of 57-66 GiB/s,
+ *     DESIGN 4.1).  The only way there is through everything in front of it:
+ *     for the duration of two hipMalloc calls this call holds ALL free device
+ *     memory (any other allocation on the device fails meanwhile - other
+ *     processes, torch in this process, other contexts), and the driver then
+ *     wipes what was given back, in the background, for a few seconds.  For a
+ *     process that owns the GPU, once, at start-up; never taken by default.
+ * Like the reference's Encoder::new (src/compress.rs:80-82: an encoder's
+ * scratch is its own and allocated once), made explicit because here it is
+ * gigabytes. */
+#define SNAPMI_PREPARE_TOP_OF_MEMORY 1u
+SNAPMI_API int snapmi_ctx_prepare(snapmi_ctx *ctx, uint64_t blocks,
+                                  uint32_t flags);
 
 /* ------------------------------------------------------------------ */
 /* 2. Scalar mirrors of snap::raw (host buffers; H2D + kernels + D2H).  */
@@ -246,17 +274,17 @@ int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value);
 /* ------------------------------------------------------------------ */
 /* snap::raw::max_compress_len, reference src/compress.rs:42-53
  * (0 when the input or the bound exceeds 2^32-1). */
-size_t snapmi_max_compress_len(size_t input_len);
+SNAPMI_API size_t snapmi_max_compress_len(size_t input_len);
 /* snap::raw::decompress_len, reference src/decompress.rs:30-35.
  * Pure header parse on the host. */
-int snapmi_decompress_len(const uint8_t *input, size_t input_len,
+SNAPMI_API int snapmi_decompress_len(const uint8_t *input, size_t input_len,
                           size_t *result, snapmi_error *err);
 /* snap::raw::Encoder::compress, reference src/compress.rs:99-154 */
-int snapmi_raw_compress(snapmi_ctx *ctx, const uint8_t *input,
+SNAPMI_API int snapmi_raw_compress(snapmi_ctx *ctx, const uint8_t *input,
                         size_t input_len, uint8_t *output, size_t output_cap,
                         size_t *written, snapmi_error *err);
 /* snap::raw::Decoder::decompress, reference src/decompress.rs:75-95 */
-int snapmi_raw_decompress(snapmi_ctx *ctx, const uint8_t *input,
+SNAPMI_API int snapmi_raw_decompress(snapmi_ctx *ctx, const uint8_t *input,
                           size_t input_len, uint8_t *output,
                           size_t output_cap, size_t *written,
                           snapmi_error *err);
@@ -285,7 +313,7 @@ int snapmi_raw_decompress(snapmi_ctx *ctx, const uint8_t *input,
  *   d_out_lens[i]              : bytes written (0 on error)
  *   d_errs[i]                  : per-stream snapmi_error (may be NULL)
  */
-int snapmi_compress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
+SNAPMI_API int snapmi_compress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                           const uint64_t *d_in_lens,
                           const uint64_t *h_in_lens, void *const *d_out_ptrs,
                           const uint64_t *d_out_caps, uint64_t *d_out_lens,
@@ -303,7 +331,7 @@ int snapmi_compress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
  * sets the option to 0; while the context's stream is being captured into a
  * hipGraph the look is skipped by itself and the call only enqueues).
  */
-int snapmi_decompress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
+SNAPMI_API int snapmi_decompress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                             const uint64_t *d_in_lens,
                             void *const *d_out_ptrs,
                             const uint64_t *d_out_caps, uint64_t *d_out_lens,
@@ -327,25 +355,25 @@ int snapmi_decompress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
  * any input - the rule snapmi_decompress_batch applies to the long streams
  * of a batch.
  */
-int snapmi_decompress_stream(snapmi_ctx *ctx, const void *d_in,
+SNAPMI_API int snapmi_decompress_stream(snapmi_ctx *ctx, const void *d_in,
                              uint64_t in_len, void *d_out, uint64_t out_cap,
                              uint64_t *d_out_len, snapmi_error *d_err);
 /* Which way the last snapmi_decompress_stream on this context went (waits
  * for it): 0 = pieces on many wavefronts, 1 = the sequential path, -1 = no
  * such call yet.  For tests and benchmarks. */
-int snapmi_stream_decode_path(snapmi_ctx *ctx);
+SNAPMI_API int snapmi_stream_decode_path(snapmi_ctx *ctx);
 
 /* decompress_len for n streams on the device (reference
  * src/decompress.rs:30-35): d_out_lens[i] = header value, d_errs[i] as the
  * reference would return. */
-int snapmi_decompress_len_batch(snapmi_ctx *ctx,
+SNAPMI_API int snapmi_decompress_len_batch(snapmi_ctx *ctx,
                                 const void *const *d_in_ptrs,
                                 const uint64_t *d_in_lens,
                                 uint64_t *d_out_lens, snapmi_error *d_errs,
                                 size_t n);
 
 /* Wait for everything enqueued on the context's stream. */
-int snapmi_ctx_synchronize(snapmi_ctx *ctx);
+SNAPMI_API int snapmi_ctx_synchronize(snapmi_ctx *ctx);
 
 /*
  * Timing of the last batch call, measured with HIP events recorded on the
@@ -362,7 +390,7 @@ typedef struct snapmi_timing {
                           k_compress_blocks or k_decompress_streams         */
     float reserved;
 } snapmi_timing;
-int snapmi_last_timing(snapmi_ctx *ctx, snapmi_timing *out);
+SNAPMI_API int snapmi_last_timing(snapmi_ctx *ctx, snapmi_timing *out);
 
 /* ------------------------------------------------------------------ */
 /* 4. Snappy frame format on the device (reference src/frame.rs,        */
@@ -375,7 +403,7 @@ int snapmi_last_timing(snapmi_ctx *ctx, snapmi_timing *out);
 /* Upper bound of snapmi_frame_compress output for n input bytes:
  * stream identifier + per chunk (8-byte header + at most the chunk itself,
  * because of the uncompressed fallback of reference src/frame.rs:85). */
-size_t snapmi_frame_max_len(size_t n);
+SNAPMI_API size_t snapmi_frame_max_len(size_t n);
 
 /*
  * What write::FrameEncoder::write_all(input) followed by into_inner()
@@ -385,7 +413,7 @@ size_t snapmi_frame_max_len(size_t n);
  *   d_chunk_offsets     : optional [chunks+1] offsets of every chunk header
  *                         in d_out (a side index; not part of the stream)
  */
-int snapmi_frame_compress(snapmi_ctx *ctx, const void *d_in, uint64_t in_len,
+SNAPMI_API int snapmi_frame_compress(snapmi_ctx *ctx, const void *d_in, uint64_t in_len,
                           void *d_out, uint64_t out_cap, uint64_t *d_out_len,
                           uint64_t *d_chunk_offsets);
 
@@ -403,7 +431,7 @@ int snapmi_frame_compress(snapmi_ctx *ctx, const void *d_in, uint64_t in_len,
  *                         an io::ErrorKind::UnexpectedEof is reported as
  *                         SNAPMI_E_UNEXPECTED_EOF
  */
-int snapmi_frame_decompress(snapmi_ctx *ctx, const void *d_in,
+SNAPMI_API int snapmi_frame_decompress(snapmi_ctx *ctx, const void *d_in,
                             uint64_t in_len, void *d_out, uint64_t out_cap,
                             uint64_t *d_out_len, snapmi_error *d_err,
                             const uint64_t *d_chunk_offsets,
@@ -425,7 +453,7 @@ int snapmi_frame_decompress(snapmi_ctx *ctx, const void *d_in,
  * 10 + sum(lens) + 8 n.  h_chunk_lens is host memory, read before the call
  * returns; the rest is asynchronous like snapmi_frame_compress.
  */
-int snapmi_frame_compress_chunks(snapmi_ctx *ctx, const void *d_in,
+SNAPMI_API int snapmi_frame_compress_chunks(snapmi_ctx *ctx, const void *d_in,
                                  const uint32_t *h_chunk_lens, size_t n,
                                  uint32_t flags, void *d_out, uint64_t out_cap,
                                  uint64_t *d_out_len,
@@ -448,7 +476,7 @@ int snapmi_frame_compress_chunks(snapmi_ctx *ctx, const void *d_in,
  * a hint: if it does not tile [identifier, in_len) with plain data chunks,
  * or a chunk needs the stale-buffer rule, the headers are walked instead.
  */
-int snapmi_frame_decompress_ex(snapmi_ctx *ctx, const void *d_in,
+SNAPMI_API int snapmi_frame_decompress_ex(snapmi_ctx *ctx, const void *d_in,
                                uint64_t in_len, void *d_out, uint64_t out_cap,
                                uint64_t *d_out_len, snapmi_error *d_err,
                                const uint64_t *d_chunk_offsets,
@@ -468,7 +496,7 @@ int snapmi_frame_decompress_ex(snapmi_ctx *ctx, const void *d_in,
  * the device without an index: it reports the reference's error), or
  * SNAPMI_E_ARGUMENT.  No GPU work.
  */
-int snapmi_frame_scan_host(const void *h_in, uint64_t in_len, uint32_t flags,
+SNAPMI_API int snapmi_frame_scan_host(const void *h_in, uint64_t in_len, uint32_t flags,
                            uint8_t *stale10, uint64_t *h_offsets,
                            uint64_t cap, uint64_t *n_chunks,
                            uint64_t *consumed);
@@ -496,12 +524,12 @@ int snapmi_frame_scan_host(const void *h_in, uint64_t in_len, uint32_t flags,
  *   (zeros for a new stream), see snapmi_frame_decompress_ex.
  */
 #define SNAPMI_FRAME_FINAL 2u
-size_t snapmi_frame_encode_bound(size_t total_bytes, size_t n_chunks);
-int snapmi_frame_encode_host(snapmi_ctx *ctx, const uint8_t *h_in,
+SNAPMI_API size_t snapmi_frame_encode_bound(size_t total_bytes, size_t n_chunks);
+SNAPMI_API int snapmi_frame_encode_host(snapmi_ctx *ctx, const uint8_t *h_in,
                              const uint32_t *h_chunk_lens, size_t n,
                              uint32_t flags, uint8_t *h_out, size_t out_cap,
                              size_t *written);
-int snapmi_frame_decode_host(snapmi_ctx *ctx, const uint8_t *h_in,
+SNAPMI_API int snapmi_frame_decode_host(snapmi_ctx *ctx, const uint8_t *h_in,
                              size_t in_len, uint32_t flags, uint8_t *stale10,
                              uint8_t *h_out, size_t out_cap, size_t *written,
                              size_t *consumed, snapmi_error *err);
@@ -518,13 +546,13 @@ int snapmi_frame_decode_host(snapmi_ctx *ctx, const uint8_t *h_in,
  * chunk boundary; every length within the format's limits), 1 otherwise or
  * when `cap` < n + 1: decode such a stream WITHOUT an index and the device
  * walk reports the reference's error.  No GPU work. */
-int snapmi_frame_index_host(const void *h_in, uint64_t in_len,
+SNAPMI_API int snapmi_frame_index_host(const void *h_in, uint64_t in_len,
                             uint64_t *h_offsets, uint64_t cap,
                             uint64_t *n_chunks);
 
 /* Masked CRC32C (reference CheckSummer::crc32c_masked, src/crc32.rs:35-38)
  * of n buffers of at most 65536 bytes each. */
-int snapmi_crc32c_masked_batch(snapmi_ctx *ctx, const void *const *d_ptrs,
+SNAPMI_API int snapmi_crc32c_masked_batch(snapmi_ctx *ctx, const void *const *d_ptrs,
                                const uint64_t *d_lens, uint32_t *d_out,
                                size_t n);
 
@@ -548,22 +576,22 @@ typedef struct snapmi_comm snapmi_comm;
 
 /* A fresh rendezvous id (ncclGetUniqueId): call on ONE rank, hand the 128
  * bytes to the others by any means (file, socket, MPI, torch store). */
-int snapmi_comm_unique_id(uint8_t id_out[SNAPMI_COMM_ID_BYTES]);
+SNAPMI_API int snapmi_comm_unique_id(uint8_t id_out[SNAPMI_COMM_ID_BYTES]);
 /* Collective: every rank calls it with the same id and world, its own rank,
  * and a context on the GPU it drives (one process per GPU). */
-int snapmi_comm_init(snapmi_ctx *ctx, const uint8_t id[SNAPMI_COMM_ID_BYTES],
+SNAPMI_API int snapmi_comm_init(snapmi_ctx *ctx, const uint8_t id[SNAPMI_COMM_ID_BYTES],
                      int rank, int world, snapmi_comm **out);
 /* Or use a communicator the host already has (an ncclComm_t, as void *);
  * it is not destroyed by snapmi_comm_destroy. */
-int snapmi_comm_wrap(snapmi_ctx *ctx, void *nccl_comm, int rank, int world,
+SNAPMI_API int snapmi_comm_wrap(snapmi_ctx *ctx, void *nccl_comm, int rank, int world,
                      snapmi_comm **out);
-void snapmi_comm_destroy(snapmi_comm *comm);
+SNAPMI_API void snapmi_comm_destroy(snapmi_comm *comm);
 /* Collective, blocking.  Every rank contributes d_send[0, send_bytes) (device
  * memory, may be empty); on `root`, d_recv[0, *total) receives the parts in
  * rank order.  h_sizes (host, [world], may be NULL) and *total are filled on
  * EVERY rank.  recv_cap matters on the root only; if the parts do not fit,
  * every rank returns SNAPMI_E_ARGUMENT and nothing is exchanged. */
-int snapmi_gatherv(snapmi_ctx *ctx, snapmi_comm *comm, int root,
+SNAPMI_API int snapmi_gatherv(snapmi_ctx *ctx, snapmi_comm *comm, int root,
                    const void *d_send, uint64_t send_bytes, void *d_recv,
                    uint64_t recv_cap, uint64_t *h_sizes, uint64_t *total);
 

@@ -63,7 +63,7 @@ extern "C" {
  *                          KiB; default 32 MiB)
  * Returns SNAPMI_E_ARGUMENT for an unknown name.
  */
-int snapmi_ctx_set_test_option(snapmi_ctx *ctx, const char *name,
+SNAPMI_API int snapmi_ctx_set_test_option(snapmi_ctx *ctx, const char *name,
                                int64_t value);
 
 #ifdef __cplusplus

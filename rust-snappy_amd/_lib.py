@@ -55,6 +55,7 @@ SYMBOLS = [
     ("snapmi_ctx_stream", _P, [_P]),
     ("snapmi_version", C.c_char_p, []),
     ("snapmi_ctx_set_option", C.c_int, [_P, C.c_char_p, C.c_int64]),
+    ("snapmi_ctx_prepare", C.c_int, [_P, C.c_uint64, C.c_uint32]),
     ("snapmi_ctx_set_test_option", C.c_int, [_P, C.c_char_p, C.c_int64]),
     ("snapmi_max_compress_len", _SZ, [_SZ]),
     ("snapmi_decompress_len", C.c_int, [C.c_char_p, _SZ, _SZP, _ERRP]),
@@ -104,10 +105,28 @@ SYMBOLS = [
 TEST_ONLY = {"snapmi_ctx_set_test_option"}
 
 _lib = None
+_product = None
+
+
+def _open(path):
+    if not path.exists():
+        raise ImportError(
+            f"{path} is missing: build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(str(path), mode=getattr(os, "RTLD_LOCAL", 0))
+    for name, res, args in SYMBOLS:
+        if name in TEST_ONLY and not hasattr(L, name):
+            continue          # the product build: no test knobs
+        f = getattr(L, name)  # AttributeError if the ABI lost a symbol
+        f.restype = res
+        f.argtypes = args
+    return L
 
 
 def load():
-    """Load libsnapmi.so; raise if it has not been built."""
+    """Load the process's library (libsnapmi.so; libsnapmi_test.so under
+    SNAPMI_TESTING=1); raise if it has not been built."""
     global _lib
     if _lib is not None:
         return _lib
@@ -119,17 +138,24 @@ def load():
         import torch  # noqa: F401
     except ImportError:
         pass
-    if not LIB_PATH.exists():
-        raise ImportError(
-            f"{LIB_PATH} is missing: build it with "
-            "`python -c 'import __graft_entry__ as g; g.build()'` "
-            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
-    L = C.CDLL(str(LIB_PATH), mode=getattr(os, "RTLD_LOCAL", 0))
-    for name, res, args in SYMBOLS:
-        if name in TEST_ONLY and not hasattr(L, name):
-            continue          # the product build: no test knobs
-        f = getattr(L, name)  # AttributeError if the ABI lost a symbol
-        f.restype = res
-        f.argtypes = args
-    _lib = L
-    return L
+    _lib = _open(LIB_PATH)
+    return _lib
+
+
+def load_product():
+    """The SHIPPED library, libsnapmi.so, whatever load() gives this process:
+    the test suite runs on the test build and, through contexts made with
+    Context(lib=load_product()), on this one as well (both can live in one
+    process: they are loaded RTLD_LOCAL)."""
+    global _product
+    if _product is None:
+        load()
+        prod = PKG_DIR / "libsnapmi.so"
+        _product = _lib if LIB_PATH == prod else _open(prod)
+    return _product
+
+
+def of(ctx):
+    """The library a context was made by (every call that takes a context
+    must go to that one)."""
+    return ctx._L if ctx is not None and getattr(ctx, "_L", None) else load()

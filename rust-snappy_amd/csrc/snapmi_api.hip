@@ -310,9 +310,6 @@ int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value)
     else if (strcmp(name, "lane_table_tries") == 0 && value >= 1 &&
              value <= 16)
         ctx->lane_table_tries = (uint32_t)value;
-    else if (strcmp(name, "lane_table_high") == 0 && value >= 0 &&
-             value <= 1)
-        ctx->lane_table_high = value != 0;
     else if (strcmp(name, "lane_table_budget_pct") == 0 && value >= 1 &&
              value <= 90)
         ctx->lane_table_budget_pct = (uint32_t)value;
@@ -630,6 +627,7 @@ namespace snapmi {
 // (k_compress_tiny under 256 bytes, k_compress_small under 1 KiB - under
 // 2 KiB with small_stream_kernel = 2) and get no blocks; 0: every stream goes
 // through the block kernels
+int prepare_lane_tables(snapmi_ctx *ctx, uint64_t blocks, bool top);
 static uint64_t small_stream_limit(const snapmi_ctx *ctx)
 {
     if (!ctx->tiny_stream_kernel)
@@ -697,6 +695,16 @@ int snapmi_compress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                            cnt8);
 }
 
+int snapmi_ctx_prepare(snapmi_ctx *ctx, uint64_t blocks, uint32_t flags)
+{
+    if (!ctx || (flags & ~(uint32_t)SNAPMI_PREPARE_TOP_OF_MEMORY))
+        return SNAPMI_E_ARGUMENT;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return snapmi::prepare_lane_tables(
+        ctx, blocks, (flags & SNAPMI_PREPARE_TOP_OF_MEMORY) != 0);
+}
+
+
 } // extern "C"
 
 namespace snapmi {
@@ -704,6 +712,269 @@ namespace snapmi {
 // batches of up to this many streams / blocks are planned and scanned by one
 // workgroup (one launch instead of three)
 constexpr size_t kPlanOneWg = 16384;
+
+// ---------------------------------------------------------------------
+// The lane kernel's hash tables: one 256 KiB table of 16-byte entries per lane
+// in flight, allocated when a launch first needs more lanes than the context
+// has tables for.
+//
+// WHERE the tables lie decides 10-25 % of the match finder's duration: HBM
+// sustains 2.0e10 dependent random read + write pairs per second on tables
+// packed into the memory a fresh process is handed first, and 2.6e10 on
+// tables that lie in the last third of the device's memory or are spread
+// over enough of it (tests/hw/zone_map.hip, addr_bits.hip, vmm_layouts.hip;
+// profiles/r6_table_placement.txt).  The placement cannot be requested, but
+// it can be measured - k_probe_tables is the kernel's own access pattern -
+// so at most lane_table_tries candidate regions are allocated and timed:
+//   0. the tables SPREAD over as much memory as the budget allows (up to a
+//      MiB per 256 KiB table);
+//   1. the tables PACKED, allocated while candidate 0 is still held (so it
+//      lies behind it);
+//   2+ spread again, behind what is held.
+// The search stops at the first candidate that probes at the fast rate; the
+// best one is kept, the others are freed.  At NO moment does the context
+// hold more than lane_table_budget_pct of the memory that was free when the
+// placement began (tests/test_gpu_parity.py polls hipMemGetInfo from a second
+// thread meanwhile).
+//
+// top_of_memory (snapmi_ctx_prepare with SNAPMI_PREPARE_TOP_OF_MEMORY, never
+// taken by a compress call on its own): ONE packed candidate allocated while
+// a filler holds everything else that is free, which is given back at once -
+// the tables then lie at the far end of the device's memory, the fast part.
+// For the duration of two hipMalloc calls the process holds the whole device
+// (another allocation on it fails meanwhile), and the driver wipes what the
+// filler gives back in the background (seconds for 250 GB, during which large
+// allocations wait: round 5 did this once per candidate inside a compress
+// call, ten times over - 72 s for a context's first 4 GiB batch,
+// profiles/r6_sweep_repro_head.txt).  That is why it is a call of its own.
+// ---------------------------------------------------------------------
+static uint32_t lane_count(const snapmi_ctx *ctx, uint64_t seg_blocks,
+                           bool both_cores)
+{
+    // waves of the lane-per-block match finder: a few per CU saturate the
+    // random-access rate of HBM; never more lanes than blocks
+    uint64_t waves = (uint64_t)ctx->num_cus * ctx->lane_waves_per_cu;
+    const uint64_t need = (seg_blocks + 63) / 64;
+    if (waves > need)
+        waves = need ? need : 1;
+    if (ctx->lane_max_waves && waves > ctx->lane_max_waves)
+        waves = ctx->lane_max_waves;
+    // k_match_both: its lane wavefronts on every CU, beside two of the
+    // window kernel
+    if (both_cores)
+        waves = (uint64_t)ctx->num_cus * kBothLaneWaves;
+    return (uint32_t)waves * 64;
+}
+
+static int place_lane_tables(snapmi_ctx *ctx, uint32_t lanes,
+                             bool top_of_memory)
+{
+    int rc;
+    const auto t_begin = std::chrono::steady_clock::now();
+    const size_t tbytes = (size_t)kMaxTable * 16;
+    if (ctx->lane_tables.p) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipFree(ctx->lane_tables.p));
+        ctx->lane_tables.p = nullptr;
+        ctx->lane_tables.cap = 0;
+        ctx->n_lanes = 0;
+    }
+    if ((rc = reserve(ctx, ctx->lane_epochs, (size_t)lanes * sizeof(uint32_t))))
+        return rc;
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+    const size_t free_before = free_b;
+    // The GPU may be shared: what this context holds while it chooses, and
+    // afterwards, stays within lane_table_budget_pct of what is free now (a
+    // third by default).
+    const size_t budget = free_b / 100 * ctx->lane_table_budget_pct;
+    // (a handful of tables has no measurable placement: only a launch that
+    // fills the chip is spread or probed)
+    const bool full = lanes >= 16384;
+    size_t spread = tbytes;
+    if (ctx->lane_table_spread && full) {
+        spread = budget / lanes / 4096 * 4096;
+        if (spread > 4 * tbytes)
+            spread = 4 * tbytes;
+        if (spread < tbytes)
+            spread = tbytes;
+    }
+    if (ctx->lane_table_stride_kib) // test option
+        spread = (size_t)ctx->lane_table_stride_kib << 10;
+    uint32_t tries = full && ctx->lane_table_tries ? ctx->lane_table_tries : 1;
+    if (spread == tbytes && tries > 1 && !ctx->lane_table_stride_kib)
+        tries = 1; // (the budget holds packed tables only: one region)
+    if (top_of_memory)
+        tries = 1;
+    // what the probe takes at the fast rate: 768 dependent read + write
+    // pairs per lane at 2.6e10 pairs/s (tests/hw/random_rw16.hip), 3 % on top
+    const float fast_ms = (float)((double)lanes * 768 / 2.6e10 * 1e3 * 1.03);
+    struct Cand {
+        void *p = nullptr;
+        size_t stride = 0, bytes = 0;
+        float ms = 0;
+    };
+    // (an error on the way out frees what was allocated here)
+    struct Held {
+        Cand best, other;
+        ~Held()
+        {
+            for (void *p : {best.p, other.p})
+                if (p)
+                    (void)hipFree(p);
+        }
+    } held;
+    ctx->probe_log.clear();
+    size_t held_peak = 0;
+    auto alloc = [&](Cand &c) {
+        const bool ok =
+            (ctx->lane_tables_uncached
+                 ? hipExtMallocWithFlags(&c.p, c.bytes, hipDeviceMallocUncached)
+                 : hipMalloc(&c.p, c.bytes)) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            c.p = nullptr;
+        }
+        return ok;
+    };
+    for (uint32_t t = 0; t < tries; t++) {
+        Cand c;
+        c.stride = top_of_memory || (t & 1) ? tbytes : spread;
+        c.bytes = (size_t)lanes * c.stride;
+        // a loser is freed before the next candidate comes unless the budget
+        // has room for all three (then the new one cannot be the loser's
+        // memory again)
+        const size_t alive = held.best.bytes + held.other.bytes;
+        if (held.other.p && alive + c.bytes > budget) {
+            HIP_TRY(ctx, hipFree(held.other.p));
+            held.other = Cand();
+        }
+        if (t && held.best.bytes + held.other.bytes + c.bytes > budget)
+            break; // no room for another candidate within the budget
+        void *filler = nullptr;
+        if (top_of_memory) {
+            // everything that is free but the region itself and a GiB
+            // beside it (with less left free the region is pieced together
+            // from what is free elsewhere, profiles/r5_table_budget.txt)
+            const size_t spare = c.bytes + ((size_t)1 << 30);
+            size_t want = free_b > spare ? free_b - spare : 0;
+            for (int k = 0; k < 3 && want >= ((size_t)8 << 30); k++) {
+                if (hipMalloc(&filler, want) == hipSuccess)
+                    break;
+                (void)hipGetLastError();
+                filler = nullptr;
+                want = want / 16 * 15;
+            }
+        }
+        bool got = alloc(c);
+        if (filler) {
+            (void)hipFree(filler);
+            if (!got) // (not behind the filler: the plain way)
+                got = alloc(c);
+        }
+        if (!got)
+            break; // keep the best so far
+        {
+            const size_t now = held.best.bytes + held.other.bytes + c.bytes;
+            held_peak = now > held_peak ? now : held_peak;
+        }
+        // (the probe runs on the memory as it comes: only the region that is
+        // kept gets zeroed)
+        if (tries > 1 || ctx->lane_table_probe || top_of_memory) {
+            hipLaunchKernelGGL(k_probe_tables, dim3(lanes / 64), dim3(64), 0,
+                               ctx->stream, (unsigned long long *)c.p,
+                               (unsigned long long)(c.stride / 16), 64u);
+            HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+            hipLaunchKernelGGL(k_probe_tables, dim3(lanes / 64), dim3(64), 0,
+                               ctx->stream, (unsigned long long *)c.p,
+                               (unsigned long long)(c.stride / 16), 768u);
+            HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+            HIP_TRY(ctx, hipEventSynchronize(ctx->ev[5]));
+            HIP_TRY(ctx, hipEventElapsedTime(&c.ms, ctx->ev[4], ctx->ev[5]));
+            char buf[48];
+            snprintf(buf, sizeof buf, "%s%.2f(%zuK)", t ? " " : "", c.ms,
+                     c.stride >> 10);
+            ctx->probe_log += buf;
+        }
+        if (!held.best.p || c.ms < held.best.ms) {
+            if (held.other.p) {
+                HIP_TRY(ctx, hipFree(held.other.p));
+                held.other = Cand();
+            }
+            held.other = held.best;
+            held.best = c;
+        } else {
+            if (held.other.p)
+                HIP_TRY(ctx, hipFree(held.other.p));
+            held.other = c;
+        }
+        if (tries > 1 && held.best.ms <= fast_ms)
+            break;
+    }
+    if (held.other.p) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipFree(held.other.p));
+        held.other = Cand();
+    }
+    if (!held.best.p)
+        return fail_ctx(ctx, SNAPMI_E_DEVICE,
+                        "hipMalloc of %zu bytes of lane tables failed",
+                        (size_t)lanes * tbytes);
+    // tables start as "never used": epoch 0 in every entry
+    HIP_TRY(ctx, hipMemset2DAsync(held.best.p, held.best.stride, 0, tbytes,
+                                  lanes, ctx->stream));
+    ctx->lane_tables.p = held.best.p;
+    ctx->lane_tables.cap = held.best.bytes;
+    ctx->lane_stride = held.best.stride / 16;
+    held.best = Cand(); // the context owns it now
+    HIP_TRY(ctx, hipMemsetAsync(ctx->lane_epochs.p, 0, (size_t)lanes * 4,
+                                ctx->stream));
+    ctx->n_lanes = lanes;
+    {
+        size_t free_after = 0;
+        (void)hipMemGetInfo(&free_after, &total_b);
+        const double ms =
+            std::chrono::duration<double, std::milli>(
+                std::chrono::steady_clock::now() - t_begin).count();
+        char buf[256];
+        snprintf(buf, sizeof buf,
+                 " | held at most %zu of budget %zu | kept %zu KiB apart, "
+                 "%u lanes, %zu bytes%s | placement %.1f ms | free %zu -> %zu",
+                 held_peak, budget, (size_t)(ctx->lane_stride * 16) >> 10,
+                 lanes, ctx->lane_tables.cap,
+                 top_of_memory ? " (top of memory)" : "", ms, free_before,
+                 free_after);
+        ctx->probe_log += buf;
+    }
+    return SNAPMI_OK;
+}
+
+
+// snapmi_ctx_prepare: the tables a batch of `blocks` blocks would make the
+// first compress call allocate, now (the same lane count launch_compress
+// derives); nothing when such a batch does not run the lane kernel or the
+// context already has that many tables - unless the far end of the memory is
+// asked for and the tables are not there yet.
+int prepare_lane_tables(snapmi_ctx *ctx, uint64_t blocks, bool top)
+{
+    if (ctx->compress_mode == 0 || blocks < ctx->lane_min_blocks)
+        return SNAPMI_OK;
+    const uint64_t seg_blocks =
+        blocks < ctx->lane_segment_blocks ? blocks : ctx->lane_segment_blocks;
+    const bool both = ctx->compress_mode == 1 && ctx->lds_order_ok &&
+                      ctx->lane_coresident &&
+                      blocks >= ctx->lane_coresident_min_blocks;
+    const uint32_t lanes = lane_count(ctx, seg_blocks, both);
+    if (lanes <= ctx->n_lanes && !(top && !ctx->lane_tables_top))
+        return SNAPMI_OK;
+    const int rc = place_lane_tables(ctx, lanes > ctx->n_lanes ? lanes
+                                                               : ctx->n_lanes,
+                                     top);
+    if (rc == SNAPMI_OK)
+        ctx->lane_tables_top = top;
+    return rc;
+}
+
 
 // k_scan_sizes over the blocks [a.blk_lo, min(a.blk_hi, host_blocks))
 static void launch_scan_sizes(const CompressArgs &a, hipStream_t s)
@@ -864,268 +1135,11 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
         a.tokens = (unsigned long long *)ctx->tokens.p;
         a.ntok = (uint32_t *)ctx->ntok.p;
     } else if (lanes_mode) {
-        // waves of the lane-per-block match finder: a few per CU saturate
-        // the random-access rate of HBM; never more lanes than blocks
-        uint64_t waves = (uint64_t)ctx->num_cus * ctx->lane_waves_per_cu;
-        const uint64_t need = (seg_blocks + 63) / 64;
-        if (waves > need)
-            waves = need ? need : 1;
-        if (ctx->lane_max_waves && waves > ctx->lane_max_waves)
-            waves = ctx->lane_max_waves;
-        // k_match_both: three lane wavefronts on every CU, beside two of
-        // the window kernel
-        if (both_cores)
-            waves = (uint64_t)ctx->num_cus * kBothLaneWaves;
-        const uint32_t lanes = (uint32_t)waves * 64;
-        if (lanes > ctx->n_lanes) { // tables must start zeroed (epoch 0)
-            // The tables are spread over more memory than they fill: HBM
-            // sustains 15-30 % more random accesses when they are not packed
-            // into one dense region, and the rate no longer depends on where
-            // that region happens to lie (tests/hw/random_rw16.hip: 2.0-2.2e10
-            // read+write/s dense, two modes between processes; 2.5-2.6e10
-            // spread over 120 GiB or more).  Up to 1 MiB per 256 KiB table,
-            // within a third of the memory that is free right now.
-            const size_t tbytes = (size_t)kMaxTable * 16;
-            size_t stride = tbytes;
-            // (only worth it for a launch that fills the chip: a small
-            // batch gets a handful of tables and no measurable placement)
-            uint32_t tries =
-                lanes >= 16384 && ctx->lane_table_tries
-                    ? ctx->lane_table_tries : 1;
-            size_t budget = 0; // bytes this context may hold while it chooses
-            if (ctx->lane_table_spread) {
-                size_t free_b = 0, total_b = 0;
-                HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
-                free_b += ctx->lane_tables.cap; // about to be released
-                // The GPU may be shared: at no moment does the placement
-                // hold more than lane_table_budget_pct of what is free now
-                // (a third by default).  While a placement is being chosen
-                // three regions are alive (best so far, last loser, new
-                // candidate), so each gets a third of the budget.
-                budget = free_b / 100 * ctx->lane_table_budget_pct;
-                stride = budget / (tries > 1 ? 3 : 1) / lanes / 4096 * 4096;
-                if (stride > 4 * tbytes)
-                    stride = 4 * tbytes;
-                if (stride < tbytes)
-                    stride = tbytes;
-                // (in the fast part of the memory - lane_table_high - packed
-                // tables probe like tables a MiB apart, 1.91-1.95 ms both,
-                // profiles/r5_table_high.txt: the spreading of round 2
-                // averaged over the two parts, and costs 13-52 GB)
-                if (ctx->lane_table_high && lanes >= 16384)
-                    stride = tbytes;
-            }
-            if (ctx->lane_table_stride_kib) // test option
-                stride = (size_t)ctx->lane_table_stride_kib << 10;
-            if (ctx->lane_tables.p) {
-                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-                HIP_TRY(ctx, hipFree(ctx->lane_tables.p));
-                ctx->lane_tables.p = nullptr;
-                ctx->lane_tables.cap = 0;
-                ctx->n_lanes = 0;
-            }
-            if ((rc = reserve(ctx, ctx->lane_epochs,
-                              (size_t)lanes * sizeof(uint32_t))))
+        const uint32_t lanes = lane_count(ctx, seg_blocks, both_cores);
+        if (lanes > ctx->n_lanes) {
+            if ((rc = place_lane_tables(ctx, lanes, /*top_of_memory=*/false)))
                 return rc;
-            // WHERE in HBM the tables land decides 10-25 % of the kernel's
-            // duration (profiles/r2_placement_probe.txt: 112-144 ms for the
-            // same launch on contexts created one after the other in one
-            // process).  The placement cannot be requested, but it can be
-            // measured: up to lane_table_tries regions are allocated - the
-            // best one so far and the last loser stay allocated meanwhile, so
-            // every new region is a different piece of memory - each is timed
-            // with k_probe_tables (the kernel's own access pattern: dependent
-            // random 16-byte read + write per lane), and the fastest is kept.
-            const size_t bytes = (size_t)lanes * stride;
-            // (a budget under three regions of tables packed densely: two
-            // alive at a time - the last loser goes before the next candidate
-            // comes; under two: the one region, unprobed)
-            const bool keep_loser =
-                !ctx->lane_table_spread || 3 * bytes <= budget;
-            if (ctx->lane_table_spread && 2 * bytes > budget)
-                tries = 1;
-            // (an error on the way out frees what was allocated here)
-            struct Regions {
-                void *best = nullptr, *loser = nullptr, *cand = nullptr;
-                ~Regions()
-                {
-                    for (void *p : {best, loser, cand})
-                        if (p)
-                            (void)hipFree(p);
-                }
-            } rg;
-            float best_ms = 0;
-            float probe_ms[16];
-            uint32_t n_probed = 0;
-            ctx->probe_log.clear();
-            size_t held_peak = 0;
-            // what the probe takes when the region is of the fast kind: 768
-            // dependent read + write pairs per lane at 2.6e10 pairs/s
-            // (tests/hw/random_rw16.hip), and 3 % on top (the fast part's
-            // windows probe at 1.94-2.07 ms, profiles/r5_zone_map.txt, and
-            // the launch follows: 111.5 ms at 1.92-1.94, 116-118 at 2.03-2.05)
-            const float fast_ms =
-                (float)((double)lanes * 768 / 2.6e10 * 1e3 * 1.03);
-            for (uint32_t t = 0; t < tries; t++) {
-                void *&cand = rg.cand;
-                void *&best = rg.best, *&loser = rg.loser;
-                cand = nullptr;
-                if (loser && !keep_loser) {
-                    void *gone = loser;
-                    loser = nullptr;
-                    HIP_TRY(ctx, hipFree(gone));
-                }
-                // WHICH regions are the fast kind was found in round 5
-                // (tests/hw/table_high.py, profiles/r5_table_high.txt): those
-                // behind the first ~190 GiB of the device's memory - a region
-                // allocated while a filler holds 160 GiB and more probes at
-                // 1.91-2.01 ms and the launch takes 111-115 ms, behind 0-128
-                // GiB 2.52-2.55 and 140-142 ms, five of five and four of
-                // four; a fresh process gets the slow kind first.  So every
-                // candidate is allocated behind a filler of everything that
-                // is free but the region itself, which is given back at once
-                // (it breaks the budget for the duration of two hipMallocs;
-                // option lane_table_high 0: never).  The first one is the
-                // fast kind nine times in ten; the next lie in front of it.
-                void *filler = nullptr;
-                // (a launch that fills the chip: a handful of tables has no
-                // measurable placement.  One context of a process at a time;
-                // a GiB stays free beside the region - with 8 GiB the region
-                // is pieced together from what is free elsewhere, too, and
-                // the first candidate probes at 2.19-2.45 ms every other time,
-                // profiles/r5_table_budget.txt)
-                static std::mutex place_mu;
-                std::unique_lock<std::mutex> place_lock(place_mu,
-                                                        std::defer_lock);
-                if (ctx->lane_table_high && lanes >= 16384) {
-                    place_lock.lock();
-                    size_t free_b = 0, total_b = 0;
-                    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-                        const size_t spare = bytes + ((size_t)1 << 30);
-                        size_t want = free_b > spare ? free_b - spare : 0;
-                        for (int k = 0; k < 3 && want >= ((size_t)8 << 30);
-                             k++) {
-                            if (hipMalloc(&filler, want) == hipSuccess)
-                                break;
-                            (void)hipGetLastError();
-                            filler = nullptr;
-                            want = want / 16 * 15;
-                        }
-                    } else {
-                        (void)hipGetLastError();
-                    }
-                }
-                // (uncached: MTYPE UC - the tables never hit in L2 anyway,
-                // tests/hw/random_policy.hip)
-                auto region = [&]() {
-                    const bool ok =
-                        (ctx->lane_tables_uncached
-                             ? hipExtMallocWithFlags(&cand, bytes,
-                                                     hipDeviceMallocUncached)
-                             : hipMalloc(&cand, bytes)) == hipSuccess;
-                    if (!ok) {
-                        (void)hipGetLastError();
-                        cand = nullptr;
-                    }
-                    return ok;
-                };
-                bool got = region();
-                if (filler) {
-                    (void)hipFree(filler);
-                    if (!got) // (not behind the filler: the plain way)
-                        got = region();
-                }
-                if (place_lock.owns_lock())
-                    place_lock.unlock();
-                if (!got)
-                    break; // no room for another candidate: keep the best
-                {
-                    const size_t held =
-                        bytes * (1 + (rg.best ? 1 : 0) + (rg.loser ? 1 : 0));
-                    held_peak = held > held_peak ? held : held_peak;
-                }
-                if (loser) {
-                    void *gone = loser;
-                    loser = nullptr;
-                    HIP_TRY(ctx, hipFree(gone));
-                }
-                // (the probe runs on the memory as it comes: only the region
-                // that is kept gets zeroed, 50 ms for 25 GB of tables)
-                float ms = 0;
-                if (tries > 1 || ctx->lane_table_probe) {
-                    hipLaunchKernelGGL(k_probe_tables, dim3(lanes / 64),
-                                       dim3(64), 0, ctx->stream,
-                                       (unsigned long long *)cand,
-                                       (unsigned long long)(stride / 16), 64u);
-                    HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
-                    hipLaunchKernelGGL(k_probe_tables, dim3(lanes / 64),
-                                       dim3(64), 0, ctx->stream,
-                                       (unsigned long long *)cand,
-                                       (unsigned long long)(stride / 16),
-                                       768u);
-                    HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
-                    HIP_TRY(ctx, hipEventSynchronize(ctx->ev[5]));
-                    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[4],
-                                                     ctx->ev[5]));
-                    char buf[32];
-                    snprintf(buf, sizeof buf, "%s%.2f", t ? " " : "", ms);
-                    ctx->probe_log += buf;
-                }
-                if (!best || ms < best_ms) {
-                    loser = best;
-                    best = cand;
-                    best_ms = ms;
-                } else {
-                    loser = cand;
-                }
-                cand = nullptr;
-                // enough: two more candidates within 2 % of the best one seen
-                // AND one of a slower kind (10-30 % off) mean the fast kind of
-                // placement has been found; every further candidate is a
-                // hipMalloc of the whole region and a third of the budget
-                // held.  (Three alike alone do not: the first three regions
-                // of a context are the slow kind together one time in three -
-                // 2.52 2.51 2.54 ms, and the launch 140 ms instead of 112:
-                // the pct33 row of round 5's first bench line.)
-                if (tries > 1) {
-                    probe_ms[n_probed++] = ms;
-                    uint32_t near = 0;
-                    bool slower = false;
-                    for (uint32_t k = 0; k < n_probed; k++) {
-                        near += probe_ms[k] <= best_ms * 1.02f;
-                        slower |= probe_ms[k] >= best_ms * 1.10f;
-                    }
-                    if ((near >= 3 && slower) || best_ms <= fast_ms)
-                        break;
-                }
-            }
-            {
-                char buf[96];
-                snprintf(buf, sizeof buf, " | held at most %zu of budget %zu",
-                         held_peak, budget);
-                ctx->probe_log += buf;
-            }
-            void *&best = rg.best, *&loser = rg.loser;
-            if (loser) {
-                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-                void *gone = loser;
-                loser = nullptr;
-                HIP_TRY(ctx, hipFree(gone));
-            }
-            if (!best)
-                return fail_ctx(ctx, SNAPMI_E_DEVICE,
-                                "hipMalloc of %zu bytes of lane tables failed",
-                                bytes);
-            // tables start as "never used": epoch 0 in every entry
-            HIP_TRY(ctx, hipMemset2DAsync(best, stride, 0, tbytes, lanes,
-                                          ctx->stream));
-            ctx->lane_tables.p = best;
-            best = nullptr; // the context owns it now
-            ctx->lane_tables.cap = bytes;
-            ctx->lane_stride = stride / 16;
-            HIP_TRY(ctx, hipMemsetAsync(ctx->lane_epochs.p, 0,
-                                        (size_t)lanes * 4, ctx->stream));
-            ctx->n_lanes = lanes;
+            ctx->lane_tables_top = false;
         }
         if ((rc = reserve(ctx, ctx->tokens, (size_t)seg_blocks * kMaxTokens *
                                                 sizeof(uint64_t))) ||
@@ -1145,13 +1159,13 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
         a.n_lanes = lanes;
     }
     a.prof = nullptr;
-#ifdef SNAPMI_PROFILE
+    PROF(
     if ((rc = reserve(ctx, ctx->st_prof, 16 * sizeof(uint64_t))))
         return rc;
     HIP_TRY(ctx, hipMemsetAsync(ctx->st_prof.p, 0, 16 * sizeof(uint64_t),
                                 ctx->stream));
     a.prof = (unsigned long long *)ctx->st_prof.p;
-#endif
+    )
 
     hipStream_t s = ctx->stream;
     ctx->timing_valid = false;
@@ -1423,7 +1437,7 @@ int launch_decompress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     a.order = (uint32_t *)order.p;
     a.bucket_pos = a.order + n;
     a.prof = nullptr;
-#ifdef SNAPMI_PROFILE
+    PROF(
     {
         int rc = reserve(ctx, ctx->st_prof, 16 * sizeof(uint64_t));
         if (rc)
@@ -1432,7 +1446,7 @@ int launch_decompress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                                     ctx->stream));
         a.prof = (unsigned long long *)ctx->st_prof.p;
     }
-#endif
+    )
     hipStream_t s = side ? side : ctx->stream;
     if (!side) {
         ctx->timing_valid = false;
@@ -2082,17 +2096,17 @@ int snapmi_decompress_len_batch(snapmi_ctx *ctx,
     return SNAPMI_OK;
 }
 
-#ifdef SNAPMI_PROFILE
+PROF(
 // experiment builds only: copy out the 16 cycle counters of the last
 // compress batch (not part of include/snapmi.h)
-int snapmi_debug_profile(snapmi_ctx *ctx, uint64_t *out16)
+SNAPMI_API int snapmi_debug_profile(snapmi_ctx *ctx, uint64_t *out16)
 {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(out16, ctx->st_prof.p, 16 * sizeof(uint64_t),
                            hipMemcpyDeviceToHost));
     return SNAPMI_OK;
 }
-#endif
+)
 
 int snapmi_last_timing(snapmi_ctx *ctx, snapmi_timing *out)
 {

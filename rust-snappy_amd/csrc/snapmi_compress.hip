@@ -250,9 +250,6 @@ struct TokenSink {
         gptr o = dst + d + (incl - size);
         d += rdlane(incl, kWave - 1);
         t = 0;
-#ifdef SNAPMI_ABLATE_FLUSH
-        return; // experiment: sizes only, nothing written
-#endif
 
         // literal tag
         if (lt) {
@@ -394,27 +391,6 @@ __device__ __forceinline__ uint32_t extend_match(P src, uint32_t n,
     }
 }
 
-#ifdef SNAPMI_PROFILE
-// (SNAPMI_PROFILE=2: the boundaries do not wait for outstanding memory
-// operations - a wait is then counted where the product build has it, in the
-// phase that first needs the data)
-#if SNAPMI_PROFILE == 2
-#define TICK_WAIT()
-#else
-#define TICK_WAIT() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
-#endif
-#define TICK(i)                                                               \
-    do {                                                                      \
-        TICK_WAIT();                                                          \
-        const uint64_t _t = __builtin_readcyclecounter();                     \
-        pt[i] += _t - t_last;                                                 \
-        t_last = _t;                                                          \
-    } while (0)
-#else
-#define TICK(i)                                                               \
-    do {                                                                      \
-    } while (0)
-#endif
 
 } // namespace
 
@@ -531,15 +507,15 @@ __device__ __forceinline__ void compress_one_block(
     // wv3 is the prefetch slot: loaded one slide ahead of its first use.
     uint32_t wbase = 0x80000000u, wv0 = 0, wv1 = 0, wv2 = 0, wv3 = 0;
     const uint32_t cI = cB + 1; // offset of this lane's probe from s - 1
-#ifdef SNAPMI_PROFILE
+    PROF(
     uint64_t pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t t_last = __builtin_readcyclecounter();
     uint64_t n_batches = 0, n_copies = 0;
-#endif
+    )
     for (;;) {
-#ifdef SNAPMI_PROFILE
+        PROF(
         n_batches++;
-#endif
+        )
         TICK(0);
         uint32_t p, nextp;
         bool active = true, probe = true;
@@ -623,9 +599,9 @@ __device__ __forceinline__ void compress_one_block(
         // literal next_emit..pk (reference :250-257) + copy (:272-273)
         out.record(next_emit, pk - next_emit, pk - ck, len);
         TICK(7);
-#ifdef SNAPMI_PROFILE
+        PROF(
         n_copies++;
-#endif
+        )
         s = pk + len;
         next_emit = s;
         chain = true;
@@ -662,7 +638,7 @@ __device__ __forceinline__ void compress_one_block(
         out.flush();
     if (lane == 0)
         a.blk_size[b] = out.d;
-#ifdef SNAPMI_PROFILE
+    PROF(
     TICK(8);
     if (lane == 0 && a.prof) {
         for (int i = 0; i < 9; i++)
@@ -671,7 +647,7 @@ __device__ __forceinline__ void compress_one_block(
         atomicAdd(&a.prof[11], (unsigned long long)n_copies);
         atomicAdd(&a.prof[12], 1ull);
     }
-#endif
+    )
 }
 
 // Device-wide block ticket, one 64-bit word: low half = blocks claimed from
@@ -887,18 +863,6 @@ __global__ __launch_bounds__(kCompressWaves * 64) void k_compress_blocks(
     const uint32_t cB = lane >= 2 ? 1 + kDelta.d[lane - 2] : lane - 1;
     const uint32_t cBn = lane >= 2 ? 1 + c2 : 0; // offset of the next probe
 
-#ifdef SNAPMI_NOLOOP
-    {
-        const uint32_t b = blockIdx.x * kCompressWaves + wave;
-        if (b < nblocks)
-            compress_one_block<false>(a, b, lane, table, tbase, c2, c3, cB,
-                                      cBn);
-    }
-#elif defined(SNAPMI_STRIDE)
-    for (uint32_t b = blockIdx.x * kCompressWaves + wave; b < nblocks;
-         b += gridDim.x * kCompressWaves)
-        compress_one_block<false>(a, b, lane, table, tbase, c2, c3, cB, cBn);
-#else
     // one ticket per wavefront per block
     // (the helper's result comes back in a VGPR: re-pin it to an SGPR so the
     // whole block state stays scalar)
@@ -909,7 +873,6 @@ __global__ __launch_bounds__(kCompressWaves * 64) void k_compress_blocks(
         compress_one_block<false>(a, b, lane, table, tbase, c2, c3, cB, cBn);
         b = uni(next_ticket(a.ticket, lane, nblocks));
     }
-#endif
 }
 
 // ---------------------------------------------------------------------
@@ -1254,15 +1217,15 @@ __device__ __forceinline__ void compress_one_block_span(
     SpanSink<decltype(out)> sink;
     sink.out = &out;
     sink.emit = 0;
-#ifdef SNAPMI_PROFILE
+    PROF(
     uint64_t pt[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t t_last = __builtin_readcyclecounter();
     uint64_t n_batches = 0, n_copies = 0;
-#endif
+    )
     for (;;) {
-#ifdef SNAPMI_PROFILE
+        PROF(
         n_batches++;
-#endif
+        )
         TICK(0);
         // room for a step's tokens (at most 16 copies of a window + a long
         // match): the one place where tokens are encoded
@@ -1316,9 +1279,9 @@ __device__ __forceinline__ void compress_one_block_span(
             if (len == 16)
                 len += extend_match(msrc, n, ck + 16, pk + 16, lane);
             sink.token(pk - sink.emit, len, pk - ck);
-#ifdef SNAPMI_PROFILE
+            PROF(
             n_copies++;
-#endif
+            )
             st.s = pk + len;
             st.next_emit = st.s;
             st.chain = 1;
@@ -1377,9 +1340,6 @@ __device__ __forceinline__ void compress_one_block_span(
                 uint32_t lit;
                 rc = span_par_walk(w, st, hits, ln.mv, old, cbit, sink.emit,
                                    vh, lit, touched, at);
-#ifdef SNAPMI_ABL_NOPUSH
-                vh = 0; // (timing experiment, wrong bytes: no tokens)
-#endif
                 TICK(14);
                 const uint32_t cnt = (uint32_t)__builtin_popcountll(vh);
                 if (cnt) {
@@ -1484,7 +1444,7 @@ __device__ __forceinline__ void compress_one_block_span(
         if constexpr (kTok)
             a.ntok[b] = out.ntok;
     }
-#ifdef SNAPMI_PROFILE
+    PROF(
     TICK(8);
     if (lane == 0 && a.prof) {
         for (int i = 0; i < 9; i++)
@@ -1495,7 +1455,7 @@ __device__ __forceinline__ void compress_one_block_span(
         atomicAdd(&a.prof[11], (unsigned long long)n_copies);
         atomicAdd(&a.prof[12], 1ull);
     }
-#endif
+    )
 }
 
 // The window kernel as the match finder of the token path (k_scan_sizes +
@@ -1659,9 +1619,7 @@ __global__ __launch_bounds__(64) void k_compress_span_lds(CompressArgs a)
 // so the block kernels never see them.
 // ---------------------------------------------------------------------
 namespace {
-#ifndef SNAPMI_TINY_STAGE_OUT
 #define SNAPMI_TINY_STAGE_OUT 0 // 1: an output column in LDS (experiment)
-#endif
 template <bool kStage> struct TinyColumns {
     typedef __attribute__((address_space(3))) uint32_t l_u32;
     typedef __attribute__((address_space(3))) uint8_t l_u8;
@@ -2312,7 +2270,6 @@ __device__ __forceinline__ void match_blocks(
                               ((unsigned long long)(mend - mpos) << 17) |
                               ((unsigned long long)(mpos - mcand) << 33);
             ntok++;
-#ifndef SNAPMI_NO_CSIZE // (ablation: only valid with lane_direct_encode 0)
             {
                 // token_bytes(), short form for the usual token (literal of
                 // at most 60 bytes, copy of at most 64): the round loop is
@@ -2324,7 +2281,6 @@ __device__ __forceinline__ void match_blocks(
                 else
                     csize += tl + 3 + (tl != 0) - (tc <= 11 && to <= 2047);
             }
-#endif
             flush = (ntok & 15) == 0;
             s = mend;
             next_emit = mend;

@@ -52,7 +52,7 @@ struct snapmi_ctx {
     uint32_t n_lanes = 0;
     uint64_t lane_stride = 0;      // 16-byte entries between two lanes' tables
     bool lane_table_spread = true; // spread the tables over free memory
-    bool lane_table_high = true;   // first candidate behind a filler (snapmi_api.hip)
+    bool lane_tables_top = false;  // placed by snapmi_ctx_prepare(TOP_OF_MEMORY)
     // SNAPMI_COMPRESS=waves|lanes|both: 0 = wavefront kernel only, 1 = lane
     // kernel on large batches and the wavefront kernel on small ones
     // (default), 2 = on large batches both kernels at once, sharing one
@@ -192,9 +192,10 @@ struct snapmi_ctx {
     uint32_t lane_waves_per_cu = 6; // 24 KiB of LDS per wave
     uint32_t lane_max_waves = 0;    // test knob: cap on lane-kernel waves (0 = none)
     // placements of the lane tables that are timed before one is kept
-    // (default 10 for a full-size launch: profiles/r2_placement_probe2.txt;
-    // a candidate costs one hipMalloc and a 3 ms probe)
-    uint32_t lane_table_tries = 10;
+    // (place_lane_tables in snapmi_api.hip: spread over the budget, then
+    // packed behind that, then spread again; a candidate costs one hipMalloc
+    // and a 3 ms probe, and the driver wipes what a loser gives back)
+    uint32_t lane_table_tries = 2;
     // percent of the free device memory the lane tables (and, while a
     // placement is chosen, their candidates) may hold: the GPU may be shared
     uint32_t lane_table_budget_pct = 33;

@@ -276,23 +276,6 @@ struct B16x {
     uint64_t lo, hi;
 };
 
-#ifdef SNAPMI_PROFILE
-#define TICK(i)                                                               \
-    do {                                                                      \
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");           \
-        const uint64_t _t = __builtin_readcyclecounter();                     \
-        pt[i] += _t - t_last;                                                 \
-        t_last = _t;                                                          \
-    } while (0)
-#define COUNT(x) (x)++
-#else
-#define TICK(i)                                                               \
-    do {                                                                      \
-    } while (0)
-#define COUNT(x)                                                              \
-    do {                                                                      \
-    } while (0)
-#endif
 
 // 8 bytes at src[pos..] for a stream of avail >= 8 readable bytes; bytes at
 // or past `avail` read as zero.  Branch-free: the load address is clamped
@@ -530,9 +513,7 @@ __global__ __launch_bounds__(1024) void k_plan_decompress_c(DecompressArgs a)
 // used here).
 // ---------------------------------------------------------------------
 namespace {
-#ifndef SNAPMI_RING
 #define SNAPMI_RING 4096 // experiment builds: 8192 / 16384 (make ring_variants)
-#endif
 constexpr uint32_t kRing2 = SNAPMI_RING;
 constexpr uint32_t kWinMax = 2048;
 typedef __attribute__((address_space(3))) uint8_t l_u8;
@@ -632,10 +613,10 @@ struct Wide {
     uint32_t s, d;    // positions in src / dst
     uint32_t ring_lo; // the ring holds dst[max(ring_lo, d - 4096), d)
     Ring2 R;
-#ifdef SNAPMI_PROFILE
+    PROF(
     uint64_t n_win = 0, n_elem = 0, n_dep = 0, n_fence = 0, n_far = 0,
              n_trip = 0, n_run = 0, n_win3 = 0;
-#endif
+    )
     __device__ __forceinline__ bool too_big() const
     {
         return src_len > 0xFFE00000ull || dst_len > 0xFFFFF000ull;
@@ -721,7 +702,7 @@ __device__ __forceinline__ void close_stream(const DecompressArgs &a,
                           x.s, x.d);
         return;
     }
-#ifdef SNAPMI_PROFILE
+    PROF(
     if (lane == 0 && a.prof) {
         atomicAdd(&a.prof[7], (unsigned long long)x.n_win3);
         atomicAdd(&a.prof[8], (unsigned long long)x.n_run);
@@ -733,7 +714,7 @@ __device__ __forceinline__ void close_stream(const DecompressArgs &a,
         atomicAdd(&a.prof[14], (unsigned long long)x.n_dep);
         atomicAdd(&a.prof[15], 1ull);
     }
-#endif
+    )
     if (x.d != x.dst_len)
         SNAPMI_FAIL(SNAPMI_HEADER_MISMATCH, x.dst_len, x.d, 0);
     if (lane == 0) {
@@ -889,9 +870,9 @@ __device__ __forceinline__ bool decode_windows2(Wide &x, const uint32_t lane)
             irregular = true;
             break;
         }
-#ifdef SNAPMI_PROFILE
+        PROF(
         x.n_elem += __builtin_popcountll(K);
-#endif
+        )
         // next window's bytes: issued now, consumed after the expand
         // (plain unaligned loads while the next window lies inside the
         // input - a uniform test; the clamped form only at the stream's end)
@@ -931,17 +912,14 @@ __device__ __forceinline__ bool decode_windows2(Wide &x, const uint32_t lane)
                        : 0;
         const uint64_t M_lw =
             K &
-#ifdef SNAPMI_DEC2_ONETRIP
-            __ballot(olen <= 16) &
-#endif
             (M_litok | (~M_lit & M_src & (M_ring | M_farok)));
         const uint64_t M_far = M_lw & ~M_lit & ~M_ring; // source in HBM
         const uint64_t M_rng = M_lw & ~M_lit & M_ring;  // source in the ring
         {
             if (M_far) {
-#ifdef SNAPMI_PROFILE
+                PROF(
                 x.n_far += __builtin_popcountll(M_far);
-#endif
+                )
                 if ((M_far & __ballot(qe > R.fenced)) != 0) {
                     R.fence_for(0xFFFFFFFFu);
                     COUNT(x.n_fence);
@@ -965,9 +943,6 @@ __device__ __forceinline__ bool decode_windows2(Wide &x, const uint32_t lane)
             // window whose output does (uniform)
             const bool wraps = (d & (kRing2 - 1)) + W > kRing2;
             for (uint32_t c = top;; c -= 16) {
-#ifdef SNAPMI_DEC2_NOTRIP
-                break;
-#endif
                 const uint64_t M_act = c == 0 ? M_lw : M_lw & __ballot(c < olen);
                 if (M_act != 0) {
                     COUNT(x.n_trip);
@@ -989,12 +964,7 @@ __device__ __forceinline__ bool decode_windows2(Wide &x, const uint32_t lane)
                         // (one unaligned 16-byte read costs the LDS one
                         // cycle per lane, two 8-byte reads two:
                         // tests/hw/lds_cost.hip; it may run into the mirror)
-#ifdef SNAPMI_DEC2_RD64
-                        v.lo = lds_ld64(rg + ((q + c) & (kRing2 - 1)));
-                        v.hi = lds_ld64(rg + ((q + c + 8) & (kRing2 - 1)));
-#else
                         __builtin_memcpy(&v, rg + ((q + c) & (kRing2 - 1)), 16);
-#endif
                     }
                     const uint32_t wa = (dstp + c) & (kRing2 - 1);
                     // (rare) the element's own bytes wrap around the ring's
@@ -1022,9 +992,6 @@ __device__ __forceinline__ bool decode_windows2(Wide &x, const uint32_t lane)
         }
         // ---- 5. the sweep: elements that depend on this window -------------
         uint64_t dep = K & ~M_lw;
-#ifdef SNAPMI_DEC2_NOSWEEP
-        dep = 0;
-#endif
         while (dep) {
             COUNT(x.n_dep);
             const uint32_t i = (uint32_t)__builtin_ctzll(dep);
@@ -1078,9 +1045,7 @@ __device__ __forceinline__ bool decode_windows2(Wide &x, const uint32_t lane)
         d += W;
         s += cur;
         w = w_next;
-#ifndef SNAPMI_DEC2_NOFLUSH
         R.flush_chunks(d);
-#endif
     }
     x.s = s;
     x.d = d;
@@ -1123,9 +1088,7 @@ __device__ __forceinline__ bool decode_windows2(Wide &x, const uint32_t lane)
 // loads can leave the input; the last bytes of a stream (and streams shorter
 // than that) are decode_windows2's.  True: something irregular.
 // ---------------------------------------------------------------------
-#ifndef SNAPMI_G3
 #define SNAPMI_G3 4
-#endif
 constexpr uint32_t kG3 = SNAPMI_G3;
 static_assert(kG3 == 2 || kG3 == 4,
               "positions in a window are masked with 64 kG3 - 1; 8 groups do "
@@ -1286,9 +1249,9 @@ __device__ __forceinline__ bool decode_windows3(Wide &x, const uint32_t lane,
             irregular = true;
             break;
         }
-#ifdef SNAPMI_PROFILE
+        PROF(
         x.n_elem += nK;
-#endif
+        )
         // next window's tags: issued now, consumed after the copy step
         uint32_t tgn[kG3];
         const bool have_next = slen - (s + cur) >= kTail3;
@@ -1344,9 +1307,9 @@ __device__ __forceinline__ bool decode_windows3(Wide &x, const uint32_t lane,
         // that latency is what a wave waits for most - all of them at once.
         B16x v0 = lit16;
         if (M_far) {
-#ifdef SNAPMI_PROFILE
+            PROF(
             x.n_far += __builtin_popcountll(M_far);
-#endif
+            )
             // sources in HBM must be completed stores
             if ((M_far & __ballot(qe > R.fenced)) != 0) {
                 R.fence_for(0xFFFFFFFFu);
@@ -1606,9 +1569,7 @@ __device__ __forceinline__ void decode_tiny(const DecompressArgs &a,
 // 8 waves per SIMD (64 VGPRs, 5 KiB of LDS each): a window is a chain of
 // LDS / HBM round trips, and two more waves to switch to are worth more than
 // a few spilled dwords (36.0 -> 32.2 ms at cfg2 for the second generation).
-#ifndef SNAPMI_DEC2_WAVES
 #define SNAPMI_DEC2_WAVES 8
-#endif
 __attribute__((amdgpu_waves_per_eu(SNAPMI_DEC2_WAVES, SNAPMI_DEC2_WAVES)))
 __global__ __launch_bounds__(64) void k_decompress_streams3(DecompressArgs a)
 {
@@ -2104,12 +2065,8 @@ __device__ __forceinline__ void stream_head(const StreamArgs &a, const uint32_t 
 // 2.0 ms; a wavefront is bound by the latency of its own dependent chain
 // (alone on the chip or not), the lanes of a round are busy to ~55 %.
 // ---------------------------------------------------------------------
-#ifndef SNAPMI_HOP_LINE
 #define SNAPMI_HOP_LINE 32
-#endif
-#ifndef SNAPMI_HOP_ITERS
 #define SNAPMI_HOP_ITERS 12
-#endif
 constexpr uint32_t kHopLine = SNAPMI_HOP_LINE; // bytes of a line
 constexpr uint32_t kHopLines = 4;              // lines of a lane's ring
 constexpr uint32_t kHopFetch = 2;              // lines fetched per round
@@ -2304,9 +2261,7 @@ __device__ __forceinline__ void hop_pool(const HopShared &h, uint32_t npool,
             const uint32_t endR = w.endR, stopOut = w.stopOut;
             const uint32_t capR = w.stopR < h.lastR ? w.stopR : h.lastR;
             const uint32_t segm = h.seg - kEntry; // landing zone: none set
-#ifndef SNAPMI_HOP_UNROLL
 #define SNAPMI_HOP_UNROLL SNAPMI_HOP_ITERS
-#endif
             for (uint32_t it = 0; it < kHopIters; it += SNAPMI_HOP_UNROLL) {
                 // (one look at "can anyone hop" per SNAPMI_HOP_UNROLL hops - by
                 // default per round: a lane that cannot, idles through them.

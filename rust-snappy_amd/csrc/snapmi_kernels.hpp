@@ -7,6 +7,7 @@
 
 #include "snapmi.h"
 #include "snapmi_tiny.hpp"
+#include "snapmi_profile.hpp"
 
 namespace snapmi {
 
@@ -63,10 +64,8 @@ constexpr uint32_t kCompressWaves = 5;
 // ... of the window kernel for blocks of at most 8 KiB (16 KiB tables)
 constexpr uint32_t kSmallTableWaves = 10;
 // k_match_both: wavefronts per CU, and how many of them are the lane kernel's
-#ifndef SNAPMI_BOTH_WAVES
 #define SNAPMI_BOTH_WAVES 6
 #define SNAPMI_BOTH_LANE_WAVES 4
-#endif
 constexpr uint32_t kBothWaves = SNAPMI_BOTH_WAVES,
                    kBothLaneWaves = SNAPMI_BOTH_LANE_WAVES;
 // token slots per block: at most 16385 tokens (every token but the last ends

@@ -49,7 +49,7 @@ def compress_device(ctx, d_in, want_index=False):
     chunks = (n + MAX_BLOCK_SIZE - 1) // MAX_BLOCK_SIZE
     index = (torch.zeros(chunks + 1, dtype=torch.int64, device=dev)
              if want_index else None)
-    rc = _lib.load().snapmi_frame_compress(
+    rc = _lib.of(ctx).snapmi_frame_compress(
         ctx._h, C.c_void_p(d_in.data_ptr()) if n else None, n,
         C.c_void_p(out.data_ptr()), cap, C.c_void_p(out_len.data_ptr()),
         C.c_void_p(index.data_ptr()) if index is not None else None)
@@ -63,7 +63,7 @@ def decompress_device(ctx, d_in, n_in, index=None, out_cap=None):
     """Frame-decompress d_in[:n_in]; returns (output tensor, length).
     Raises snap.Error with the reference's variant and fields."""
     dev = d_in.device
-    L = _lib.load()
+    L = _lib.of(ctx)
     out_len = torch.zeros(1, dtype=torch.int64, device=dev)
     err = torch.zeros(32, dtype=torch.uint8, device=dev)
     n_idx = (index.numel() - 1) if index is not None else 0
@@ -106,7 +106,7 @@ def compress_chunks_device(ctx, d_in, chunk_lens, ident=True):
     dev = d_in.device
     out = torch.empty(max(cap, 16), dtype=torch.uint8, device=dev)
     out_len = torch.zeros(1, dtype=torch.int64, device=dev)
-    rc = _lib.load().snapmi_frame_compress_chunks(
+    rc = _lib.of(ctx).snapmi_frame_compress_chunks(
         ctx._h, C.c_void_p(d_in.data_ptr()) if n else None,
         lens.ctypes.data_as(C.c_void_p), n, 0 if ident else 1,
         C.c_void_p(out.data_ptr()), cap, C.c_void_p(out_len.data_ptr()), None)
@@ -154,7 +154,7 @@ def decompress_batch_device(ctx, d_in, n_in, n_chunks, index=None,
     out_len = torch.zeros(1, dtype=torch.int64, device=dev)
     err = torch.zeros(32, dtype=torch.uint8, device=dev)
     st = (C.c_uint8 * 10)(*stale) if stale is not None else None
-    rc = _lib.load().snapmi_frame_decompress_ex(
+    rc = _lib.of(ctx).snapmi_frame_decompress_ex(
         ctx._h, C.c_void_p(d_in.data_ptr()) if n_in else None, n_in,
         C.c_void_p(out.data_ptr()), cap, C.c_void_p(out_len.data_ptr()),
         C.c_void_p(err.data_ptr()),
@@ -172,7 +172,7 @@ def decompress_batch_device(ctx, d_in, n_in, n_chunks, index=None,
 def encode_host(ctx, data, chunk_lens, ident=True):
     """snapmi_frame_encode_host: host bytes -> framed bytes, chunk boundaries
     given by the caller."""
-    L = _lib.load()
+    L = _lib.of(ctx)
     lens = np.ascontiguousarray(chunk_lens, dtype=np.uint32)
     n = int(lens.size)
     cap = L.snapmi_frame_encode_bound(len(data), n)
@@ -226,7 +226,7 @@ def _address(buf):
 def encode_host_into(ctx, buf, chunk_lens, out, ident=True):
     """snapmi_frame_encode_host from any buffer into the HostBuffer `out`
     (no copies on the Python side); returns the bytes written."""
-    L = _lib.load()
+    L = _lib.of(ctx)
     lens = np.ascontiguousarray(chunk_lens, dtype=np.uint32)
     addr, n, keep = _address(buf)
     written = C.c_size_t(0)
@@ -244,7 +244,7 @@ def decode_host(ctx, data, out, continuation, final, stale):
     """snapmi_frame_decode_host: decode the whole chunks at the start of
     `data` (bytes) into the bytearray `out`; returns (written, consumed,
     Error or None).  `stale`: bytearray(10) of decoder state, updated."""
-    L = _lib.load()
+    L = _lib.of(ctx)
     written, consumed = C.c_size_t(0), C.c_size_t(0)
     err = _lib.SnapmiError()
     flags = (1 if continuation else 0) | (2 if final else 0)
@@ -307,7 +307,7 @@ def crc32c_masked(ctx, data):
     ptrs = torch.tensor([buf.data_ptr()], dtype=torch.int64, device=dev)
     lens = torch.tensor([len(data)], dtype=torch.int64, device=dev)
     out = torch.zeros(1, dtype=torch.int32, device=dev)
-    rc = _lib.load().snapmi_crc32c_masked_batch(
+    rc = _lib.of(ctx).snapmi_crc32c_masked_batch(
         ctx._h, C.c_void_p(ptrs.data_ptr()), C.c_void_p(lens.data_ptr()),
         C.c_void_p(out.data_ptr()), 1)
     if rc:

@@ -24,19 +24,26 @@ def _raise(ctx, rc, err=None):
     if rc >= 100:
         msg = None
         if ctx is not None and ctx._h:
-            msg = _lib.load().snapmi_last_error(ctx._h).decode()
+            msg = _lib.of(ctx).snapmi_last_error(ctx._h).decode()
         raise DeviceError(rc, message=msg or "no usable HIP device")
     if err is not None and err.kind == rc:
         raise Error(rc, err.a, err.b, err.c)
     raise Error(rc)
 
 
-class Context:
-    """snapmi_ctx: one HIP device + stream + device scratch."""
+class TestOnlyOption(RuntimeError):
+    """set_test_option on a context of the product library (the knobs of
+    include/snapmi_test.h exist in libsnapmi_test.so only)."""
+    __test__ = False
 
-    def __init__(self, device=0, stream=None):
+
+class Context:
+    """snapmi_ctx: one HIP device + stream + device scratch.  `lib`: the
+    loaded library that makes it (default: the process's, _lib.load())."""
+
+    def __init__(self, device=0, stream=None, lib=None):
         self._h = None
-        L = _lib.load()
+        L = self._L = lib or _lib.load()
         h = C.c_void_p()
         rc = L.snapmi_ctx_create(int(device), stream, C.byref(h))
         if rc != 0:
@@ -47,7 +54,7 @@ class Context:
 
     def close(self):
         if self._h:
-            _lib.load().snapmi_ctx_destroy(self._h)
+            self._L.snapmi_ctx_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -64,7 +71,7 @@ class Context:
 
     def set_option(self, name, value):
         """snapmi_ctx_set_option: tuning knobs (never change results)."""
-        rc = _lib.load().snapmi_ctx_set_option(self._h, name.encode(),
+        rc = self._L.snapmi_ctx_set_option(self._h, name.encode(),
                                                int(value))
         if rc:
             _raise(self, rc)
@@ -72,9 +79,9 @@ class Context:
     def set_test_option(self, name, value):
         """snapmi_ctx_set_test_option (include/snapmi_test.h): knobs of the
         test suite and the experiment drivers."""
-        L = _lib.load()
+        L = self._L
         if not hasattr(L, "snapmi_ctx_set_test_option"):
-            raise RuntimeError(
+            raise TestOnlyOption(
                 "set_test_option: this is the product library; the test "
                 "knobs live in libsnapmi_test.so (SNAPMI_TESTING=1)")
         rc = L.snapmi_ctx_set_test_option(self._h, name.encode(),
@@ -82,22 +89,36 @@ class Context:
         if rc:
             _raise(self, rc)
 
+    def prepare(self, blocks, top_of_memory=False):
+        """snapmi_ctx_prepare: the lane tables of a batch of `blocks` 64 KiB
+        blocks now; top_of_memory: SNAPMI_PREPARE_TOP_OF_MEMORY (holds the
+        whole device for a moment - see include/snapmi.h)."""
+        rc = self._L.snapmi_ctx_prepare(self._h, int(blocks),
+                                        1 if top_of_memory else 0)
+        if rc:
+            _raise(self, rc)
+
+    def table_probe_log(self):
+        """snapmi_table_probe_log: what the last placement of the lane tables
+        probed, held, kept and took."""
+        return self._L.snapmi_table_probe_log(self._h).decode()
+
     @property
     def stream(self):
-        return _lib.load().snapmi_ctx_stream(self._h)
+        return self._L.snapmi_ctx_stream(self._h)
 
     def synchronize(self):
-        rc = _lib.load().snapmi_ctx_synchronize(self._h)
+        rc = self._L.snapmi_ctx_synchronize(self._h)
         if rc:
             _raise(self, rc)
 
     def last_kernel(self):
         """snapmi_last_kernel: the dominant kernel of the last batch call."""
-        return _lib.load().snapmi_last_kernel(self._h).decode()
+        return self._L.snapmi_last_kernel(self._h).decode()
 
     def last_timing(self):
         t = _lib.SnapmiTiming()
-        rc = _lib.load().snapmi_last_timing(self._h, C.byref(t))
+        rc = self._L.snapmi_last_timing(self._h, C.byref(t))
         if rc:
             _raise(self, rc)
         return {"plan_ms": t.plan_ms, "codec_ms": t.codec_ms,
@@ -145,7 +166,7 @@ class Encoder:
         out = (C.c_char * len(output)).from_buffer(output)
         n = C.c_size_t(0)
         err = _lib.SnapmiError()
-        rc = _lib.load().snapmi_raw_compress(self.ctx._h, data, len(data),
+        rc = _lib.of(self.ctx).snapmi_raw_compress(self.ctx._h, data, len(data),
                                              out, len(output), C.byref(n),
                                              C.byref(err))
         if rc:
@@ -173,7 +194,7 @@ class Decoder:
             output if len(output) else bytearray(1))
         n = C.c_size_t(0)
         err = _lib.SnapmiError()
-        rc = _lib.load().snapmi_raw_decompress(self.ctx._h, data, len(data),
+        rc = _lib.of(self.ctx).snapmi_raw_decompress(self.ctx._h, data, len(data),
                                                out, len(output), C.byref(n),
                                                C.byref(err))
         if rc:
@@ -203,7 +224,7 @@ def compress_batch(ctx, in_ptrs, in_lens, out_ptrs, out_caps, out_lens,
     h = None
     if host_in_lens is not None:
         h = C.c_void_p(host_in_lens.data_ptr())
-    rc = _lib.load().snapmi_compress_batch(
+    rc = _lib.of(ctx).snapmi_compress_batch(
         ctx._h, _ptr(in_ptrs), _ptr(in_lens), h, _ptr(out_ptrs),
         _ptr(out_caps), _ptr(out_lens), _ptr(errs), n)
     if rc:
@@ -213,7 +234,7 @@ def compress_batch(ctx, in_ptrs, in_lens, out_ptrs, out_caps, out_lens,
 def decompress_batch(ctx, in_ptrs, in_lens, out_ptrs, out_caps, out_lens,
                      errs=None):
     n = in_ptrs.numel()
-    rc = _lib.load().snapmi_decompress_batch(
+    rc = _lib.of(ctx).snapmi_decompress_batch(
         ctx._h, _ptr(in_ptrs), _ptr(in_lens), _ptr(out_ptrs), _ptr(out_caps),
         _ptr(out_lens), _ptr(errs), n)
     if rc:
@@ -224,7 +245,7 @@ def decompress_stream(ctx, d_in, n_in, d_out, out_len, err):
     """ONE long raw stream (uint8 CUDA tensor d_in[:n_in]) decoded by many
     wavefronts into d_out; out_len: int64[1], err: uint8[32] CUDA tensors.
     Same results and errors as decompress_batch with one stream."""
-    rc = _lib.load().snapmi_decompress_stream(
+    rc = _lib.of(ctx).snapmi_decompress_stream(
         ctx._h, _ptr(d_in), int(n_in), _ptr(d_out), d_out.numel(),
         _ptr(out_len), _ptr(err))
     if rc:
@@ -234,12 +255,12 @@ def decompress_stream(ctx, d_in, n_in, d_out, out_len, err):
 def stream_decode_path(ctx):
     """0 = the last decompress_stream ran as pieces on many wavefronts, 1 =
     sequential path, -1 = none yet."""
-    return _lib.load().snapmi_stream_decode_path(ctx._h)
+    return _lib.of(ctx).snapmi_stream_decode_path(ctx._h)
 
 
 def decompress_len_batch(ctx, in_ptrs, in_lens, out_lens, errs=None):
     n = in_ptrs.numel()
-    rc = _lib.load().snapmi_decompress_len_batch(
+    rc = _lib.of(ctx).snapmi_decompress_len_batch(
         ctx._h, _ptr(in_ptrs), _ptr(in_lens), _ptr(out_lens), _ptr(errs), n)
     if rc:
         _raise(ctx, rc)

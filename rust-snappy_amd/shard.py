@@ -90,7 +90,7 @@ class Comm:
 
     def __init__(self, ctx, ident, rank, world):
         from . import _lib, raw
-        self._L, self._raw, self.ctx = _lib.load(), raw, ctx
+        self._L, self._raw, self.ctx = _lib.of(ctx), raw, ctx
         self.rank, self.world = rank, world
         h = C.c_void_p()
         rc = self._L.snapmi_comm_init(ctx._h, bytes(ident), rank, world,
@@ -105,7 +105,7 @@ class Comm:
         address as an int); the communicator stays the host's."""
         from . import _lib, raw
         self = cls.__new__(cls)
-        self._L, self._raw, self.ctx = _lib.load(), raw, ctx
+        self._L, self._raw, self.ctx = _lib.of(ctx), raw, ctx
         self.rank, self.world = rank, world
         h = C.c_void_p()
         rc = self._L.snapmi_comm_wrap(ctx._h, C.c_void_p(nccl_comm), rank,

@@ -5,11 +5,15 @@ import pytest
 
 import os
 
-# the suite runs on the TEST build of the library (libsnapmi_test.so: the same
+# The process loads the TEST build of the library (libsnapmi_test.so: the same
 # sources with the knobs of include/snapmi_test.h and the cross-check kernels
-# compiled in); rust-snappy_amd/_lib.py picks it when SNAPMI_TESTING is set.
-# The product library (libsnapmi.so) is what smoke(), bench.py and the tools
-# load, and tests/test_abi_cpu.py checks what it exports.
+# compiled in; rust-snappy_amd/_lib.py picks it when SNAPMI_TESTING is set) -
+# and the SHIPPED library beside it (libsnapmi.so, _lib.load_product()): the
+# "product*" parameters of the ctx / cctx fixtures below make their contexts
+# with that one, so every test written against those fixtures - the
+# reference's suite, the bounds, the parity files - also runs through the
+# library that smoke(), bench.py and the tools load.  A test that needs a
+# knob of the test build is skipped there (TestOnlyOption).
 os.environ.setdefault("SNAPMI_TESTING", "1")
 
 ROOT = Path(__file__).resolve().parent.parent
@@ -21,6 +25,27 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by gpurun)")
 
 
+@pytest.hookimpl(hookwrapper=True)
+def pytest_pyfunc_call(pyfuncitem):
+    """A test that asks a product-library context for a test-build knob is
+    skipped (it is covered on the test build's parameters)."""
+    outcome = yield
+    if outcome.excinfo is not None:
+        from rust_snappy_amd.raw import TestOnlyOption
+        if issubclass(outcome.excinfo[0], TestOnlyOption):
+            try:
+                pytest.skip("needs a knob of the test build; this parameter "
+                            "runs the shipped library")
+            except BaseException:  # noqa: BLE001 - the Skipped exception
+                outcome.force_exception(sys.exc_info()[1])
+
+
+def product_context():
+    """A context of the SHIPPED library (libsnapmi.so) in this process."""
+    import rust_snappy_amd as R
+    return R.raw.Context(0, lib=R._lib.load_product())
+
+
 @pytest.fixture(scope="session")
 def built():
     import __graft_entry__ as g
@@ -28,18 +53,22 @@ def built():
     return True
 
 
-@pytest.fixture(scope="session", params=["dec3", "dec2"])
+@pytest.fixture(scope="session", params=["dec3", "dec2", "product"])
 def ctx(request, built):
     """A context per decoder kernel: k_decompress_streams3 (element per lane,
     128-byte windows; the default) and the second-generation
     k_decompress_streams2 kept as a cross-check, so every decoder parity test
-    runs through both."""
+    runs through both - and "product": the shipped library with its default
+    options."""
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import rust_snappy_amd as R
-    c = R.raw.Context(0)
-    c.set_option("decode_kernel", {"dec3": 3, "dec2": 2}[request.param])
+    if request.param == "product":
+        c = product_context()
+    else:
+        c = R.raw.Context(0)
+        c.set_option("decode_kernel", {"dec3": 3, "dec2": 2}[request.param])
     yield c
     c.close()
 
@@ -48,7 +77,9 @@ def ctx(request, built):
                 params=["spans", "spans_lds", "waves", "waves_lds", "lanes",
                         "lanes_segmented", "lanes_overlap", "both",
                         "spans_match", "small_tables", "small_tables_lanes",
-                        "coresident"])
+                        "coresident", "product", "product-lanes",
+                        "product-spans_lds", "product-small_tables",
+                        "product-coresident"])
 def cctx(request, built):
     """A context per compressor kernel: the wavefront-per-block kernels (window
     steps and, as the cross-check, one copy per step; five tables per CU and
@@ -62,12 +93,25 @@ def cctx(request, built):
     few there are, the larger blocks to the window kernel as
     match finder or to the lane kernel (both skip the other classes' blocks)
     - the configurations above switch those kernels off, so that they keep
-    testing the kernels they name on blocks of every size."""
+    testing the kernels they name on blocks of every size.
+    "product": the SHIPPED library (libsnapmi.so) with its default options -
+    the routing a user gets; "product-<name>": the shipped library forced
+    into configuration <name> (those that need no knob of the test build)."""
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import rust_snappy_amd as R
-    c = R.raw.Context(0)
+    if request.param == "product":
+        c = product_context()
+        yield c
+        c.close()
+        return
+    product = request.param.startswith("product-")
+    if product:
+        request = type("P", (), {"param": request.param[len("product-"):]})
+        c = product_context()
+    else:
+        c = R.raw.Context(0)
     c.set_option("compress_mode", {"spans": 0, "spans_lds": 0, "waves": 0,
                                    "waves_lds": 0, "lanes": 1,
                                    "lanes_segmented": 1, "lanes_overlap": 1,
@@ -112,8 +156,9 @@ def cctx(request, built):
         # the plain kernel covered)
         c.set_option("lane_speculate", 0)
     # matched in two halves, the first half encoded on the side stream
-    c.set_test_option("lane_overlap_encode",
-                 2 if request.param == "lanes_overlap" else 0)
+    if not product:
+        c.set_test_option("lane_overlap_encode",
+                          2 if request.param == "lanes_overlap" else 0)
     yield c
     c.close()
 
