@@ -119,8 +119,8 @@ impl fmt::Display for Error {
             ),
             Error::StreamHeaderMismatch { ref bytes } => write!(
                 f,
-                "snappy: corrupt input (expected sNaPpY stream header but got {:?})",
-                bytes
+                "snappy: corrupt input (expected sNaPpY stream header but got {})",
+                escape(&**bytes) // reference :304-309
             ),
             Error::UnsupportedChunkType { byte } => write!(
                 f,
@@ -144,4 +144,13 @@ impl fmt::Display for Error {
             ),
         }
     }
+}
+
+// reference :337-340: the bytes as std::ascii::escape_default prints them
+fn escape(bytes: &[u8]) -> String {
+    bytes
+        .iter()
+        .flat_map(|&b| std::ascii::escape_default(b))
+        .map(|b| b as char)
+        .collect()
 }

@@ -68,3 +68,74 @@ def test_debug_form_and_equality():
     # device failures are not snap::Error variants: their own text
     d = R.error.DeviceError(100, message="no usable HIP device")
     assert "Device" in str(d) and "no usable HIP device" in str(d)
+
+
+def _rust_display_arms(text):
+    """The arms of `impl fmt::Display for Error` in a Rust source: a list of
+    (variant, header flag or None, format string, argument expressions) in
+    source order.  Handles `write!(f, "..", a, b)` with the string continued
+    over lines by a trailing backslash."""
+    import re
+    body = text[text.index("impl fmt::Display for Error"):]
+    arms = []
+    pat = re.compile(
+        r"Error::(\w+)\s*(\{[^}]*\})?\s*=>\s*(?:\{\s*)?write!\(\s*f,\s*"
+        r"\"((?:[^\"\\]|\\.)*)\"\s*((?:,(?:[^;()]|\([^()]*\))*?)?)\s*\)",
+        re.S)
+    for m in pat.finditer(body):
+        fmt = re.sub(r"\\\n\s*", "", m.group(3))     # line continuations
+        args = [a.strip() for a in m.group(4).split(",") if a.strip()]
+        args = [re.sub(r"\s*//.*", "", a).strip() for a in args]
+        header = None
+        if m.group(2) and "header:" in m.group(2):
+            header = "true" in m.group(2)
+        arms.append((m.group(1), header, fmt, args))
+    return arms
+
+
+def test_shim_display_is_the_references_and_the_c_abis_text(built):
+    """shim/src/error.rs has never met a compiler; what can be pinned without
+    one: every arm of its `impl fmt::Display for Error` - the format string
+    and the number of arguments - equals what rust-snappy_amd/error.py and
+    snapmi_error_string print for the same variant (both tested against the
+    reference's text above), and StreamHeaderMismatch goes through
+    std::ascii::escape_default like the reference's (src/error.rs:304-309,
+    337-340), not through {:?} of a Vec<u8> (round 5's divergence)."""
+    import ctypes as C
+    import re
+    from conftest import ROOT
+    from rust_snappy_amd import _lib
+    L = _lib.load()
+    text = (ROOT / "shim" / "src" / "error.rs").read_text()
+    arms = _rust_display_arms(text)
+    kinds = ["TooBig", "BufferTooSmall", "Empty", "Header", "HeaderMismatch",
+             "Literal", "CopyRead", "CopyWrite", "Offset", "StreamHeader",
+             "StreamHeaderMismatch", "UnsupportedChunkType",
+             "UnsupportedChunkLength", "UnsupportedChunkLength", "Checksum"]
+    assert [a[0] for a in arms] == kinds, [a[0] for a in arms]
+    probe = (1234567, 89, 4321)              # distinct values per field
+    for variant, header, fmt, args in arms:
+        kind = kinds.index(variant) + 1 if variant != "Checksum" else 14
+        if variant == "UnsupportedChunkLength":
+            kind = 13
+        assert fmt.count("{}") == len(args), (variant, fmt, args)
+        assert "{:?}" not in fmt, (variant, fmt)
+        if variant == "StreamHeaderMismatch":
+            assert re.fullmatch(r"escape\(&\*\*bytes\)", args[0]), args
+            a = int.from_bytes(b"sNaP\x00\n", "little")
+            vals, want_args = (a, 0, 0), ["sNaP\\x00\\n"]
+        elif variant == "UnsupportedChunkLength":
+            vals, want_args = (probe[0], 1 if header else 0, 0), [probe[0]]
+        else:
+            vals, want_args = probe, list(probe[:len(args)])
+        want = fmt
+        for v in want_args:
+            want = want.replace("{}", str(v), 1)
+        e = E(kind, *vals)
+        assert e.display() == want, (variant, e.display(), want)
+        err = _lib.SnapmiError(kind, 0, *vals)
+        buf = C.create_string_buffer(512)
+        n = L.snapmi_error_string(C.byref(err), buf, 512)
+        assert buf.value.decode() == want and n == len(want), variant
+    assert "fn escape(bytes: &[u8]) -> String" in text and \
+        "escape_default" in text
