@@ -135,3 +135,73 @@ def test_foreign_encoder_streams():
         assert O.decompress(stream, len(want)) == want
         if O.libsnappy() is not None:
             assert O.libsnappy_uncompress(stream) == want
+
+
+def _port_fast():
+    import ctypes as C
+    L = O.lib()
+    L.snapf_max_compressed_length.restype = C.c_size_t
+    L.snapf_max_compressed_length.argtypes = [C.c_size_t]
+
+    def compress(data):
+        cap = L.snapf_max_compressed_length(len(data))
+        out = C.create_string_buffer(max(cap, 1))
+        n = C.c_size_t(cap)
+        rc = L.snapf_compress(bytes(data), C.c_size_t(len(data)), out,
+                              C.byref(n))
+        return rc, out.raw[:n.value]
+
+    def uncompress(data, cap):
+        out = C.create_string_buffer(max(cap, 1))
+        n = C.c_size_t(cap)
+        rc = L.snapf_uncompress(bytes(data), C.c_size_t(len(data)), out,
+                                C.byref(n))
+        return rc, out.raw[:n.value] if rc == 0 else b""
+    return compress, uncompress
+
+
+def test_port_fast_computes_the_oracles_results():
+    """oracle/snappy_port_fast.c is the restatement WITH the reference's fast
+    paths (16-byte blind copies src/compress.rs:440-453, src/decompress.rs:
+    170-183; tag table and the three copy strategies :233-343) that bench.py's
+    cpu_baseline times; a timing of wrong results would be worthless, so: its
+    bytes are the oracle's on the corpus, the golden vector, structured and
+    random inputs and the foreign-encoder streams, and it refuses exactly
+    what the oracle refuses (every error KAT, the baddata files, truncations
+    of a good stream, a short output buffer)."""
+    import foreign
+    compress, uncompress = _port_fast()
+    rng = random.Random(606)
+    inputs = [d for _, d in O.corpus_round()] + [
+        (O.CORPUS / "Mark.Twain-Tom.Sawyer.txt").read_bytes(), b"", b"a",
+        b"a" * 120, kats.RANDOM1, kats.RANDOM2, kats.RANDOM3, kats.RANDOM4]
+    inputs += kats.small_copy_inputs() + kats.small_regular_inputs()[::5]
+    for _ in range(300):
+        alpha = rng.choice([1, 2, 3, 4, 16, 256])
+        n = rng.choice([0, 1, 15, 16, 17, 18, 31, 32, 33, 300, 5000, 65535,
+                        65536, 65537, rng.randrange(0, 150000)])
+        inputs.append(bytes(rng.choices(range(alpha), k=n)))
+    for d in inputs:
+        rc, c = compress(d)
+        assert rc == 0 and c == O.compress(d), len(d)
+        rc, back = uncompress(c, len(d))
+        assert rc == 0 and back == d, len(d)
+        if len(d) > 1:   # a short output buffer: BufferTooSmall, like :84-90
+            assert uncompress(c, len(d) - 1)[0] == 2
+    for stream, want in foreign.cases():
+        rc, back = uncompress(stream, len(want))
+        assert rc == 0 and back == want
+    for name, data, want, bad_header in kats.ERROR_KATS:
+        rc, _ = uncompress(data, 1 << 16)
+        assert rc != 0, name
+    for name in ("baddata1.snappy", "baddata2.snappy", "baddata3.snappy"):
+        assert uncompress((O.CORPUS / name).read_bytes(), 1 << 20)[0] != 0
+    good = O.compress((O.CORPUS / "html").read_bytes())
+    for cut in list(range(0, 64)) + [len(good) // 2, len(good) - 1]:
+        piece = good[:cut]
+        try:
+            O.decompress(piece, 102400)
+            ok = True
+        except O.SnapError:
+            ok = False
+        assert (uncompress(piece, 102400)[0] == 0) == ok, cut
