@@ -65,6 +65,29 @@ size_t host_varint(const uint8_t *p, size_t n, uint64_t *value)
 } // namespace
 
 namespace snapmi {
+// the lane tables back to the device: a hipMalloc region, or physical chunks
+// mapped into one address range (place_lane_tables)
+static void free_lane_tables(snapmi_ctx *ctx)
+{
+    if (!ctx->lane_tables.p)
+        return;
+    if (ctx->lane_va_bytes) {
+        (void)hipMemUnmap(ctx->lane_tables.p, ctx->lane_va_bytes);
+        for (auto h : ctx->lane_chunks)
+            (void)hipMemRelease(h);
+        (void)hipMemAddressFree(ctx->lane_tables.p, ctx->lane_va_bytes);
+        ctx->lane_chunks.clear();
+        ctx->lane_va_bytes = 0;
+    } else {
+        (void)hipFree(ctx->lane_tables.p);
+    }
+    ctx->lane_tables.p = nullptr;
+    ctx->lane_tables.cap = 0;
+    ctx->n_lanes = 0;
+}
+} // namespace snapmi
+
+namespace snapmi {
 // option release_scratch: the compressor's per-batch scratch goes back to
 // the allocator.  Only behind a synchronisation of ctx->stream (nothing of a
 // batch is in flight): snapmi_ctx_synchronize and the scalar / libsnappy
@@ -250,6 +273,7 @@ void snapmi_ctx_destroy(snapmi_ctx *ctx)
         (void)hipHostFree((void *)ctx->h_mail);
     if (ctx->h_ratio)
         (void)hipHostFree((void *)ctx->h_ratio);
+    snapmi::free_lane_tables(ctx);
     for (DevBuf *b : {&ctx->blk_first, &ctx->slot_first, &ctx->blk_size,
                       &ctx->blk_off, &ctx->slots, &ctx->plan_part,
                       &ctx->st_in, &ctx->st_out,
@@ -257,7 +281,7 @@ void snapmi_ctx_destroy(snapmi_ctx *ctx)
                       &ctx->order, &ctx->fr_tables, &ctx->fr_desc,
                       &ctx->fr_meta, &ctx->fr_scan, &ctx->fr_slots,
                       &ctx->fr_chunk_off,
-                      &ctx->tokens, &ctx->ntok, &ctx->lane_tables,
+                      &ctx->tokens, &ctx->ntok,
                       &ctx->lane_epochs, &ctx->sd_tables, &ctx->sd_desc,
                       &ctx->bl_modes, &ctx->bl_list, &ctx->bl_descs,
                       &ctx->bl_order})
@@ -408,10 +432,7 @@ int snapmi_ctx_set_test_option(snapmi_ctx *ctx, const char *name,
         // drop the tables so the next launch places new ones
         if (ctx->lane_tables.p) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            HIP_TRY(ctx, hipFree(ctx->lane_tables.p));
-            ctx->lane_tables.p = nullptr;
-            ctx->lane_tables.cap = 0;
-            ctx->n_lanes = 0;
+            snapmi::free_lane_tables(ctx);
         }
     } else if (strcmp(name, "lane_epoch_preset") == 0 && value >= -1 &&
              value <= 0xFFFF)
@@ -774,10 +795,7 @@ static int place_lane_tables(snapmi_ctx *ctx, uint32_t lanes,
     const size_t tbytes = (size_t)kMaxTable * 16;
     if (ctx->lane_tables.p) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        HIP_TRY(ctx, hipFree(ctx->lane_tables.p));
-        ctx->lane_tables.p = nullptr;
-        ctx->lane_tables.cap = 0;
-        ctx->n_lanes = 0;
+        free_lane_tables(ctx);
     }
     if ((rc = reserve(ctx, ctx->lane_epochs, (size_t)lanes * sizeof(uint32_t))))
         return rc;
@@ -837,6 +855,124 @@ static int place_lane_tables(snapmi_ctx *ctx, uint32_t lanes,
         }
         return ok;
     };
+    // ---- candidate 0 of a chip-filling launch: CHUNKS.  Spreading pays for
+    // what lies between the tables with memory; here that memory is given
+    // back.  Physical chunks (hipMemCreate) are created one after the other,
+    // `pitch` times as many as the tables need; every pitch-th is mapped into
+    // one address range and the others are released at once: the tables lie
+    // packed in their range and spread over the device's memory, and the
+    // context HOLDS what the tables fill (17 GB for 65 536 lanes) - within
+    // the budget all the while (pitch x the tables for a moment).  Measured
+    // equal to a MiB per table over memory that stays held
+    // (tests/hw/vmm_layouts.hip, vmm_spread.hip: chunks of a GiB at every
+    // fourth, of 256 MiB at every fourth, against 64 GiB held).  Any call of
+    // the virtual-memory API that fails sends the placement to the plain
+    // hipMalloc candidates below.
+    if (full && ctx->lane_table_spread && !top_of_memory &&
+        !ctx->lane_table_stride_kib && !ctx->lane_tables_uncached) {
+        const size_t bytes = (size_t)lanes * tbytes;
+        const size_t CH = bytes >= ((size_t)8 << 30) ? (size_t)1 << 30
+                                                     : (size_t)256 << 20;
+        const size_t need = (bytes + CH - 1) / CH;
+        size_t pitch = budget / (need * CH);
+        if (pitch > 4)
+            pitch = 4;
+        if (pitch >= 2) {
+            hipMemAllocationProp prop = {};
+            prop.type = hipMemAllocationTypePinned;
+            prop.location.type = hipMemLocationTypeDevice;
+            prop.location.id = ctx->device;
+            std::vector<hipMemGenericAllocationHandle_t> all;
+            all.reserve(need * pitch);
+            bool ok = true;
+            for (size_t i = 0; ok && i < need * pitch; i++) {
+                hipMemGenericAllocationHandle_t h;
+                ok = hipMemCreate(&h, CH, &prop, 0) == hipSuccess;
+                if (ok)
+                    all.push_back(h);
+            }
+            void *va = nullptr;
+            size_t mapped = 0;
+            if (ok)
+                ok = hipMemAddressReserve(&va, need * CH, 0, nullptr, 0) ==
+                     hipSuccess;
+            if (ok) {
+                // (the last of every group of `pitch`: the farthest in)
+                for (size_t i = 0; ok && i < need; i++) {
+                    ok = hipMemMap((char *)va + i * CH, CH, 0,
+                                   all[i * pitch + pitch - 1], 0) == hipSuccess;
+                    if (ok)
+                        mapped = i + 1;
+                }
+            }
+            if (ok) {
+                hipMemAccessDesc acc = {};
+                acc.location = prop.location;
+                acc.flags = hipMemAccessFlagsProtReadWrite;
+                ok = hipMemSetAccess(va, need * CH, &acc, 1) == hipSuccess;
+            }
+            held_peak = all.size() * CH;
+            // give back what lies between (and, on failure, everything)
+            std::vector<hipMemGenericAllocationHandle_t> kept;
+            for (size_t i = 0; i < all.size(); i++) {
+                if (ok && i % pitch == pitch - 1)
+                    kept.push_back(all[i]);
+                else
+                    (void)hipMemRelease(all[i]);
+            }
+            if (!ok) {
+                (void)hipGetLastError();
+                if (mapped)
+                    (void)hipMemUnmap(va, mapped * CH);
+                for (size_t i = 0; i < mapped; i++)
+                    (void)hipMemRelease(all[i * pitch + pitch - 1]);
+                if (va)
+                    (void)hipMemAddressFree(va, need * CH);
+                held_peak = 0;
+                ctx->probe_log += "chunks: the virtual-memory calls failed ";
+            } else {
+                ctx->lane_tables.p = va;
+                ctx->lane_tables.cap = need * CH;
+                ctx->lane_chunks = kept;
+                ctx->lane_chunk_bytes = CH;
+                ctx->lane_va_bytes = need * CH;
+                ctx->lane_stride = tbytes / 16;
+                float ms = 0;
+                hipLaunchKernelGGL(k_probe_tables, dim3(lanes / 64), dim3(64),
+                                   0, ctx->stream, (unsigned long long *)va,
+                                   (unsigned long long)(tbytes / 16), 64u);
+                HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+                hipLaunchKernelGGL(k_probe_tables, dim3(lanes / 64), dim3(64),
+                                   0, ctx->stream, (unsigned long long *)va,
+                                   (unsigned long long)(tbytes / 16), 768u);
+                HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+                HIP_TRY(ctx, hipEventSynchronize(ctx->ev[5]));
+                HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]));
+                // tables start as "never used": epoch 0 in every entry
+                hipLaunchKernelGGL(k_zero16, dim3(ctx->num_cus * 8), dim3(256),
+                                   0, ctx->stream, (unsigned long long *)va,
+                                   (unsigned long long)(bytes / 16));
+                HIP_TRY(ctx, hipMemsetAsync(ctx->lane_epochs.p, 0,
+                                            (size_t)lanes * 4, ctx->stream));
+                ctx->n_lanes = lanes;
+                size_t free_after = 0;
+                (void)hipMemGetInfo(&free_after, &total_b);
+                const double t_ms =
+                    std::chrono::duration<double, std::milli>(
+                        std::chrono::steady_clock::now() - t_begin).count();
+                char buf[320];
+                snprintf(buf, sizeof buf,
+                         "%.2f(chunks: %zu of %zu x %zu MiB) | held at most "
+                         "%zu of budget %zu | kept %zu KiB apart, %u lanes, "
+                         "%zu bytes | placement %.1f ms | free %zu -> %zu",
+                         ms, need, need * pitch, CH >> 20, held_peak, budget,
+                         tbytes >> 10, lanes, ctx->lane_tables.cap, t_ms,
+                         free_before, free_after);
+                ctx->probe_log += buf;
+                return SNAPMI_OK;
+            }
+        }
+    }
     for (uint32_t t = 0; t < tries; t++) {
         Cand c;
         c.stride = top_of_memory || (t & 1) ? tbytes : spread;

@@ -837,6 +837,19 @@ __global__ __launch_bounds__(64) void k_probe_tables(unsigned long long *tables,
         t[0] = (u32x4){state, 0, 0, 0};
 }
 
+// n 16-byte entries to zero (the lane tables when they are mapped chunks:
+// nothing but a kernel is known to reach every such mapping)
+__global__ __launch_bounds__(256) void k_zero16(unsigned long long *p,
+                                                unsigned long long n)
+{
+    typedef __attribute__((address_space(1))) u32x4 g_u32x4;
+    g_u32x4 *q = (g_u32x4 *)p;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 +
+                                threadIdx.x;
+         i < n; i += (unsigned long long)gridDim.x * 256)
+        q[i] = (u32x4){0, 0, 0, 0};
+}
+
 #ifdef SNAPMI_TESTING // the one-copy-per-step kernels of rounds 1-3: the
                       // test build's cross-check (option span_kernel 0)
 // ---------------------------------------------------------------------

@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <string>
+#include <vector>
 
 #include "snapmi.h"
 
@@ -49,6 +50,11 @@ struct snapmi_ctx {
     snapmi::DevBuf blk_first, slot_first, blk_size, blk_off, slots, plan_part;
     // lane-per-block match finder: tokens, token counts, HBM hash tables
     snapmi::DevBuf tokens, ntok, lane_tables, lane_epochs;
+    // lane_tables made of physical chunks (hipMemCreate) mapped into one
+    // address range (place_lane_tables, snapmi_api.hip): the chunks and the
+    // bytes of the range; empty / 0 when lane_tables.p came from hipMalloc
+    std::vector<hipMemGenericAllocationHandle_t> lane_chunks;
+    size_t lane_chunk_bytes = 0, lane_va_bytes = 0;
     uint32_t n_lanes = 0;
     uint64_t lane_stride = 0;      // 16-byte entries between two lanes' tables
     bool lane_table_spread = true; // spread the tables over free memory

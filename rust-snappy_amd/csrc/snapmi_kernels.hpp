@@ -99,6 +99,7 @@ struct DecompressArgs {
 };
 
 __global__ void k_probe_lds_order(uint32_t *bad);
+__global__ void k_zero16(unsigned long long *p, unsigned long long n);
 __global__ void k_probe_tables(unsigned long long *tables,
                                unsigned long long stride, uint32_t steps);
 __global__ void k_plan_compress(CompressArgs a);
