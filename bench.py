@@ -593,7 +593,16 @@ def main():
         return ctx.last_timing()
 
     # ---- parity gate before any number is reported ----------------------
+    # (the first compress call of the context on its own: it allocates the
+    # scratch and places the lane tables - the line carries what it took and
+    # the device's free memory around it, so that a record explains itself)
+    torch.cuda.synchronize()
+    free_before_first = torch.cuda.mem_get_info(dev)[0]
+    t_first = time.perf_counter()
     do_compress()
+    ctx.synchronize()
+    first_call_ms = (time.perf_counter() - t_first) * 1e3
+    free_after_first = torch.cuda.mem_get_info(dev)[0]
     do_decompress()
     ctx.synchronize()
     cl = comp_lens.cpu().numpy()
@@ -642,6 +651,7 @@ def main():
     k_comp_ms, k_dec_ms, t_comp, t_dec, compact_ms, plan_ms = [], [], 0.0, \
         0.0, [], []
     k_dom_ms = []
+    w_comp, w_dec = [], []   # wall ms of every timed call (incl. its wait)
     comp_kernel, dec_kernel = "k_match_both", "k_decompress_streams3"
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -659,11 +669,14 @@ def main():
         k_dec_ms.append(td["codec_ms"])
         t_comp += tb - ta
         t_dec += tc - tb
+        w_comp.append((tb - ta) * 1e3)
+        w_dec.append((tc - tb) * 1e3)
     barrier()
     elapsed = time.perf_counter() - t0
     # ---- the same gate AFTER the timed steps: what the last step left in
     # `comp` and `back` is still the oracle's bytes and the input
     verified_after = False
+    placement_log = None
     if not args.no_verify:
         cl2 = comp_lens.cpu().numpy()
         assert (cl2 == cl).all(), "compressed lengths changed during the run"
@@ -685,8 +698,8 @@ def main():
                     f"after the timed steps: round trip of stream {j}"
         verified_after = True
     if rank == 0:
-        probe = R._lib.load().snapmi_table_probe_log(ctx._h).decode()
-        log(f"[bench] lane-table placement probe ms per candidate: {probe}")
+        placement_log = ctx.table_probe_log()
+        log(f"[bench] lane-table placement: {placement_log}")
         log("[bench] compress kernel ms per step: "
             + " ".join(f"{x:.1f}/{y:.1f}" for x, y in zip(k_dom_ms, k_comp_ms))
             + " | decompress: " + " ".join(f"{x:.1f}" for x in k_dec_ms))
@@ -827,7 +840,26 @@ def main():
                 "traffic_measured": traffic_measured,
                 "traffic_source": traffic_note,
                 "alg_bytes_per_launch": alg,
-                "avg_launch_ms": round(kdom * 1e3, 3)},
+                "avg_launch_ms": round(kdom * 1e3, 3),
+                # which bytes: the algorithmic bytes of the compress
+                # DIRECTION, U read + C written.  This kernel
+                # reads U and writes tokens; C is written by k_encode_tokens
+                # behind it - so the same bytes over the whole compress side:
+                "bytes_counted": "U + C of the compress direction; C is "
+                                 "written by k_encode_tokens behind this "
+                                 "kernel (whole_side: both kernels' time)",
+                "whole_side": {
+                    "kernels": f"{dom_name} + k_scan_sizes + k_encode_tokens",
+                    "avg_ms": round(kc * 1e3, 3),
+                    "achieved": round(alg / kc / 1e9, 2),
+                    "frac": round(alg / kc / 1e9 / HBM_PEAK_GBS, 5)}},
+            "placement": placement_log,
+            "first_compress_call_ms": round(first_call_ms, 1),
+            "free_gib_around_first_call": [
+                round(free_before_first / GIB, 1),
+                round(free_after_first / GIB, 1)],
+            "step_wall_ms": {"compress": [round(x, 2) for x in w_comp],
+                             "decompress": [round(x, 2) for x in w_dec]},
             "roofline_decompress": {
                 "kernel": dec_name, "bound": "hbm",
                 "achieved": round(ach_d, 2), "peak": HBM_PEAK_GBS,

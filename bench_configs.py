@@ -236,12 +236,37 @@ def cfg3(args, ctx, dev):
             "decode_no_index_ms": round(tw * 1e3, 2)}
 
 
-def raw_tiles(ctx, dev, blob, gib, steps, want=None):
+def stream_probe(t, write=True):
+    """GB/s of a plain streaming pass over the uint8 tensor `t` - a fill
+    (write) or a sum (read) by torch's own kernels: where in the device's
+    memory a buffer lies decides 20 % of what streams into it (tests/hw/
+    zone_stream.hip: writes run at 4.7 TB/s into the first 64 GiB a process is
+    handed and at 5.2-6.3 TB/s behind them, reads at 5.7 / 6.0-6.3)."""
+    v = t[:t.numel() // 8 * 8].view(torch.int64)
+    for k in range(3):
+        if k == 1:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        if write:
+            v.fill_(0)
+        else:
+            v.sum()
+    torch.cuda.synchronize()
+    return round(2 * v.numel() * 8 / (time.perf_counter() - t0) / 1e9)
+
+
+def raw_tiles(ctx, dev, blob, gib, steps, want=None, diag=None,
+              back_first=False):
     """`blob` as independent raw streams tiled to `gib`: compress and
-    decompress rates, first/last stream checked against `want`."""
+    decompress rates, first/last stream checked against `want`.  `diag`: a
+    dict for the streaming rates of the buffers where they lie."""
     from rust_snappy_amd import batch, raw
     reps = max(1, int(gib * GIB / max(1, len(blob))))
     stride = (len(blob) + 15) // 16 * 16
+    back = None
+    if back_first:   # the decoder's output buffer before everything else
+        back = batch.StreamBatch.empty(
+            np.full(reps, len(blob), dtype=np.int64), dev)
     one = np.zeros(stride, dtype=np.uint8)
     one[:len(blob)] = np.frombuffer(blob, dtype=np.uint8)
     data = torch.from_numpy(one).to(dev).repeat(reps)
@@ -251,7 +276,8 @@ def raw_tiles(ctx, dev, blob, gib, steps, want=None):
     cap = raw.max_compress_len(len(blob))
     comp = batch.StreamBatch.empty(np.full(reps, cap, dtype=np.int64), dev)
     clens = torch.zeros(reps, dtype=torch.int64, device=dev)
-    back = batch.StreamBatch.empty(lens, dev)
+    if back is None:
+        back = batch.StreamBatch.empty(lens, dev)
     blens = torch.zeros(reps, dtype=torch.int64, device=dev)
 
     def enc():
@@ -262,6 +288,10 @@ def raw_tiles(ctx, dev, blob, gib, steps, want=None):
         raw.decompress_batch(ctx, comp.d_ptrs, clens, back.d_ptrs,
                              back.d_lens, blens, None)
 
+    if diag is not None:
+        diag.update({"write_gbs_into_compressed": stream_probe(comp.data),
+                     "write_gbs_into_decoded": stream_probe(back.data),
+                     "read_gbs_of_input": stream_probe(data, write=False)})
     enc()
     ctx.synchronize()
     if want is not None:
@@ -278,16 +308,41 @@ def raw_tiles(ctx, dev, blob, gib, steps, want=None):
 def cfg5(args, ctx, dev):
     import oracle_lib as O
     jpg = (O.CORPUS / "fireworks.jpeg").read_bytes()
-    n, c, reps, te, td = raw_tiles(ctx, dev, jpg, args.gib, args.steps,
-                                   O.compress(jpg))
-    return {"config": "cfg5 incompressible (fireworks.jpeg tiles)",
-            "gib": round(n / GIB, 3), "streams": reps,
-            "compress_gibs": round(n / GIB / te, 2),
-            "decompress_gibs": round(n / GIB / td, 2),
-            "compress_hbm_frac": round((n + c) / te / 8e12, 4),
-            "decompress_hbm_frac": round((n + c) / td / 8e12, 4),
-            "compress_ms": round(te * 1e3, 2),
-            "decompress_ms": round(td * 1e3, 2)}
+
+    def row(n, c, reps, te, td, diag):
+        return {"gib": round(n / GIB, 3), "streams": reps,
+                "compress_gibs": round(n / GIB / te, 2),
+                "decompress_gibs": round(n / GIB / td, 2),
+                "compress_hbm_frac": round((n + c) / te / 8e12, 4),
+                "decompress_hbm_frac": round((n + c) / td / 8e12, 4),
+                "compress_ms": round(te * 1e3, 2),
+                "decompress_ms": round(td * 1e3, 2), **diag}
+    diag = {"free_gib_before": round(torch.cuda.mem_get_info(dev)[0] / GIB)}
+    res = {"config": "cfg5 incompressible (fireworks.jpeg tiles)"}
+    res.update(row(*raw_tiles(ctx, dev, jpg, args.gib, args.steps,
+                              O.compress(jpg), diag), diag))
+    # Round 5 left a riddle: this pure streaming path took 11.8 ms to decode
+    # on one box and 14.0 on the next.  It is WHERE the buffers lie (see
+    # stream_probe): the same call with every buffer allocated behind a
+    # spacer of 96 GiB, and with the decoder's output buffer allocated first
+    # (the part of the memory that takes writes slowest) - beside the row above, whose buffers lie wherever the allocator
+    # put them after the configs that ran before.
+    torch.cuda.empty_cache()
+    d2 = {}
+    res["decoded_buffer_allocated_first"] = row(
+        *raw_tiles(ctx, dev, jpg, args.gib, args.steps, O.compress(jpg), d2,
+                   back_first=True), d2)
+    torch.cuda.empty_cache()
+    need = 3.3 * args.gib + 96 + 8
+    if torch.cuda.mem_get_info(dev)[0] / GIB > need:
+        spacer = torch.empty(int(96 * GIB), dtype=torch.uint8, device=dev)
+        d3 = {}
+        res["behind_a_96_gib_spacer"] = row(
+            *raw_tiles(ctx, dev, jpg, args.gib, args.steps, O.compress(jpg),
+                       d3), d3)
+        del spacer
+        torch.cuda.empty_cache()
+    return res
 
 
 def files(args, ctx, dev):

@@ -15,6 +15,7 @@
 #include <new>
 #include <string>
 #include <deque>
+#include <atomic>
 #include <chrono>
 #include <thread>
 #include <vector>
@@ -1176,6 +1177,7 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     a.lane_stride = kMaxTable;
     a.n_lanes = 0;
     a.tok_base = 0;
+    a.tok_stride = kMaxTokens;
     a.small_limit = (uint32_t)small_stream_limit(ctx);
     a.cls_lo = 0;
     a.cls_hi = kMaxBlock;
@@ -1260,11 +1262,17 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     }
     // both match finders on every CU (k_match_both): launches that fill the
     // chip with lanes anyway
+    // tokens per block: 16 400 (128 KiB) - or 2 112 (16.5 KiB) when every
+    // block of the batch is of at most 8 KiB: a batch of 4 KiB pages used to
+    // reserve 32 times its input
+    const uint32_t tok_stride =
+        use_small && nb_big == 0 ? kMaxTokensSmall : kMaxTokens;
+    a.tok_stride = tok_stride;
     const bool both_cores = lanes_mode && !waves_mode && !span_match &&
                             ctx->lds_order_ok && ctx->lane_coresident &&
                             nb_big >= ctx->lane_coresident_min_blocks;
     if (lanes_mode && span_match) {
-        if ((rc = reserve(ctx, ctx->tokens, (size_t)seg_blocks * kMaxTokens *
+        if ((rc = reserve(ctx, ctx->tokens, (size_t)seg_blocks * tok_stride *
                                                 sizeof(uint64_t))) ||
             (rc = reserve(ctx, ctx->ntok, (size_t)blocks * sizeof(uint32_t))))
             return rc;
@@ -1277,7 +1285,7 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                 return rc;
             ctx->lane_tables_top = false;
         }
-        if ((rc = reserve(ctx, ctx->tokens, (size_t)seg_blocks * kMaxTokens *
+        if ((rc = reserve(ctx, ctx->tokens, (size_t)seg_blocks * tok_stride *
                                                 sizeof(uint64_t))) ||
             (rc = reserve(ctx, ctx->ntok, (size_t)blocks * sizeof(uint32_t))))
             return rc;
@@ -2552,11 +2560,117 @@ struct SeamReq {
     snapmi_error err;
 };
 
+// The single-launch path of a lone small call (round 6): a request of under
+// 256 bytes (compress: input; uncompress: compressed bytes, at most 256 of
+// output) that has no company runs as ONE kernel whose descriptor, input and
+// output lie in pinned host memory - the caller's staging buffers, which the
+// device reaches over the link - and whose end the host sees by polling a
+// word of that memory: no copy commands, no plan kernel, no stream
+// synchronisation (round 5: two copies each way, two to three kernels and a
+// hipStreamSynchronize, ~80 us for 200 bytes).  The reference's seam is a
+// plain function call (snappy-cpp/src/lib.rs:13-64); this is as close as a
+// device gets.  Returns false when it cannot run (the batch path takes over).
+struct SeamTinyBlock {  // in ctx->pin_desc
+    uint64_t in_ptr, in_len, out_ptr, out_cap, out_len;
+    snapmi_error err;
+    uint32_t order0;         // DecompressArgs::order: stream 0
+    uint32_t bucket_pos[66]; // (unused by the kernel; room the args point at)
+    uint32_t done;
+};
+
+bool seam_tiny(snapmi_ctx *ctx, SeamReq *r)
+{
+    if (r->in_len == 0 || r->in_len >= kTinyCompress)
+        return false;
+    if (r->compress ? !ctx->tiny_stream_kernel : r->dev_out > 256)
+        return false;
+    if (pin_reserve(ctx, &ctx->pin_desc, &ctx->pin_desc_cap,
+                    sizeof(SeamTinyBlock) + 64) != SNAPMI_OK)
+        return false;
+    SeamTinyBlock *h = (SeamTinyBlock *)ctx->pin_desc;
+    void *d_blk = nullptr, *d_in = nullptr, *d_out = nullptr;
+    if (hipHostGetDevicePointer(&d_blk, h, 0) != hipSuccess ||
+        hipHostGetDevicePointer(&d_in, (void *)r->pin_in, 0) != hipSuccess ||
+        hipHostGetDevicePointer(&d_out, r->pin_out, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    SeamTinyBlock *d = (SeamTinyBlock *)d_blk;
+    const uint32_t seq = ++ctx->seam_seq ? ctx->seam_seq : ++ctx->seam_seq;
+    h->in_ptr = (uint64_t)(uintptr_t)d_in;
+    h->in_len = r->in_len;
+    h->out_ptr = (uint64_t)(uintptr_t)d_out;
+    h->out_cap = r->out_cap < r->dev_out ? r->out_cap : r->dev_out;
+    h->out_len = 0;
+    memset(&h->err, 0, sizeof h->err);
+    h->order0 = 0;
+    h->done = 0;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    if (r->compress) {
+        hipLaunchKernelGGL(k_seam_compress_tiny, dim3(1), dim3(64), 0,
+                           ctx->stream, (const uint8_t *)d_in,
+                           (uint32_t)r->in_len, (uint8_t *)d_out,
+                           (unsigned long long *)&d->out_len, &d->done, seq);
+    } else {
+        DecompressArgs a;
+        memset(&a, 0, sizeof a);
+        a.in_ptrs = (const void *const *)&d->in_ptr;
+        a.in_lens = &d->in_len;
+        a.out_ptrs = (void *const *)&d->out_ptr;
+        a.out_caps = &d->out_cap;
+        a.out_lens = &d->out_len;
+        a.errs = &d->err;
+        a.n_streams = 1;
+        a.order = &d->order0;
+        a.bucket_pos = d->bucket_pos;
+        hipLaunchKernelGGL(k_seam_decompress_tiny, dim3(1), dim3(64), 0,
+                           ctx->stream, a, &d->done, seq);
+    }
+    if (hipGetLastError() != hipSuccess)
+        return false;
+    // the end: the device's release store of `seq` (spin; after 2 ms of it,
+    // the stream's own wait - a queue behind somebody else's work)
+    volatile uint32_t *done = &h->done;
+    const auto t0 = std::chrono::steady_clock::now();
+    bool seen = false;
+    for (uint32_t spins = 0;; spins++) {
+        if (*done == seq) {
+            seen = true;
+            break;
+        }
+        if ((spins & 255) == 255 &&
+            std::chrono::steady_clock::now() - t0 >
+                std::chrono::milliseconds(2))
+            break;
+    }
+    if (!seen && (hipStreamSynchronize(ctx->stream) != hipSuccess ||
+                  *done != seq)) {
+        (void)hipGetLastError();
+        r->rc = SNAPMI_E_DEVICE;
+        r->written = 0;
+        memset(&r->err, 0, sizeof r->err);
+        r->err.kind = SNAPMI_E_DEVICE;
+        return true;
+    }
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    r->err = h->err;
+    r->rc = r->compress ? SNAPMI_OK : h->err.kind;
+    r->written = r->rc == SNAPMI_OK ? (size_t)h->out_len : 0;
+    if (r->written > r->dev_out) {
+        r->rc = SNAPMI_E_DEVICE;
+        r->written = 0;
+    }
+    return true;
+}
+
 // one batch of requests of one kind on `ctx` (no lock held)
 void seam_execute(snapmi_ctx *ctx, const std::vector<SeamReq *> &batch)
 {
     const size_t n = batch.size();
     const bool compress = batch[0]->compress;
+    if (n == 1 && hipSetDevice(ctx->device) == hipSuccess &&
+        seam_tiny(ctx, batch[0]))
+        return;
     auto fail_all = [&](int rc) {
         for (SeamReq *r : batch) {
             r->rc = rc;
@@ -2598,7 +2712,13 @@ void seam_execute(snapmi_ctx *ctx, const std::vector<SeamReq *> &batch)
         h_in_lens[i] = batch[i]->in_len;
         h_out_ptrs[i] =
             (uint64_t)(uintptr_t)((uint8_t *)ctx->st_out.p + out_off[i]);
-        h_out_caps[i] = batch[i]->out_cap; // the caller's is what is checked
+        // (the caller's capacity was checked against what the call needs -
+        // max_compress_len / the header's length - before it got here; the
+        // kernels get what the request's slab holds, so that their own cap
+        // checks keep them inside it)
+        h_out_caps[i] = batch[i]->out_cap < batch[i]->dev_out
+                            ? batch[i]->out_cap
+                            : batch[i]->dev_out;
     }
     hipStream_t s = ctx->stream;
     bool ok = true;
@@ -2664,6 +2784,9 @@ struct SeamCombiner {
     std::deque<SeamReq *> q; // under g_pool.mu
     static constexpr size_t kMaxBatch = 1024;
     static constexpr size_t kMaxBytes = (size_t)1 << 30;
+    // (under g_pool.mu) batches running now; when a request last had company
+    size_t in_flight = 0;
+    std::chrono::steady_clock::time_point last_company{};
 
     void run(SeamReq *r)
     {
@@ -2706,8 +2829,14 @@ struct SeamCombiner {
     void lead(std::unique_lock<std::mutex> &lock, snapmi_ctx *ctx, SeamReq *r)
     {
         // requests that are arriving right now join: until the queue has not
-        // grown for ~8 us, 50 us at most (a call is ~1 500 us of GPU time)
-        {
+        // grown for ~8 us, 50 us at most (a call is ~1 500 us of GPU time) -
+        // unless this caller has been alone for a while (no second request
+        // queued or in flight during the last 2 ms): a single-threaded
+        // caller pays no window at all
+        const auto t_enter = std::chrono::steady_clock::now();
+        if (q.size() > 1 || in_flight > 0)
+            last_company = t_enter;
+        if (t_enter - last_company <= std::chrono::milliseconds(2)) {
             size_t seen = q.size();
             lock.unlock();
             const auto t0 = std::chrono::steady_clock::now();
@@ -2749,9 +2878,13 @@ struct SeamCombiner {
                 ++it;
             }
         }
+        if (batch.size() > 1)
+            last_company = std::chrono::steady_clock::now();
+        in_flight++;
         lock.unlock();
         seam_execute(ctx, batch);
         lock.lock();
+        in_flight--;
         for (SeamReq *x : batch)
             x->state = 2;
         g_pool.idle.push_back(ctx);

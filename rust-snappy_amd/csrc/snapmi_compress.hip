@@ -1140,7 +1140,7 @@ __device__ __forceinline__ void compress_one_block_span(
         // match finder only: tokens for k_encode_tokens (which also writes
         // the varint of block 0)
         out.init((TokenWriter::g_u64 *)a.tokens +
-                     (uint64_t)(b - a.tok_base) * kMaxTokens,
+                     (uint64_t)(b - a.tok_base) * a.tok_stride,
                  lane);
     } else {
         gptr dst;
@@ -1676,7 +1676,10 @@ template <bool kStage> struct TinyColumns {
 };
 } // namespace
 
-__global__ __launch_bounds__(64) void k_compress_tiny(CompressArgs a)
+// stream i of the batch by this lane (k_compress_tiny: 64 consecutive streams
+// per wavefront; k_seam_compress_tiny: one)
+__device__ __forceinline__ void compress_tiny_stream(const CompressArgs &a,
+                                                     const uint64_t i)
 {
     constexpr bool kStage = SNAPMI_TINY_STAGE_OUT != 0;
     constexpr uint32_t kW = kTinyCompress / 4;         // dwords per column
@@ -1685,7 +1688,6 @@ __global__ __launch_bounds__(64) void k_compress_tiny(CompressArgs a)
     __shared__ uint32_t ttab[kW * 64];
     __shared__ uint32_t tout[kWo * 64];
     const uint32_t lane = threadIdx.x;
-    const uint64_t i = (uint64_t)blockIdx.x * 64 + lane;
     if (i >= a.n_streams)
         return;
     const uint64_t len = a.in_lens[i];
@@ -1726,6 +1728,62 @@ __global__ __launch_bounds__(64) void k_compress_tiny(CompressArgs a)
             dst[k + j] = (uint8_t)(last >> (8 * j));
     }
     a.out_lens[i] = d;
+}
+
+__global__ __launch_bounds__(64) void k_compress_tiny(CompressArgs a)
+{
+    compress_tiny_stream(a, (uint64_t)blockIdx.x * 64 + threadIdx.x);
+}
+
+// The libsnappy seam's single-launch path (snapmi_api.hip, seam_tiny): ONE
+// stream of 1..255 bytes whose input and output lie in pinned host memory the
+// device reaches over the link - no copy commands, no plan kernel, the
+// stream's description in the kernel's arguments (a descriptor in host
+// memory is a round trip over the link per dependent load), and the host
+// learns of the end from *done (it polls it; a system-scope fence puts the
+// output and the length in front of it).  All 64 lanes bring the input in -
+// one load instruction, one round trip - and clear the table; lane 0 runs
+// the reference's loop (snapmi_tiny.hpp) and stores the elements as they come.
+__global__ __launch_bounds__(64) void k_seam_compress_tiny(
+    const uint8_t *in, uint32_t n, uint8_t *out, unsigned long long *out_len,
+    uint32_t *done, uint32_t seq)
+{
+    constexpr bool kStage = SNAPMI_TINY_STAGE_OUT != 0;
+    constexpr uint32_t kW = kTinyCompress / 4; // dwords per column (64)
+    constexpr uint32_t kWo = kStage ? (kTinyOutMax + 3) / 4 : 1;
+    __shared__ uint32_t tin[kW * 64];
+    __shared__ uint32_t ttab[kW * 64];
+    __shared__ uint32_t tout[kWo * 64];
+    const uint32_t lane = threadIdx.x;
+    gcptr src = (gcptr)in;
+    {
+        // dword `lane` of the input into lane 0's column (reads stay inside
+        // the stream: the last partial dword bytewise)
+        const uint32_t k = 4 * lane;
+        uint32_t v = 0;
+        if (k + 4 <= n) {
+            v = ld32u(src + k);
+        } else {
+            for (uint32_t j = 0; k + j < n; j++)
+                v |= (uint32_t)src[k + j] << (8 * j);
+        }
+        tin[lane * 64] = v;
+        ttab[lane * 64] = 0; // fresh table: src/compress.rs:506
+    }
+    __syncthreads();
+    if (lane != 0)
+        return;
+    typedef TinyColumns<kStage> Columns;
+    Columns m;
+    m.in = (typename Columns::l_u32 *)tin;
+    m.tb = (typename Columns::l_u32 *)ttab;
+    m.out = (typename Columns::l_u32 *)tout;
+    m.gout = (gptr)out;
+    const uint32_t d = tiny_compress(m, n);
+    *out_len = d;
+    __threadfence_system();
+    __hip_atomic_store(done, seq, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---------------------------------------------------------------------
@@ -2022,7 +2080,7 @@ __device__ __forceinline__ void match_blocks(
                 n = total - boff < kMaxBlock ? (uint32_t)(total - boff)
                                              : kMaxBlock;
                 tok = (g_u64 *)a.tokens +
-                      (uint64_t)(b - a.tok_base) * kMaxTokens;
+                      (uint64_t)(b - a.tok_base) * a.tok_stride;
                 ntok = 0;
                 csize = 0;
                 next_emit = 0;
@@ -2469,7 +2527,7 @@ __global__ __launch_bounds__(64) void k_encode_tokens(CompressArgs a)
     out.init(src, n, dst, lane);
     typedef __attribute__((address_space(1))) unsigned long long g_u64;
     const g_u64 *tok =
-        (const g_u64 *)a.tokens + (uint64_t)(b - a.tok_base) * kMaxTokens;
+        (const g_u64 *)a.tokens + (uint64_t)(b - a.tok_base) * a.tok_stride;
     const uint32_t count = a.ntok[b];
     uint32_t pos_base = 0;
     // (the next pass's tokens are loaded before this pass is encoded: one

@@ -224,6 +224,7 @@ struct snapmi_ctx {
     bool timing_is_compress = false;
     bool dominant_split = false; // ev[4]/ev[5] bracket k_match_blocks
     uint64_t codec_launches = 0;
+    uint32_t seam_seq = 0; // the seam's single-launch path: its last ticket
 };
 
 namespace snapmi {

@@ -1796,6 +1796,20 @@ __global__ __launch_bounds__(64) void k_decompress_tiny(DecompressArgs a)
                                                a.n_streams);
 }
 
+// The libsnappy seam's single-launch path (snapmi_api.hip, seam_tiny): ONE
+// stream of under 256 compressed bytes; descriptor, input and output in
+// pinned host memory, *done polled by the host (k_seam_compress_tiny).
+__global__ __launch_bounds__(64) void k_seam_decompress_tiny(
+    DecompressArgs a, uint32_t *done, uint32_t seq)
+{
+    decompress_lane_streams<kTinyLog2, kWave>(a, 0, 1);
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        __hip_atomic_store(done, seq, __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 __global__ __launch_bounds__(64) void k_decompress_small(DecompressArgs a)
 {
     if (a.gate && uni64(*a.gate) != a.gate_value)

@@ -30,7 +30,11 @@ struct CompressArgs {
     uint32_t *ticket; // device-wide block ticket counter, zeroed per launch
     // lane-per-block match finder (k_match_blocks): token stream per block,
     // per-lane epoch-tagged hash tables in HBM
-    unsigned long long *tokens; // [(blk_hi - blk_lo) * kMaxTokens]
+    unsigned long long *tokens; // [(blk_hi - blk_lo) * tok_stride]
+    // tokens per block of the array above: kMaxTokens, or - a batch whose
+    // blocks are all of at most 8 KiB (pages, short frame chunks) -
+    // kMaxTokensSmall: a copy is four bytes or more
+    uint32_t tok_stride;
     uint32_t *ntok;             // [blocks]
     uint32_t blk_lo, blk_hi;    // blocks this lane/encode launch covers
     uint32_t tok_base;          // block whose tokens lie at tokens[0]
@@ -72,6 +76,7 @@ constexpr uint32_t kBothWaves = SNAPMI_BOTH_WAVES,
 // in a copy of >= 4 bytes), rounded up to whole 128-byte groups of 16 so a
 // lane can write its tokens a full cache line at a time
 constexpr uint32_t kMaxTokens = 16400;
+constexpr uint32_t kMaxTokensSmall = 8192 / 4 + 64; // blocks of <= 8 KiB
 
 // Batch of raw streams to decompress.
 struct DecompressArgs {
@@ -100,6 +105,12 @@ struct DecompressArgs {
 
 __global__ void k_probe_lds_order(uint32_t *bad);
 __global__ void k_zero16(unsigned long long *p, unsigned long long n);
+__global__ void k_seam_compress_tiny(const uint8_t *in, uint32_t n,
+                                     uint8_t *out,
+                                     unsigned long long *out_len,
+                                     uint32_t *done, uint32_t seq);
+__global__ void k_seam_decompress_tiny(DecompressArgs a, uint32_t *done,
+                                       uint32_t seq);
 __global__ void k_probe_tables(unsigned long long *tables,
                                unsigned long long stride, uint32_t steps);
 __global__ void k_plan_compress(CompressArgs a);

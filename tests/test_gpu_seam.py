@@ -135,3 +135,66 @@ def test_combined_calls_give_every_caller_the_oracles_bytes(built):
     for t in threads:
         t.join()
     assert not errors, errors[:3]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lib", ["test", "product"])
+def test_single_launch_path_of_small_calls(built, lib):
+    """A lone snappy_compress / snappy_uncompress of under 256 bytes runs as
+    ONE kernel over pinned host memory (seam_tiny, snapmi_api.hip): every
+    input length 1..255 over three alphabets compresses to the oracle's bytes
+    and comes back; every small error KAT of the reference's decoder
+    (test/tests.rs:345-466) is refused with SNAPPY_INVALID_INPUT; a short
+    output buffer is SNAPPY_BUFFER_TOO_SMALL; a stream whose header promises
+    more than 256 bytes (the batch path's) still decodes; and 300 such calls
+    take a fraction of what round 5's path took (80 us each)."""
+    import ctypes as C
+    import random
+    import time
+    import kats
+    import oracle_lib as O
+    from rust_snappy_amd import _lib
+    L = _lib.load_product() if lib == "product" else _lib.load()
+    rng = random.Random(66)
+
+    def press(d):
+        cap = C.c_size_t(L.snappy_max_compressed_length(len(d)))
+        out = C.create_string_buffer(cap.value)
+        assert L.snappy_compress(bytes(d), len(d), out, C.byref(cap)) == 0
+        return out.raw[:cap.value]
+
+    def depress(c, room=None):
+        n = C.c_size_t(0)
+        if L.snappy_uncompressed_length(bytes(c), len(c), C.byref(n)) != 0:
+            return 1, b""
+        cap = C.c_size_t(n.value if room is None else room)
+        out = C.create_string_buffer(max(cap.value, 1))
+        rc = L.snappy_uncompress(bytes(c), len(c), out, C.byref(cap))
+        return rc, out.raw[:cap.value] if rc == 0 else b""
+    for n in range(1, 256):
+        for alpha in (2, 16, 256):
+            d = bytes(rng.choices(range(alpha), k=n))
+            c = press(d)
+            assert c == O.compress(d), (n, alpha)
+            assert depress(c) == (0, d), (n, alpha)
+    assert press(b"") == b"\x00" and depress(b"\x00") == (0, b"")
+    for name, data, want, bad_header in kats.ERROR_KATS:
+        if 0 < len(data) < 256:
+            assert depress(data)[0] == 1, name
+    zeros = O.compress(b"\x00" * 4096)          # 200 bytes in, 4 KiB out
+    assert len(zeros) < 256 and depress(zeros) == (0, b"\x00" * 4096)
+    c = press(b"hello hello hello hello")
+    assert depress(c, room=5)[0] == 2
+    d = bytes(rng.choices(range(4), k=200))
+    c = press(d)
+    t0 = time.perf_counter()
+    for _ in range(300):
+        assert press(d) == c
+    tc = (time.perf_counter() - t0) / 300 * 1e6
+    t0 = time.perf_counter()
+    for _ in range(300):
+        assert depress(c) == (0, d)
+    td = (time.perf_counter() - t0) / 300 * 1e6
+    print(f"\n200-byte calls through snappy-c.h ({lib}): compress {tc:.1f} us, "
+          f"uncompress {td:.1f} us (ctypes call overhead included)")
+    assert tc < 60 and td < 60, (tc, td)
