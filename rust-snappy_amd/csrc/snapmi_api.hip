@@ -9,6 +9,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <condition_variable>
 #include <mutex>
@@ -1171,6 +1172,7 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     a.host_slots = (uint32_t)slots;
     a.ticket = (uint32_t *)ctx->ticket.p;
     a.tokens = nullptr;
+    a.tok_exc = nullptr;
     a.ntok = nullptr;
     a.lane_tables = nullptr;
     a.lane_epochs = nullptr;
@@ -1272,11 +1274,16 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                             ctx->lds_order_ok && ctx->lane_coresident &&
                             nb_big >= ctx->lane_coresident_min_blocks;
     if (lanes_mode && span_match) {
-        if ((rc = reserve(ctx, ctx->tokens, (size_t)seg_blocks * tok_stride *
-                                                sizeof(uint64_t))) ||
+        if ((rc = reserve(ctx, ctx->tokens, (size_t)seg_blocks * tok_stride * 9 / 2 +
+                                                4096)) ||
             (rc = reserve(ctx, ctx->ntok, (size_t)blocks * sizeof(uint32_t))))
             return rc;
         a.tokens = (unsigned long long *)ctx->tokens.p;
+        // (the exception lists behind the token arrays, 8-byte aligned)
+        a.tok_exc = (unsigned long long *)((uint8_t *)ctx->tokens.p +
+                                           (((size_t)seg_blocks * tok_stride * 4 +
+                                             255) &
+                                            ~(size_t)255));
         a.ntok = (uint32_t *)ctx->ntok.p;
     } else if (lanes_mode) {
         const uint32_t lanes = lane_count(ctx, seg_blocks, both_cores);
@@ -1285,8 +1292,8 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                 return rc;
             ctx->lane_tables_top = false;
         }
-        if ((rc = reserve(ctx, ctx->tokens, (size_t)seg_blocks * tok_stride *
-                                                sizeof(uint64_t))) ||
+        if ((rc = reserve(ctx, ctx->tokens, (size_t)seg_blocks * tok_stride * 9 / 2 +
+                                                4096)) ||
             (rc = reserve(ctx, ctx->ntok, (size_t)blocks * sizeof(uint32_t))))
             return rc;
         if (ctx->lane_epoch_preset >= 0) { // test knob, see snapmi_ctx.hpp
@@ -1296,6 +1303,11 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
             ctx->lane_epoch_preset = -1;
         }
         a.tokens = (unsigned long long *)ctx->tokens.p;
+        // (the exception lists behind the token arrays, 8-byte aligned)
+        a.tok_exc = (unsigned long long *)((uint8_t *)ctx->tokens.p +
+                                           (((size_t)seg_blocks * tok_stride * 4 +
+                                             255) &
+                                            ~(size_t)255));
         a.ntok = (uint32_t *)ctx->ntok.p;
         a.lane_tables = (unsigned long long *)ctx->lane_tables.p;
         a.lane_epochs = (uint32_t *)ctx->lane_epochs.p;
@@ -2519,7 +2531,17 @@ struct SeamLease {
     }
 };
 
-// pinned staging of the calling thread (grow-only, freed with the thread)
+// set by an atexit handler: the process is leaving, the HIP runtime with it
+std::atomic<bool> g_seam_exiting{false};
+struct SeamExitHook {
+    SeamExitHook()
+    {
+        atexit([] { g_seam_exiting.store(true, std::memory_order_release); });
+    }
+} g_seam_exit_hook;
+
+// pinned staging of the calling thread (at most 2 MiB kept between calls,
+// freed with the thread)
 struct ThreadPin {
     void *p = nullptr;
     size_t cap = 0;
@@ -2540,10 +2562,24 @@ struct ThreadPin {
         cap = want;
         return true;
     }
+    // a call that needed a large buffer does not leave it with the thread
+    // for good: above kKeep the buffer goes back once the call is over
+    static constexpr size_t kKeep = (size_t)2 << 20;
+    void trim()
+    {
+        if (cap > kKeep) {
+            (void)hipHostFree(p);
+            p = nullptr;
+            cap = 0;
+        }
+    }
     ~ThreadPin()
     {
-        if (p)
-            (void)hipHostFree(p); // (may fail while the process leaves)
+        // (a thread that ends while the process is leaving may find the HIP
+        // runtime gone: its own teardown frees pinned memory then, and a
+        // call into it would not come back)
+        if (p && !g_seam_exiting.load(std::memory_order_acquire))
+            (void)hipHostFree(p);
     }
 };
 thread_local ThreadPin tl_pin_in, tl_pin_out;
@@ -2929,6 +2965,8 @@ int seam_call(bool compress, const uint8_t *input, size_t input_len,
         memcpy(output, r.pin_out, r.written);
         *written = r.written;
     }
+    tl_pin_in.trim();
+    tl_pin_out.trim();
     if (r.rc >= SNAPMI_E_DEVICE)
         fprintf(stderr, "snapmi: %s: device failure (no CPU fallback)\n",
                 what);

@@ -967,8 +967,9 @@ __device__ __forceinline__ void lds_mskor(uint32_t byte_addr, uint32_t mask,
 
 namespace {
 // The window kernel as a MATCH FINDER for k_encode_tokens (k_match_spans):
-// tokens leave in that kernel's format (literal length | copy length << 17 |
-// offset << 33) and what they will encode to is added up (token_bytes) - so
+// tokens leave in that kernel's format (four bytes each and an exception
+// list, snapmi_kernels.hpp) and what they will encode to is added up
+// (token_bytes) - so
 // that, as behind k_match_blocks, every block's size is known before a byte
 // of it is written and the encoder can put it at its final position (no
 // scratch slots, no k_compact).  Round 5: a step's tokens are stored by the
@@ -976,18 +977,24 @@ namespace {
 // a token register (two ds_permute and their round trip per step), no flush:
 // one predicated 8-byte store and a per-lane sum of sizes.
 struct TokenWriter {
+    typedef __attribute__((address_space(1))) uint32_t g_u32;
     typedef __attribute__((address_space(1))) unsigned long long g_u64;
-    g_u64 *tok;    // this block's token array
+    g_u32 *tok;    // this block's token array
+    g_u64 *exc;    // ... and its exception list
     uint32_t ntok; // tokens stored so far (uniform)
+    uint32_t nexc; // exceptions stored so far (uniform)
     uint32_t dsum; // encoded bytes of the tokens THIS LANE stored
     uint32_t d;    // finish(): encoded bytes of the block (uniform)
     uint32_t t;    // always 0 (TokenSink's interface: nothing is pending)
     uint32_t lane;
 
-    __device__ __forceinline__ void init(g_u64 *tokens, uint32_t l)
+    __device__ __forceinline__ void init(g_u32 *tokens, g_u64 *exceptions,
+                                         uint32_t l)
     {
         tok = tokens;
+        exc = exceptions;
         ntok = 0;
+        nexc = 0;
         dsum = 0;
         d = 0;
         t = 0;
@@ -1000,30 +1007,37 @@ struct TokenWriter {
                                               uint32_t copy_len)
     {
         (void)lit_start; // (k_encode_tokens adds the lengths up)
+        const bool fits = tok_fits(lit_len, copy_len);
         if (lane == 0) {
-            tok[ntok] = (unsigned long long)lit_len |
-                        ((unsigned long long)copy_len << 17) |
-                        ((unsigned long long)offset << 33);
+            tok[ntok] = tok_pack(lit_len, copy_len, offset);
+            if (!fits)
+                exc[nexc] = tok_pack64(lit_len, copy_len, offset);
             dsum += token_bytes(lit_len, copy_len, offset);
         }
         ntok++;
+        nexc += fits ? 0u : 1u;
     }
     // the copies of a window step: lane `mine` holds the rank-th of cnt
-    // tokens, a copy of 4..15 bytes (one element: src/compress.rs:339-356)
+    // tokens, a copy of 4..15 bytes (one element: src/compress.rs:339-356).
+    // Only the step's FIRST copy can come behind a literal of 1 024 bytes or
+    // more (the literals between a window's copies are shorter than the
+    // window): at most one exception per step, `first_long` (uniform) says so.
     __device__ __forceinline__ void put_step(bool mine, uint32_t rank,
                                              uint32_t cnt, uint32_t lit_len,
                                              uint32_t copy_len,
                                              uint32_t offset)
     {
+        const bool big = mine && lit_len > 1023u;
         if (mine)
-            tok[ntok + rank] = (unsigned long long)lit_len |
-                               ((unsigned long long)copy_len << 17) |
-                               ((unsigned long long)offset << 33);
+            tok[ntok + rank] = tok_pack(lit_len, copy_len, offset);
+        if (big)
+            exc[nexc] = tok_pack64(lit_len, copy_len, offset);
         const uint32_t lt =
             lit_len == 0 ? 0 : (lit_len <= 60 ? 1 : (lit_len <= 256 ? 2 : 3));
         const uint32_t fin = copy_len <= 11 && offset <= 2047 ? 2 : 3;
         dsum += mine ? lt + lit_len + fin : 0;
         ntok += cnt;
+        nexc += __builtin_amdgcn_ballot_w64(big) ? 1u : 0u;
     }
     __device__ __forceinline__ void flush() {}
     __device__ __forceinline__ void finish()
@@ -1139,8 +1153,10 @@ __device__ __forceinline__ void compress_one_block_span(
     if constexpr (kTok) {
         // match finder only: tokens for k_encode_tokens (which also writes
         // the varint of block 0)
-        out.init((TokenWriter::g_u64 *)a.tokens +
+        out.init((TokenWriter::g_u32 *)a.tokens +
                      (uint64_t)(b - a.tok_base) * a.tok_stride,
+                 (TokenWriter::g_u64 *)a.tok_exc +
+                     (uint64_t)(b - a.tok_base) * (a.tok_stride / 16),
                  lane);
     } else {
         gptr dst;
@@ -1978,7 +1994,7 @@ namespace {
 // lane's block) and token buffers (16 tokens = one 128-byte line: every store
 // of a lane is its own DRAM transaction, and those are what bounds the kernel)
 constexpr uint32_t kLaneRingWords = 64 * 64;
-constexpr uint32_t kLaneTokWords = 64 * 16;
+constexpr uint32_t kLaneTokWords = 64 * 16; // (in 8-byte words: 32 tokens a lane)
 // lane: 0..63 of this wavefront; g: its lane id among all lanes of the launch
 // (its table, its epoch)
 template <bool kSpec>
@@ -1987,8 +2003,8 @@ __device__ __forceinline__ void match_blocks(
     __attribute__((address_space(3))) uint32_t *const ring,
     __attribute__((address_space(3))) unsigned long long *const tokbuf)
 {
-    typedef __attribute__((address_space(3))) unsigned long long l_u64;
-    l_u64 *const tbuf = tokbuf + lane * 16;
+    typedef __attribute__((address_space(3))) uint32_t l_tok;
+    l_tok *const tbuf = (l_tok *)(tokbuf + lane * 16); // 32 tokens = 128 B
     typedef __attribute__((address_space(3))) uint32_t l_u32;
     typedef __attribute__((address_space(3))) u32x4 l_u32x4;
     typedef __attribute__((address_space(1))) u32x4 g_u32x4;
@@ -2027,7 +2043,10 @@ __device__ __forceinline__ void match_blocks(
     // the block (src_al = src - mis) are in `win`, at their offset mod 256
     uint32_t mis = 0, hi = 0;
     gcptr src = nullptr, src_al = nullptr;
-    g_u64 *tok = nullptr;
+    typedef __attribute__((address_space(1))) uint32_t g_tok;
+    g_tok *tok = nullptr;
+    g_u64 *exc = nullptr; // the block's exception list (snapmi_kernels.hpp)
+    uint32_t nexc = 0;
 
     for (;;) {
         // Tickets are taken for the whole wavefront at once: the lanes that
@@ -2079,16 +2098,19 @@ __device__ __forceinline__ void match_blocks(
                 src = (gcptr)a.in_ptrs[lo] + boff;
                 n = total - boff < kMaxBlock ? (uint32_t)(total - boff)
                                              : kMaxBlock;
-                tok = (g_u64 *)a.tokens +
+                tok = (g_tok *)a.tokens +
                       (uint64_t)(b - a.tok_base) * a.tok_stride;
+                exc = (g_u64 *)a.tok_exc +
+                      (uint64_t)(b - a.tok_base) * (a.tok_stride / 16);
                 ntok = 0;
+                nexc = 0;
                 csize = 0;
                 next_emit = 0;
                 have = true;
                 if (n <= a.cls_lo || n > a.cls_hi) {
                     have = false; // another launch's block
                 } else if (n < kMinNonLiteral) { // src/compress.rs:140-146
-                    tok[0] = (unsigned long long)n;
+                    tok[0] = tok_pack(n, 0, 0);
                     a.ntok[b] = 1;
                     a.blk_size[b] = token_bytes(n, 0, 0);
                     have = false;
@@ -2337,22 +2359,23 @@ __device__ __forceinline__ void match_blocks(
         bool flush = false;
         if (matched) {
             // token: literal next_emit..mpos, copy (mpos - mcand, mend - mpos)
-            tbuf[ntok & 15] = (unsigned long long)(mpos - next_emit) |
-                              ((unsigned long long)(mend - mpos) << 17) |
-                              ((unsigned long long)(mpos - mcand) << 33);
-            ntok++;
             {
                 // token_bytes(), short form for the usual token (literal of
                 // at most 60 bytes, copy of at most 64): the round loop is
                 // not free of VALU cost
                 const uint32_t tl = mpos - next_emit, tc = mend - mpos,
                                to = mpos - mcand;
-                if (tl > 60 || tc > 64)
+                tbuf[ntok & 31] = tok_pack(tl, tc, to);
+                ntok++;
+                if (tl > 60 || tc > 64) {
                     csize += token_bytes(tl, tc, to);
-                else
+                    if (!tok_fits(tl, tc)) // rare: its numbers in full
+                        exc[nexc++] = tok_pack64(tl, tc, to);
+                } else {
                     csize += tl + 3 + (tl != 0) - (tc <= 11 && to <= 2047);
+                }
             }
-            flush = (ntok & 15) == 0;
+            flush = (ntok & 31) == 0;
             s = mend;
             next_emit = mend;
             mode = kChain;
@@ -2369,9 +2392,9 @@ __device__ __forceinline__ void match_blocks(
                 finished = true;
         }
         if (finished)
-            flush = flush || (ntok & 15) != 0;
+            flush = flush || (ntok & 31) != 0;
         if (flush) { // the token group that holds token ntok-1
-            g_u32x4 *to = (g_u32x4 *)(tok + ((ntok - 1) & ~15u));
+            g_u32x4 *to = (g_u32x4 *)(tok + ((ntok - 1) & ~31u));
             const l_u32x4 *from = (const l_u32x4 *)tbuf;
             const u32x4 t0 = from[0], t1 = from[1], t2 = from[2], t3 = from[3],
                         t4 = from[4], t5 = from[5], t6 = from[6], t7 = from[7];
@@ -2380,8 +2403,11 @@ __device__ __forceinline__ void match_blocks(
         }
         if (finished) { // done(): src/compress.rs:417-426
             if (next_emit < n) {
-                tok[ntok++] = (unsigned long long)(n - next_emit);
-                csize += token_bytes(n - next_emit, 0, 0);
+                const uint32_t tl = n - next_emit;
+                tok[ntok++] = tok_pack(tl, 0, 0);
+                if (!tok_fits(tl, 0))
+                    exc[nexc++] = tok_pack64(tl, 0, 0);
+                csize += token_bytes(tl, 0, 0);
             }
             a.ntok[b] = ntok;
             a.blk_size[b] = csize;
@@ -2525,24 +2551,46 @@ __global__ __launch_bounds__(64) void k_encode_tokens(CompressArgs a)
     }
     TokenSink out;
     out.init(src, n, dst, lane);
+    typedef __attribute__((address_space(1))) uint32_t g_tok;
     typedef __attribute__((address_space(1))) unsigned long long g_u64;
-    const g_u64 *tok =
-        (const g_u64 *)a.tokens + (uint64_t)(b - a.tok_base) * a.tok_stride;
+    const g_tok *tok =
+        (const g_tok *)a.tokens + (uint64_t)(b - a.tok_base) * a.tok_stride;
+    const g_u64 *exc = (const g_u64 *)a.tok_exc +
+                       (uint64_t)(b - a.tok_base) * (a.tok_stride / 16);
     const uint32_t count = a.ntok[b];
-    uint32_t pos_base = 0;
+    uint32_t pos_base = 0, exc_base = 0;
     // (the next pass's tokens are loaded before this pass is encoded: one
     // memory latency less on the chain of every pass)
-    unsigned long long tnext = lane < count ? tok[lane] : 0;
+    uint32_t tnext = lane < count ? tok[lane] : 0;
     for (uint32_t t0 = 0; t0 < count; t0 += kWave) {
         const uint32_t m = count - t0 < kWave ? count - t0 : kWave;
         uint32_t L = 0, C = 0, O = 0;
-        const unsigned long long t = tnext;
+        const uint32_t t = tnext;
         if (t0 + kWave + lane < count)
             tnext = tok[t0 + kWave + lane];
+        const uint32_t field = (t >> 10) & 63u;
         if (lane < m) {
-            L = (uint32_t)t & 0x1FFFFu;
-            C = (uint32_t)(t >> 17) & 0xFFFFu;
-            O = (uint32_t)(t >> 33) & 0xFFFFu;
+            L = t & 1023u;
+            C = field == kTokLiteral ? 0u : field + 4u;
+            O = t >> 16;
+        }
+        // a token that did not fit four bytes: its numbers are in the
+        // block's exception list, in the order of such tokens (rare: a pass
+        // without one pays a ballot)
+        const bool ex = lane < m && field == kTokException;
+        const uint64_t E = __builtin_amdgcn_ballot_w64(ex);
+        if (E) {
+            if (ex) {
+                const unsigned long long f =
+                    exc[exc_base +
+                        __builtin_amdgcn_mbcnt_hi(
+                            (uint32_t)(E >> 32),
+                            __builtin_amdgcn_mbcnt_lo((uint32_t)E, 0))];
+                L = (uint32_t)f & 0x1FFFFu;
+                C = (uint32_t)(f >> 17) & 0xFFFFu;
+                O = (uint32_t)(f >> 33) & 0xFFFFu;
+            }
+            exc_base += (uint32_t)__builtin_popcountll(E);
         }
         const uint32_t span = L + C;
         const uint32_t incl = wave_inclusive_scan(span);

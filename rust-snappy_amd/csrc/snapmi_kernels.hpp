@@ -30,7 +30,10 @@ struct CompressArgs {
     uint32_t *ticket; // device-wide block ticket counter, zeroed per launch
     // lane-per-block match finder (k_match_blocks): token stream per block,
     // per-lane epoch-tagged hash tables in HBM
-    unsigned long long *tokens; // [(blk_hi - blk_lo) * tok_stride]
+    // [(blk_hi - blk_lo) * tok_stride] u32 tokens, then [.. * tok_stride /
+    // 16] u64 exceptions (tok_exc): see kMaxTokens below
+    unsigned long long *tokens;
+    unsigned long long *tok_exc;
     // tokens per block of the array above: kMaxTokens, or - a batch whose
     // blocks are all of at most 8 KiB (pages, short frame chunks) -
     // kMaxTokensSmall: a copy is four bytes or more
@@ -72,11 +75,43 @@ constexpr uint32_t kSmallTableWaves = 10;
 #define SNAPMI_BOTH_LANE_WAVES 4
 constexpr uint32_t kBothWaves = SNAPMI_BOTH_WAVES,
                    kBothLaneWaves = SNAPMI_BOTH_LANE_WAVES;
-// token slots per block: at most 16385 tokens (every token but the last ends
-// in a copy of >= 4 bytes), rounded up to whole 128-byte groups of 16 so a
-// lane can write its tokens a full cache line at a time
-constexpr uint32_t kMaxTokens = 16400;
+// Tokens (what a match finder hands k_encode_tokens): FOUR bytes each since
+// round 6 - offset << 16 | field << 10 | literal length (0..1023), field =
+// copy length - 4 (copies of 4..64 bytes), kTokLiteral (no copy: the block's
+// last literal) or kTokException: a token that does not fit - a literal of
+// 1 024 bytes or more, a copy of more than 64 - whose three numbers lie, in
+// round 5's 8-byte form (literal | copy << 17 | offset << 33), in the block's
+// exception list, in the order of their tokens.  Such a token covers 65
+// bytes of input or more, so a block has at most 1 008 of them.
+// Token slots per block: at most 16 385 tokens (every token but the last
+// ends in a copy of >= 4 bytes), rounded up to whole 128-byte groups of 32 so
+// a lane can write its tokens a full line at a time; the exception lists (8
+// bytes x tok_stride / 16 per block) lie behind the token arrays of a launch:
+// 4.5 x tok_stride bytes per block in all, 73.9 KB (round 5: 131.2).
+constexpr uint32_t kMaxTokens = 16416;
 constexpr uint32_t kMaxTokensSmall = 8192 / 4 + 64; // blocks of <= 8 KiB
+constexpr uint32_t kTokLiteral = 61, kTokException = 62;
+#if defined(__HIPCC__)
+__device__ __forceinline__ bool tok_fits(uint32_t lit, uint32_t copy)
+{
+    return lit <= 1023u && copy <= 64u;
+}
+// (copy == 0: a literal alone; a copy is 4 bytes or more)
+__device__ __forceinline__ uint32_t tok_pack(uint32_t lit, uint32_t copy,
+                                             uint32_t offset)
+{
+    const uint32_t field = copy ? copy - 4u : kTokLiteral;
+    return tok_fits(lit, copy) ? (offset << 16) | (field << 10) | lit
+                               : kTokException << 10;
+}
+__device__ __forceinline__ unsigned long long tok_pack64(uint32_t lit,
+                                                         uint32_t copy,
+                                                         uint32_t offset)
+{
+    return (unsigned long long)lit | ((unsigned long long)copy << 17) |
+           ((unsigned long long)offset << 33);
+}
+#endif
 
 // Batch of raw streams to decompress.
 struct DecompressArgs {
