@@ -62,6 +62,28 @@ def build_round():
         lens, dtype=np.int64), shas
 
 
+def source_sha16():
+    """sha256[:16] over the sources a bench line is a measurement OF: the
+    kernels and the C ABI (rust-snappy_amd/csrc, include), the Python
+    mirror, this file and bench_configs.py - in sorted order, path and bytes.
+    The GPU box has no .git; this is how a line under profiles/ says which
+    code it is of (tests/test_bench_spawn_cpu.py compares the committed final
+    line with the tree)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = []
+    for pat in ("rust-snappy_amd/csrc/*", "include/*.h",
+                "rust-snappy_amd/*.py"):
+        files += sorted(ROOT.glob(pat))
+    files += [ROOT / "bench.py", ROOT / "bench_configs.py"]
+    for f in files:
+        if f.is_file() and f.suffix in (".hip", ".hpp", ".h", ".py", ".map",
+                                        "") and f.name != "__pycache__":
+            h.update(str(f.relative_to(ROOT)).encode())
+            h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def usable_cores():
     """CPUs this process can actually use: the scheduler affinity mask capped
     by the cgroup CPU quota (os.cpu_count() is the machine's, not ours)."""
@@ -797,7 +819,8 @@ def main():
                     :200]
         if not traffic_measured:
             pmc_name = None
-            for cand in ("r5_pmc_traffic.json", "r4_pmc_traffic.json",
+            for cand in ("r6_pmc_traffic.json", "r5_pmc_traffic.json",
+                         "r4_pmc_traffic.json",
                          "r3_pmc_traffic.json"):
                 if (ROOT / "profiles" / cand).exists():
                     pmc_name = cand
@@ -853,6 +876,8 @@ def main():
                     "avg_ms": round(kc * 1e3, 3),
                     "achieved": round(alg / kc / 1e9, 2),
                     "frac": round(alg / kc / 1e9 / HBM_PEAK_GBS, 5)}},
+            "source_sha16": source_sha16(),
+            "git_sha": os.environ.get("SNAPMI_GIT_SHA"),
             "placement": placement_log,
             "first_compress_call_ms": round(first_call_ms, 1),
             "free_gib_around_first_call": [

@@ -63,3 +63,27 @@ def test_more_gpus_than_devices_is_refused():
         return
     p = run(["--gpus", "2"])
     assert p.returncode != 0 and "GPU(s) visible" in p.stderr
+
+
+def test_committed_final_bench_line_is_of_this_tree():
+    """Round 5 landed placement code after its last full bench run, and the
+    driver's record then held a row nobody had seen.  The final line of a
+    round (profiles/r6_final_bench.json: one default `python bench.py` on one
+    box) says which sources it measured - `source_sha16`, sha256 over the
+    kernels, the C ABI, the Python mirror, bench.py and bench_configs.py - and
+    this test compares it with the tree: code that lands behind the last full
+    run fails here."""
+    import json
+    import pytest
+    from conftest import ROOT
+    import bench
+    path = ROOT / "profiles" / "r6_final_bench.json"
+    if not path.exists():
+        pytest.skip("no final bench line committed yet")
+    line = json.loads(path.read_text().strip().splitlines()[-1])
+    assert line["source_sha16"] == bench.source_sha16(), \
+        "sources changed after the final bench run: run " \
+        "tests/hw/final_profile.sh again and commit profiles/r6_final_*"
+    assert line["n_gpus"] == 1 and line["roofline"]["traffic_measured"]
+    assert line["cpu_baseline"]["kind"] == "port"
+    assert "sweep" in line["extras"] and "budget" in line["extras"]
