@@ -183,6 +183,14 @@ SNAPMI_API const char *snapmi_version(void);
  *                          to 2047 bytes (slower than the block kernels from
  *                          1 KiB on); 0: they are one-block streams of the
  *                          block kernels
+ *   "span_schedule"        1 (default): a window-kernel launch of more blocks
+ *                          than it has wavefronts (1 280) chooses the order
+ *                          of its blocks as it goes - the first block of
+ *                          every stream first, then the blocks of streams
+ *                          that proved heavy, the light ones last - so that
+ *                          it ends with small jobs (256 MiB of mixed files:
+ *                          a quarter less time); 0: ticket order; 2: also
+ *                          for fewer blocks
  *   "lane_min_blocks"      batches with at least this many 64 KiB blocks use
  *                          the lane-per-block kernel (default 20480 = 1.25 GiB)
  *   "lane_speculate"       1 (default): a lane-kernel launch of at most 24 576

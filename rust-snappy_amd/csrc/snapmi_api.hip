@@ -283,7 +283,7 @@ void snapmi_ctx_destroy(snapmi_ctx *ctx)
                       &ctx->order, &ctx->fr_tables, &ctx->fr_desc,
                       &ctx->fr_meta, &ctx->fr_scan, &ctx->fr_slots,
                       &ctx->fr_chunk_off,
-                      &ctx->tokens, &ctx->ntok,
+                      &ctx->tokens, &ctx->ntok, &ctx->sched,
                       &ctx->lane_epochs, &ctx->sd_tables, &ctx->sd_desc,
                       &ctx->bl_modes, &ctx->bl_list, &ctx->bl_descs,
                       &ctx->bl_order})
@@ -341,6 +341,8 @@ int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value)
         ctx->lane_table_budget_pct = (uint32_t)value;
     else if (strcmp(name, "window_tokens") == 0 && value >= 0 && value <= 1)
         ctx->window_tokens = (int)value;
+    else if (strcmp(name, "span_schedule") == 0 && value >= 0 && value <= 2)
+        ctx->span_schedule = (int)value;
     else if (strcmp(name, "lane_coresident") == 0 && value >= 0 && value <= 1)
         ctx->lane_coresident = (int)value;
     else if (strcmp(name, "lane_coresident_min_blocks") == 0 && value >= 1)
@@ -939,21 +941,28 @@ static int place_lane_tables(snapmi_ctx *ctx, uint32_t lanes,
                 ctx->lane_chunk_bytes = CH;
                 ctx->lane_va_bytes = need * CH;
                 ctx->lane_stride = tbytes / 16;
+                ctx->lane_chunk_count = (uint32_t)need;
+                ctx->lane_per_chunk = (uint32_t)(CH / tbytes);
                 float ms = 0;
+                const uint32_t per_chunk = (uint32_t)(CH / tbytes);
                 hipLaunchKernelGGL(k_probe_tables, dim3(lanes / 64), dim3(64),
                                    0, ctx->stream, (unsigned long long *)va,
-                                   (unsigned long long)(tbytes / 16), 64u);
+                                   (unsigned long long)(tbytes / 16), 64u,
+                                   (uint32_t)need, per_chunk);
                 HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
                 hipLaunchKernelGGL(k_probe_tables, dim3(lanes / 64), dim3(64),
                                    0, ctx->stream, (unsigned long long *)va,
-                                   (unsigned long long)(tbytes / 16), 768u);
+                                   (unsigned long long)(tbytes / 16), 768u,
+                                   (uint32_t)need, per_chunk);
                 HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
                 HIP_TRY(ctx, hipEventSynchronize(ctx->ev[5]));
                 HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]));
                 // tables start as "never used": epoch 0 in every entry
+                // (every chunk in full: the lanes' tables are dealt out
+                // over all of them)
                 hipLaunchKernelGGL(k_zero16, dim3(ctx->num_cus * 8), dim3(256),
                                    0, ctx->stream, (unsigned long long *)va,
-                                   (unsigned long long)(bytes / 16));
+                                   (unsigned long long)(need * CH / 16));
                 HIP_TRY(ctx, hipMemsetAsync(ctx->lane_epochs.p, 0,
                                             (size_t)lanes * 4, ctx->stream));
                 ctx->n_lanes = lanes;
@@ -1021,11 +1030,13 @@ static int place_lane_tables(snapmi_ctx *ctx, uint32_t lanes,
         if (tries > 1 || ctx->lane_table_probe || top_of_memory) {
             hipLaunchKernelGGL(k_probe_tables, dim3(lanes / 64), dim3(64), 0,
                                ctx->stream, (unsigned long long *)c.p,
-                               (unsigned long long)(c.stride / 16), 64u);
+                               (unsigned long long)(c.stride / 16), 64u, 0u,
+                               0u);
             HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
             hipLaunchKernelGGL(k_probe_tables, dim3(lanes / 64), dim3(64), 0,
                                ctx->stream, (unsigned long long *)c.p,
-                               (unsigned long long)(c.stride / 16), 768u);
+                               (unsigned long long)(c.stride / 16), 768u, 0u,
+                               0u);
             HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
             HIP_TRY(ctx, hipEventSynchronize(ctx->ev[5]));
             HIP_TRY(ctx, hipEventElapsedTime(&c.ms, ctx->ev[4], ctx->ev[5]));
@@ -1063,6 +1074,8 @@ static int place_lane_tables(snapmi_ctx *ctx, uint32_t lanes,
                                   lanes, ctx->stream));
     ctx->lane_tables.p = held.best.p;
     ctx->lane_tables.cap = held.best.bytes;
+    ctx->lane_chunk_count = 0;
+    ctx->lane_per_chunk = 0;
     ctx->lane_stride = held.best.stride / 16;
     held.best = Cand(); // the context owns it now
     HIP_TRY(ctx, hipMemsetAsync(ctx->lane_epochs.p, 0, (size_t)lanes * 4,
@@ -1173,10 +1186,13 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     a.ticket = (uint32_t *)ctx->ticket.p;
     a.tokens = nullptr;
     a.tok_exc = nullptr;
+    a.sched = nullptr;
     a.ntok = nullptr;
     a.lane_tables = nullptr;
     a.lane_epochs = nullptr;
     a.lane_stride = kMaxTable;
+    a.lane_chunks = 0;
+    a.lane_per_chunk = 0;
     a.n_lanes = 0;
     a.tok_base = 0;
     a.tok_stride = kMaxTokens;
@@ -1312,6 +1328,8 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
         a.lane_tables = (unsigned long long *)ctx->lane_tables.p;
         a.lane_epochs = (uint32_t *)ctx->lane_epochs.p;
         a.lane_stride = ctx->lane_stride;
+        a.lane_chunks = ctx->lane_chunk_count;
+        a.lane_per_chunk = ctx->lane_per_chunk;
         a.n_lanes = lanes;
     }
     a.prof = nullptr;
@@ -1398,6 +1416,24 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                                                      : ctx->num_cus / 2)
                                : (uint64_t)ctx->num_cus;
                 const uint32_t wgs = (uint32_t)(want < cus ? want : cus);
+                // several blocks per wavefront, the window kernel alone:
+                // the order of the blocks is chosen as the launch goes
+                // (SpanSched, snapmi_compress.hip: heavy streams first,
+                // light ones last - a launch ends with its small jobs)
+                bool sched = !lanes_mode && ctx->span_kernel &&
+                             (ctx->span_schedule == 2 ||
+                              (ctx->span_schedule == 1 &&
+                               blocks > (uint64_t)wgs * kCompressWaves));
+                if (sched) {
+                    const size_t head = (size_t)(16 + n) * 4;
+                    const size_t lists = (size_t)2 * (slots + 1) * 4;
+                    if ((rc = reserve(ctx, ctx->sched, head + lists)))
+                        return rc;
+                    HIP_TRY(ctx, hipMemsetAsync(ctx->sched.p, 0, head, ws));
+                    HIP_TRY(ctx, hipMemsetAsync((uint8_t *)ctx->sched.p + head,
+                                                0xFF, lists, ws));
+                    a.sched = (uint32_t *)ctx->sched.p;
+                }
 #ifdef SNAPMI_TESTING
                 hipLaunchKernelGGL(ctx->span_kernel ? k_compress_spans
                                                     : k_compress_blocks,
@@ -1407,6 +1443,7 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                 hipLaunchKernelGGL(k_compress_spans, dim3(wgs),
                                    dim3(kCompressWaves * 64), 0, ws, a);
 #endif
+                a.sched = nullptr;
             }
         }
         if (lanes_mode) {

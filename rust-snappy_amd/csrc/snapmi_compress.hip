@@ -821,11 +821,16 @@ __global__ __launch_bounds__(64) void k_probe_lds_order(uint32_t *bad)
 // ---------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_probe_tables(unsigned long long *tables,
                                                      unsigned long long stride,
-                                                     uint32_t steps)
+                                                     uint32_t steps,
+                                                     uint32_t chunks,
+                                                     uint32_t per_chunk)
 {
     typedef __attribute__((address_space(1))) u32x4 g_u32x4;
     const uint32_t gid = blockIdx.x * 64 + threadIdx.x;
-    g_u32x4 *t = (g_u32x4 *)tables + (uint64_t)gid * stride;
+    // (the lane kernel's own lane -> table map: CompressArgs::lane_chunks)
+    const uint32_t slot =
+        chunks ? (gid % chunks) * per_chunk + gid / chunks : gid;
+    g_u32x4 *t = (g_u32x4 *)tables + (uint64_t)slot * stride;
     uint32_t state = gid * 2654435761u + 12345u;
     for (uint32_t i = 0; i < steps; i++) {
         const uint32_t h = (state * 0x1E35A7BDu) >> 18;
@@ -1582,6 +1587,140 @@ __global__ __launch_bounds__(1024) void k_post_ratio(
     }
 }
 
+// ---------------------------------------------------------------------
+// The order of a window-kernel launch (round 6).  A block is one wavefront's
+// from start to end, blocks differ in cost by what they hold (kppkn.gtb:
+// 1 884 window steps a block, HTML 740, a PDF 100), and a launch of a few
+// blocks per wavefront in ticket order ends when its last-started heavy block
+// does: 256 MiB of the corpus round took 7.9 ms where the work divided by the
+// wavefronts is 5 (list scheduling: makespan <= mean + the heaviest job).
+// Longest-first needs the costs, and the only cheap predictor of a block's
+// cost is a block of the same stream.  So: pass 1 = the FIRST block of every
+// stream; whoever finishes a block posts its cycles per KiB for its stream.
+// Pass 2 = the other blocks in stream order - but a wavefront that draws a
+// block of a stream known to be light or middling (under 0.7 / 1.3 of the
+// launch's running mean) puts it on a list instead and draws again: the heavy
+// and the unknown run first, the middle list next, the light list last, and
+// the launch ends with small jobs.  Every block is run exactly once; results
+// do not depend on the order (blocks are independent:
+// src/compress.rs:148,514-516).
+//   sched[0] ticket  [1] blocks classified in pass 2  [2] blocks costed
+//   [3] (unused)  [4..5] u64 sum of costs  [6] pushed M  [7] popped M
+//   [8] pushed L  [9] popped L            then: cost[n_streams],
+//   listM[slots], listL[slots] (kSchedEmpty = not written yet)
+// ---------------------------------------------------------------------
+namespace {
+constexpr uint32_t kSchedEmpty = 0xFFFFFFFFu, kSchedHead = 16;
+struct SpanSched {
+    uint32_t *w;
+    uint32_t n_streams, slots, nblocks;
+    __device__ __forceinline__ uint32_t *cost() const { return w + kSchedHead; }
+    __device__ __forceinline__ uint32_t *list(int which) const
+    {
+        return w + kSchedHead + n_streams + (which ? slots : 0);
+    }
+    // the stream of pass-2 entry j: slot_first[st] <= j < slot_first[st + 1]
+    __device__ __forceinline__ uint32_t stream_of_slot(const CompressArgs &a,
+                                                       uint32_t j) const
+    {
+        uint32_t lo = 0, hi = n_streams;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (a.slot_first[mid] <= j)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        return lo;
+    }
+    // lane 0: the next block to run, or kSchedEmpty when the launch is over
+    __device__ uint32_t next(const CompressArgs &a)
+    {
+        for (;;) {
+            const uint32_t t = atomicAdd(&w[0], 1u);
+            if (t >= n_streams + slots)
+                break;
+            if (t < n_streams) { // pass 1: the stream's first block
+                const uint32_t b = a.blk_first[t];
+                if (a.blk_first[t + 1] > b && b < nblocks)
+                    return b;
+                continue; // a stream without blocks
+            }
+            const uint32_t j = t - n_streams;
+            const uint32_t st = stream_of_slot(a, j);
+            const uint32_t b = a.blk_first[st] + (j - a.slot_first[st]) + 1;
+            uint32_t cls = 0; // 0 run now, 1 middle list, 2 light list
+            if (b < nblocks) {
+                const uint32_t c = __hip_atomic_load(
+                    &cost()[st], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t done = __hip_atomic_load(
+                    &w[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (c && done >= 64) {
+                    const unsigned long long sum = __hip_atomic_load(
+                        (unsigned long long *)&w[4], __ATOMIC_RELAXED,
+                        __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long mean = sum / done;
+                    cls = 10ull * c < 7ull * mean    ? 2
+                          : 10ull * c < 13ull * mean ? 1
+                                                     : 0;
+                }
+                if (cls) {
+                    const uint32_t i = atomicAdd(&w[cls == 1 ? 6 : 8], 1u);
+                    __hip_atomic_store(&list(cls - 1)[i], b, __ATOMIC_RELEASE,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            __threadfence();
+            atomicAdd(&w[1], 1u); // this entry is classified
+            if (b < nblocks && cls == 0)
+                return b;
+        }
+        // the lists: middle first, then light; an entry may still be on its
+        // way while pass 2 is being classified by others
+        for (int which = 0; which < 2; which++) {
+            for (;;) {
+                const uint32_t i = atomicAdd(&w[which ? 9 : 7], 1u);
+                if (i >= slots)
+                    break;
+                uint32_t b;
+                for (;;) {
+                    b = __hip_atomic_load(&list(which)[i], __ATOMIC_ACQUIRE,
+                                          __HIP_MEMORY_SCOPE_AGENT);
+                    if (b != kSchedEmpty)
+                        break;
+                    const uint32_t cl = __hip_atomic_load(
+                        &w[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    if (cl >= slots &&
+                        i >= __hip_atomic_load(&w[which ? 8 : 6],
+                                               __ATOMIC_ACQUIRE,
+                                               __HIP_MEMORY_SCOPE_AGENT))
+                        break; // all of pass 2 is classified: none will come
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                if (b == kSchedEmpty)
+                    break;
+                return b;
+            }
+        }
+        return kSchedEmpty;
+    }
+    // lane 0, behind a block of n bytes of stream st that took `cycles`
+    __device__ __forceinline__ void post(uint32_t st, uint32_t n,
+                                         unsigned long long cycles)
+    {
+        unsigned long long c = (cycles << 10) / (n ? n : 1);
+        if (c > 0x7FFFFFFFull)
+            c = 0x7FFFFFFFull;
+        if (c == 0)
+            c = 1;
+        __hip_atomic_store(&cost()[st], (uint32_t)c, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        atomicAdd((unsigned long long *)&w[4], c);
+        atomicAdd(&w[2], 1u);
+    }
+};
+} // namespace
+
 __global__ __launch_bounds__(kCompressWaves * 64) void k_compress_spans(
     CompressArgs a)
 {
@@ -1594,6 +1733,42 @@ __global__ __launch_bounds__(kCompressWaves * 64) void k_compress_spans(
     uint32_t nblocks = a.blk_first[a.n_streams];
     if (nblocks > a.host_blocks)
         nblocks = a.host_blocks;
+    if (a.sched) { // the order chosen as the launch goes (SpanSched)
+        SpanSched sc;
+        sc.w = a.sched;
+        sc.n_streams = a.n_streams;
+        sc.slots = a.slot_first[a.n_streams] < a.host_slots
+                       ? a.slot_first[a.n_streams]
+                       : a.host_slots;
+        sc.nblocks = nblocks;
+        for (;;) {
+            uint32_t b = 0;
+            if (lane == 0)
+                b = sc.next(a);
+            b = uni(b);
+            if (b == kSchedEmpty)
+                break;
+            const unsigned long long t0 = __builtin_readcyclecounter();
+            compress_one_block_span<false>(a, b, lane, table, tbase);
+            if (lane == 0) {
+                // (the block's stream and length once more: two loads and a
+                // short search per block of ~4 M cycles)
+                uint32_t lo = 0, hi = a.n_streams;
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (a.blk_first[mid] <= b)
+                        lo = mid;
+                    else
+                        hi = mid;
+                }
+                const uint64_t left =
+                    a.in_lens[lo] - (uint64_t)(b - a.blk_first[lo]) * kMaxBlock;
+                sc.post(lo, left < kMaxBlock ? (uint32_t)left : kMaxBlock,
+                        __builtin_readcyclecounter() - t0);
+            }
+        }
+        return;
+    }
     uint32_t b = uni(next_ticket(a.ticket, lane, nblocks));
     while (b != 0xFFFFFFFFu) {
         if (lane == 0 && a.ntok)
@@ -2015,7 +2190,11 @@ __device__ __forceinline__ void match_blocks(
     typedef __attribute__((address_space(1))) u64x2 g_entry;
     // 16-byte entries: x = bytes 0..7 at the position, y = bytes 8..11 |
     // position << 32 | epoch << 48
-    g_entry *const tab = (g_entry *)a.lane_tables + (uint64_t)g * a.lane_stride;
+    const uint32_t slot =
+        a.lane_chunks ? (g % a.lane_chunks) * a.lane_per_chunk + g / a.lane_chunks
+                      : g;
+    g_entry *const tab =
+        (g_entry *)a.lane_tables + (uint64_t)slot * a.lane_stride;
     unsigned long long epoch = a.lane_epochs[g]; // 16 bits used
     unsigned long long first8 = 0; // bytes 0..11 of the block (empty entry)
     uint32_t first4b = 0;

@@ -55,6 +55,7 @@ struct snapmi_ctx {
     // bytes of the range; empty / 0 when lane_tables.p came from hipMalloc
     std::vector<hipMemGenericAllocationHandle_t> lane_chunks;
     size_t lane_chunk_bytes = 0, lane_va_bytes = 0;
+    uint32_t lane_chunk_count = 0, lane_per_chunk = 0; // lane -> table map
     uint32_t n_lanes = 0;
     uint64_t lane_stride = 0;      // 16-byte entries between two lanes' tables
     bool lane_table_spread = true; // spread the tables over free memory
@@ -71,6 +72,11 @@ struct snapmi_ctx {
     // scratch).  Measured equal within 3 % either way on 64 MiB .. 1 GiB
     // (profiles/r5_span_sweep.txt), so the path without scratch is the default
     int window_tokens = 0;
+    // k_compress_spans on more blocks than it has wavefronts: 1 (default) the
+    // order of the blocks is chosen as the launch goes (SpanSched,
+    // snapmi_compress.hip), 0 ticket order, 2 scheduled whatever the count
+    int span_schedule = 1;
+    snapmi::DevBuf sched;
     // 1: lane-kernel launches of at least lane_coresident_min_blocks blocks
     // run k_match_both - three lane wavefronts and two window wavefronts on
     // every CU, one two-ended ticket

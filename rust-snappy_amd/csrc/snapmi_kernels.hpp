@@ -28,6 +28,10 @@ struct CompressArgs {
     uint32_t host_blocks; // launch geometry computed from the host lengths
     uint32_t host_slots;
     uint32_t *ticket; // device-wide block ticket counter, zeroed per launch
+    // k_compress_spans alone on a batch of several blocks per wavefront:
+    // the order of the blocks is chosen as the launch goes (SpanSched in
+    // snapmi_compress.hip); nullptr: blocks in ticket order
+    uint32_t *sched;
     // lane-per-block match finder (k_match_blocks): token stream per block,
     // per-lane epoch-tagged hash tables in HBM
     // [(blk_hi - blk_lo) * tok_stride] u32 tokens, then [.. * tok_stride /
@@ -44,6 +48,12 @@ struct CompressArgs {
     uint32_t direct; // k_encode_tokens writes final positions (no slots)
     unsigned long long *lane_tables; // lane g: 16-byte entries from g * lane_stride
     unsigned long long lane_stride;  // >= kMaxTable (tables are spread out)
+    // tables made of mapped chunks (place_lane_tables): lane g's table is
+    // slot (g % lane_chunks) * lane_per_chunk + g / lane_chunks, so that a
+    // launch of FEWER lanes than the context has tables still uses every
+    // chunk - the spread over the device's memory is what the chunks are for
+    // (0: slot g)
+    uint32_t lane_chunks, lane_per_chunk;
     uint32_t *lane_epochs;      // [lanes]
     uint32_t n_lanes;
     // experiment builds (-DSNAPMI_PROFILE) only: 16 u64 cycle counters
@@ -147,7 +157,8 @@ __global__ void k_seam_compress_tiny(const uint8_t *in, uint32_t n,
 __global__ void k_seam_decompress_tiny(DecompressArgs a, uint32_t *done,
                                        uint32_t seq);
 __global__ void k_probe_tables(unsigned long long *tables,
-                               unsigned long long stride, uint32_t steps);
+                               unsigned long long stride, uint32_t steps,
+                               uint32_t chunks, uint32_t per_chunk);
 __global__ void k_plan_compress(CompressArgs a);
 __global__ void k_plan_compress_a(CompressArgs a);
 __global__ void k_plan_compress_b(CompressArgs a, uint32_t nparts);

@@ -77,7 +77,8 @@ def ctx(request, built):
                 params=["spans", "spans_lds", "waves", "waves_lds", "lanes",
                         "lanes_segmented", "lanes_overlap", "both",
                         "spans_match", "small_tables", "small_tables_lanes",
-                        "coresident", "product", "product-lanes",
+                        "coresident", "spans_sched", "product",
+                        "product-lanes",
                         "product-spans_lds", "product-small_tables",
                         "product-coresident"])
 def cctx(request, built):
@@ -112,6 +113,11 @@ def cctx(request, built):
         c = product_context()
     else:
         c = R.raw.Context(0)
+    if request.param == "spans_sched":
+        # the window kernel with the order of its blocks chosen as the launch
+        # goes (SpanSched), however few blocks there are
+        request = type("P", (), {"param": "spans"})
+        c.set_option("span_schedule", 2)
     c.set_option("compress_mode", {"spans": 0, "spans_lds": 0, "waves": 0,
                                    "waves_lds": 0, "lanes": 1,
                                    "lanes_segmented": 1, "lanes_overlap": 1,
