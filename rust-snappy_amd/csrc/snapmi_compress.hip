@@ -1634,7 +1634,9 @@ struct SpanSched {
         return lo;
     }
     // lane 0: the next block to run, or kSchedEmpty when the launch is over
-    __device__ uint32_t next(const CompressArgs &a)
+    // (out of line, like next_ticket: an inlined ticket loop under `if (lane
+    // == 0)` inside a persistent loop once compiled into a hang)
+    __device__ __forceinline__ uint32_t next(const CompressArgs &a)
     {
         for (;;) {
             const uint32_t t = atomicAdd(&w[0], 1u);
@@ -1721,6 +1723,18 @@ struct SpanSched {
 };
 } // namespace
 
+// (the whole wavefront calls, lane 0 draws - the shape of next_ticket, which
+// is known to compile into what it says inside a persistent loop)
+__device__ __noinline__ uint32_t span_sched_next(SpanSched sc,
+                                                 const CompressArgs &a,
+                                                 uint32_t lane)
+{
+    uint32_t b = 0;
+    if (lane == 0)
+        b = sc.next(a);
+    return uni(b);
+}
+
 __global__ __launch_bounds__(kCompressWaves * 64) void k_compress_spans(
     CompressArgs a)
 {
@@ -1742,10 +1756,7 @@ __global__ __launch_bounds__(kCompressWaves * 64) void k_compress_spans(
                        : a.host_slots;
         sc.nblocks = nblocks;
         for (;;) {
-            uint32_t b = 0;
-            if (lane == 0)
-                b = sc.next(a);
-            b = uni(b);
+            const uint32_t b = uni(span_sched_next(sc, a, lane));
             if (b == kSchedEmpty)
                 break;
             const unsigned long long t0 = __builtin_readcyclecounter();
