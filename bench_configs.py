@@ -422,12 +422,13 @@ def round_tiles(ctx, dev, gib, steps, diag=None):
         ctx.synchronize()
         calls.append(round((time.perf_counter() - t0) * 1e3, 2))
     te = time_it(enc_logged if diag is not None else enc, steps, ctx)
+    enc_kernel = ctx.last_kernel()
     td = time_it(dec, steps, ctx)
     if diag is not None:
         diag.update({
             "first_call_ms": round(first_ms, 1),
             "call_ms": calls,            # the warm call, then the timed ones
-            "kernel": ctx.last_kernel(),
+            "kernel": enc_kernel,        # the compress side's dominant kernel
             "placement": ctx.table_probe_log(),
             "free_gib_before": round(free0 / GIB, 1),
             "free_gib_after": round(torch.cuda.mem_get_info(dev)[0] / GIB, 1)})
