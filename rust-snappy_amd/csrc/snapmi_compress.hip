@@ -1122,18 +1122,12 @@ struct WaveDev {
     }
 };
 
-// early_cost (k_compress_spans with its launch order, SpanSched): where lane
-// 0 posts the block's cycles per KiB once 8 KiB of it are parsed - if the
-// stream's cost is still unknown - so that the other blocks of the stream can
-// be classified long before this one ends; t0 = the cycle counter at the
-// block's start.  nullptr (every other caller): nothing, at no cost.
 template <bool kLds, bool kTok = false>
 __device__ __forceinline__ void compress_one_block_span(
     const CompressArgs &a, const uint32_t b, const uint32_t lane,
     const lptr16 table, const uint32_t tbase,
     __attribute__((address_space(3))) uint8_t *lblock = nullptr,
-    const uint32_t tcap = kMaxTable, uint32_t *early_cost = nullptr,
-    const unsigned long long t0 = 0)
+    const uint32_t tcap = kMaxTable)
 {
     // stream lookup: blk_first[st] <= b < blk_first[st + 1]
     uint32_t lo_s = 0, hi_s = a.n_streams;
@@ -1268,14 +1262,12 @@ __device__ __forceinline__ void compress_one_block_span(
         )
         TICK(0);
         // room for a step's tokens (at most 16 copies of a window + a long
-        // match): tokens are encoded in one place per kind of step - in a
-        // window step UNDER the gather of the candidates' bytes (round 6:
-        // the flush is independent of what the step is waiting for there)
+        // match): the one place where tokens are encoded
+        if constexpr (!kTok) {
+            if (out.t + 17 > kWave)
+                out.flush();
+        }
         if (!st.chain && st.q >= kSpanRun) {
-            if constexpr (!kTok) {
-                if (out.t + 17 > kWave)
-                    out.flush();
-            }
             // ---- schedule step (k_compress_blocks' batch for q > 0): lane l
             // is probe q + l of the run that began at run0
             // (this lane's two schedule entries were requested one step
@@ -1359,10 +1351,6 @@ __device__ __forceinline__ void compress_one_block_span(
                       0xFFFFu;
             TICK(2);
             const B16 y = ld128u(msrc + old);
-            if constexpr (!kTok) {
-                if (out.t + 17 > kWave)
-                    out.flush();
-            }
             TICK(3);
             SpanLanes ln;
             ln.mv = common16(x, y);
@@ -1448,15 +1436,6 @@ __device__ __forceinline__ void compress_one_block_span(
                 run0 = st.s - st.q;
             }
             TICK(6);
-            if (early_cost && st.s >= 8192u) {
-                if (lane == 0) {
-                    unsigned long long c =
-                        ((__builtin_readcyclecounter() - t0) << 10) / st.s;
-                    c = c > 0x7FFFFFFFull ? 0x7FFFFFFFull : (c ? c : 1);
-                    atomicCAS(early_cost + st_i, 0u, (uint32_t)c);
-                }
-                early_cost = nullptr;
-            }
         }
         // keep the register window covering s - 1 .. s + 126
         if constexpr (!kLds) {
@@ -1781,8 +1760,7 @@ __global__ __launch_bounds__(kCompressWaves * 64) void k_compress_spans(
             if (b == kSchedEmpty)
                 break;
             const unsigned long long t0 = __builtin_readcyclecounter();
-            compress_one_block_span<false>(a, b, lane, table, tbase, nullptr,
-                                           kMaxTable, sc.cost(), t0);
+            compress_one_block_span<false>(a, b, lane, table, tbase);
             if (lane == 0) {
                 // (the block's stream and length once more: two loads and a
                 // short search per block of ~4 M cycles)

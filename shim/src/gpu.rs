@@ -32,6 +32,9 @@ pub const SNAPMI_FRAME_CONTINUATION: u32 = 1;
 pub const SNAPMI_FRAME_FINAL: u32 = 2;
 pub const SNAPMI_E_UNEXPECTED_EOF: i32 = 64;
 pub const SNAPMI_E_DEVICE: i32 = 100;
+/// `snapmi_ctx_prepare`: place the tables at the far end of the device's
+/// memory (holds ALL free device memory for a moment: include/snapmi.h)
+pub const SNAPMI_PREPARE_TOP_OF_MEMORY: u32 = 1;
 
 extern "C" {
     pub fn snapmi_ctx_create(device: c_int, hip_stream: *mut c_void, out: *mut *mut SnapmiCtx) -> c_int;
@@ -49,6 +52,7 @@ extern "C" {
         ctx: *mut SnapmiCtx, input: *const u8, input_len: usize, output: *mut u8,
         output_cap: usize, written: *mut usize, err: *mut SnapmiError,
     ) -> c_int;
+    pub fn snapmi_ctx_prepare(ctx: *mut SnapmiCtx, blocks: u64, flags: u32) -> c_int;
     pub fn snapmi_host_alloc(bytes: usize) -> *mut c_void;
     pub fn snapmi_host_free(p: *mut c_void);
     pub fn snapmi_frame_scan_host(

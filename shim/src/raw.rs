@@ -6,6 +6,8 @@
 //! (`snapmi_compress_batch` / the frame types of this crate), not with one
 //! 100 KB call at a time - see INTEGRATION.md section 1 for the latency of
 //! these calls.
+use std::io;
+
 use crate::error::{Error, Result};
 use crate::gpu::{self, Context, Failure, SnapmiError};
 use crate::MAX_INPUT_SIZE;
@@ -48,6 +50,23 @@ impl Encoder {
     /// A new encoder on this thread's GPU.
     pub fn new() -> Encoder {
         Encoder { ctx: Context::new() }
+    }
+
+    /// Not in the reference: allocates, now, the device memory that batches
+    /// of up to `blocks` 64 KiB blocks will need (`snapmi_ctx_prepare`) - what
+    /// `Encoder::new` does for the reference's 34 KiB of tables
+    /// (src/compress.rs:80-82) is gigabytes here, so it is a call of its own.
+    /// `top_of_memory`: see `SNAPMI_PREPARE_TOP_OF_MEMORY` in include/snapmi.h
+    /// (for a process that owns the GPU; seizes it for a moment).
+    pub fn prepare(&mut self, blocks: u64, top_of_memory: bool) -> io::Result<()> {
+        let flags = if top_of_memory { gpu::SNAPMI_PREPARE_TOP_OF_MEMORY } else { 0 };
+        match unsafe { gpu::snapmi_ctx_prepare(self.ctx.as_ptr(), blocks, flags) } {
+            0 => Ok(()),
+            k => Err(io::Error::new(
+                io::ErrorKind::Other,
+                format!("snapmi_ctx_prepare: {} ({})", k, self.ctx.last_error()),
+            )),
+        }
     }
 
     /// Compresses `input` into `output` (which must hold
