@@ -1,6 +1,8 @@
 """The lane tables' placement as the library chooses it: bench.py's workload
 on fresh contexts at lane_table_budget_pct 33 (the default), 20 and 10 -
-compress ms, GiB/s, the probe log; a negative percentage: lane_table_high 0
+compress ms, GiB/s, the probe log; a negative percentage: the far end of the
+memory first (snapmi_ctx_prepare with SNAPMI_PREPARE_TOP_OF_MEMORY; round 5's
+lane_table_high option is gone)
 (no filler in front of the first candidate).
 usage: python tests/hw/table_budget.py [gib] [pct ...]"""
 import sys
@@ -23,7 +25,8 @@ print(f"# bench.py's workload at {gib:g} GiB, compress, a fresh context per "
 for pct in pcts:
     c = raw.Context(0)
     c.set_option("lane_table_budget_pct", abs(pct))
-    c.set_option("lane_table_high", 1 if pct > 0 else 0)
+    if pct < 0:  # 8 GiB of the corpus round: 50 blocks per 2 928 571 bytes
+        c.prepare(int(gib * 2**30 / 2928571) * 50, top_of_memory=True)
     free0 = torch.cuda.mem_get_info(dev)[0]
     ub, cb, n, te, td = B.round_tiles(c, dev, gib, 3)
     log = _lib.load().snapmi_table_probe_log(c._h).decode()
