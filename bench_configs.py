@@ -497,7 +497,13 @@ def budget(args, ctx, dev):
         c.close()
         torch.cuda.empty_cache()
     # ... and the explicit opt-in: snapmi_ctx_prepare(TOP_OF_MEMORY) before
-    # the first batch (holds the whole device for a moment, include/snapmi.h)
+    # the first batch (holds the whole device for a moment, include/snapmi.h).
+    # NOTE what this row is: the call is made for a process that asks FIRST;
+    # here it is the fourth context of a process that has allocated and freed
+    # hundreds of GB, where "the far end" is wherever the allocator's free
+    # lists say (the device reuses what was freed last): the row shows the
+    # call's cost and that it works, not its best case
+    # (profiles/r6_budget_chunks.txt: 71.6-71.8 GiB/s in a fresh process)
     c = raw.Context(ctx.device)
     rounds = max(1, int(round(args.gib * GIB / 2928571)))
     free0 = torch.cuda.mem_get_info(dev)[0]

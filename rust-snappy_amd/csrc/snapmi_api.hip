@@ -916,7 +916,13 @@ static int place_lane_tables(snapmi_ctx *ctx, uint32_t lanes,
                 ok = hipMemSetAccess(va, need * CH, &acc, 1) == hipSuccess;
             }
             held_peak = all.size() * CH;
-            // give back what lies between (and, on failure, everything)
+            // give back what lies between - on failure everything: the
+            // mappings first, every chunk once, the address range
+            if (!ok) {
+                (void)hipGetLastError();
+                if (mapped)
+                    (void)hipMemUnmap(va, mapped * CH);
+            }
             std::vector<hipMemGenericAllocationHandle_t> kept;
             for (size_t i = 0; i < all.size(); i++) {
                 if (ok && i % pitch == pitch - 1)
@@ -925,11 +931,6 @@ static int place_lane_tables(snapmi_ctx *ctx, uint32_t lanes,
                     (void)hipMemRelease(all[i]);
             }
             if (!ok) {
-                (void)hipGetLastError();
-                if (mapped)
-                    (void)hipMemUnmap(va, mapped * CH);
-                for (size_t i = 0; i < mapped; i++)
-                    (void)hipMemRelease(all[i * pitch + pitch - 1]);
                 if (va)
                     (void)hipMemAddressFree(va, need * CH);
                 held_peak = 0;

@@ -871,7 +871,7 @@ def _budget_batch():
     return ins, batch.StreamBatch.from_bytes(ins)
 
 
-@pytest.mark.parametrize("lib", ["test", "product"])
+@pytest.mark.parametrize("lib", ["test", "product", "product-plain"])
 @pytest.mark.parametrize("pct", [10, 33])
 def test_lane_table_placement_stays_within_its_budget(built, pct, lib):
     """The GPU may be shared: NO compress call holds more than
@@ -881,14 +881,20 @@ def test_lane_table_placement_stays_within_its_budget(built, pct, lib):
     duration of two hipMallocs per candidate).  A second thread polls
     hipMemGetInfo while a context's first chip-filling launch (16 384 lanes
     or more) places its tables; the bytes are the oracle's as ever.  On the
-    test build and on the shipped library with its default options."""
+    test build and on the shipped library with its default options (tables
+    as mapped chunks), and on the shipped library without spreading (one
+    plain hipMalloc region)."""
     import re
     import torch
     from conftest import product_context
     from rust_snappy_amd import batch
-    if lib == "product":
+    if lib.startswith("product"):
         c = product_context()
         c.set_option("lane_min_blocks", 1)
+        if lib == "product-plain":
+            # no spreading: one packed region from hipMalloc, the path the
+            # placement also takes when the virtual-memory calls fail
+            c.set_option("lane_table_spread", 0)
     else:
         c = _lane_ctx()
     c.set_option("lane_table_budget_pct", pct)
@@ -903,7 +909,9 @@ def test_lane_table_placement_stays_within_its_budget(built, pct, lib):
                   r"apart, (\d+) lanes, (\d+) bytes \| placement ([0-9.]+) ms",
                   log)
     assert m, log
-    assert 1 <= len(re.findall(r"\d+\.\d+\(", m.group(1))) <= 2, log  # candidates
+    n_cand = len(re.findall(r"\d+\.\d+\(", m.group(1)))
+    assert (n_cand == 0 if lib == "product-plain" else 1 <= n_cand <= 2), log
+    assert ("chunks:" in log) == (lib != "product-plain"), log
     held, budget, kept = int(m.group(2)), int(m.group(3)), int(m.group(6))
     assert 0 < kept <= held <= budget <= pct / 100 * free1 + (1 << 20), log
     assert float(m.group(7)) < 3000, log          # no seconds of placement
