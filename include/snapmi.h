@@ -198,8 +198,15 @@ SNAPMI_API const char *snapmi_version(void);
  *                          the table entry of the probe that follows a miss -
  *                          fewer dependent rounds per block where a block's
  *                          latency is what is waited for; 0: never
- *   "lane_segment_blocks"  blocks per lane-kernel launch (default 262144 =
- *                          16 GiB of input; bounds the token scratch)
+ *   "lane_segment_blocks"  most blocks per lane-kernel launch (default
+ *                          262144 = 16 GiB of input).  A larger batch is
+ *                          matched and encoded in equal launches of at most
+ *                          this many blocks, and the token scratch - 72 KiB a
+ *                          block, 1.13x the input - is one launch's: at cfg2
+ *                          (146 700 blocks) 73 350 makes the context hold
+ *                          23.3 GB instead of 29.1 and costs 8 % of the
+ *                          compress rate, 48 900 21.2 GB (tokens 0.42x the
+ *                          input) and 25 % (profiles/r6_token_segments.txt)
  *   "lane_table_spread"    1 (default): the lane kernel's hash tables are
  *                          spread over up to 4x their size, as far as the
  *                          budget below allows (HBM sustains up to 30 % more

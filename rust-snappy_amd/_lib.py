@@ -9,8 +9,9 @@ import os
 from pathlib import Path
 
 PKG_DIR = Path(__file__).resolve().parent
-# SNAPMI_LIB selects another build of the same ABI (ablation / experiment
-# builds made by `make -C rust-snappy_amd/csrc ablate`); never a CPU codec.
+# SNAPMI_LIB selects another build of the same ABI (the profile build of
+# `make -C rust-snappy_amd/csrc profile`, a fresh build in a scratch
+# directory: __graft_entry__.fresh_build_check); never a CPU codec.
 # A process that says SNAPMI_TESTING=1 (the test suite: tests/conftest.py; the
 # experiment drivers under tests/hw/) gets libsnapmi_test.so - the same
 # sources with the test knobs and the cross-check kernels compiled in

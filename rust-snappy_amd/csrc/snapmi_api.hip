@@ -773,6 +773,19 @@ constexpr size_t kPlanOneWg = 16384;
 // call, ten times over - 72 s for a context's first 4 GiB batch,
 // profiles/r6_sweep_repro_head.txt).  That is why it is a call of its own.
 // ---------------------------------------------------------------------
+// The lane kernel runs over segments of the block list so that the token
+// scratch stays bounded: at most lane_segment_blocks blocks a launch, and the
+// launches of a batch equal in size - a short last launch has one block per
+// lane or fewer and ends when its heaviest block does, as a full one would.
+static uint64_t segment_blocks(const snapmi_ctx *ctx, uint64_t blocks)
+{
+    if (blocks <= ctx->lane_segment_blocks)
+        return blocks;
+    const uint64_t launches =
+        (blocks + ctx->lane_segment_blocks - 1) / ctx->lane_segment_blocks;
+    return (blocks + launches - 1) / launches;
+}
+
 static uint32_t lane_count(const snapmi_ctx *ctx, uint64_t seg_blocks,
                            bool both_cores)
 {
@@ -1111,8 +1124,7 @@ int prepare_lane_tables(snapmi_ctx *ctx, uint64_t blocks, bool top)
 {
     if (ctx->compress_mode == 0 || blocks < ctx->lane_min_blocks)
         return SNAPMI_OK;
-    const uint64_t seg_blocks =
-        blocks < ctx->lane_segment_blocks ? blocks : ctx->lane_segment_blocks;
+    const uint64_t seg_blocks = segment_blocks(ctx, blocks);
     const bool both = ctx->compress_mode == 1 && ctx->lds_order_ok &&
                       ctx->lane_coresident &&
                       blocks >= ctx->lane_coresident_min_blocks;
@@ -1223,7 +1235,7 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     // (k_match_spans): every block at its final position, no slots, no
     // k_compact, the encoder a wide kernel of its own.  What the small-block
     // kernel runs on, and - option window_tokens - a mid-size batch (more
-    // than two blocks per CU, fewer than lane_min_blocks); costs 128 KiB of
+    // than two blocks per CU, fewer than lane_min_blocks); costs 72 KiB of
     // tokens per block of the batch.
     const bool win_tok =
         blocks > 0 && ctx->lds_order_ok && ctx->compress_mode == 1 && !big &&
@@ -1235,11 +1247,9 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     const bool lanes_mode =
         blocks > 0 &&
         (!ctx->lds_order_ok || (ctx->compress_mode != 0 && big) || win_tok);
-    // the lane kernel runs over segments of the block list so that the token
-    // scratch (128 KiB per block) stays bounded; "both at once" needs the
-    // whole list in one segment
-    const uint64_t seg_blocks =
-        blocks < ctx->lane_segment_blocks ? blocks : ctx->lane_segment_blocks;
+    // (segment_blocks: equal launches that bound the token scratch; "both at
+    // once" needs the whole list in one segment)
+    const uint64_t seg_blocks = segment_blocks(ctx, blocks);
     const bool waves_mode =
         blocks > 0 && ctx->lds_order_ok &&
         (!lanes_mode || ctx->compress_mode == 0 ||
@@ -1281,9 +1291,10 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     }
     // both match finders on every CU (k_match_both): launches that fill the
     // chip with lanes anyway
-    // tokens per block: 16 400 (128 KiB) - or 2 112 (16.5 KiB) when every
-    // block of the batch is of at most 8 KiB: a batch of 4 KiB pages used to
-    // reserve 32 times its input
+    // tokens per block: 16 416 of 4 bytes and an exception list of a sixteenth
+    // of that in 8-byte tokens (72 KiB together) - or 2 112 when every block
+    // of the batch is of at most 8 KiB: a batch of 4 KiB pages used to reserve
+    // 32 times its input
     const uint32_t tok_stride =
         use_small && nb_big == 0 ? kMaxTokensSmall : kMaxTokens;
     a.tok_stride = tok_stride;

@@ -977,7 +977,7 @@ static int frame_compress_impl(snapmi_ctx *ctx, const void *d_in,
     if (rc)
         return rc;
     // segments of at most lane_segment_blocks chunks (16 GiB of input by
-    // default): 76 KiB of slot + 128 KiB of tokens per chunk of a segment
+    // default): 76 KiB of slot + 72 KiB of tokens per chunk of a segment
     const uint32_t seg = n < ctx->lane_segment_blocks
                              ? n
                              : ctx->lane_segment_blocks;
