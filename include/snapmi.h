@@ -207,6 +207,20 @@ SNAPMI_API const char *snapmi_version(void);
  *                          23.3 GB instead of 29.1 and costs 8 % of the
  *                          compress rate, 48 900 21.2 GB (tokens 0.42x the
  *                          input) and 25 % (profiles/r6_token_segments.txt)
+ *   "token_pool_pct"       42 (default): the token pool - where the match
+ *                          finders of a large batch leave their tokens for
+ *                          the encoder, in pages of 2 KiB taken as a block
+ *                          needs them - is this share of what the worst case
+ *                          of every block would take (74 KiB a block, 1.16x
+ *                          the input; 42 % = 0.49x; the corpus round needs
+ *                          0.44x, English text 0.71x).  A block that finds no
+ *                          page is compressed a second time by the window
+ *                          kernel (same bytes; costs that block twice), and
+ *                          the context's next batch gets a pool half as large
+ *                          again when more than 1 % of a batch did.  100: no
+ *                          block ever spills.  Never under
+ *   "token_pool_min_pages" 32768 (default; 64 MiB): batches of up to 885
+ *                          blocks never spill
  *   "lane_table_spread"    1 (default): the lane kernel's hash tables are
  *                          spread over up to 4x their size, as far as the
  *                          budget below allows (HBM sustains up to 30 % more
@@ -282,6 +296,19 @@ SNAPMI_API int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t 
 #define SNAPMI_PREPARE_TOP_OF_MEMORY 1u
 SNAPMI_API int snapmi_ctx_prepare(snapmi_ctx *ctx, uint64_t blocks,
                                   uint32_t flags);
+
+/* What a context holds and what its last batch did, by name:
+ *   "scratch_bytes"         device memory the context's grow-only buffers
+ *                           hold now (lane tables, token pool, plans, ...)
+ *   "token_scratch_bytes"   ... the token pool, its page tables, the counts
+ *   "token_pool_pages"      pages (2 KiB) of the last token-path launch's pool
+ *   "token_pool_pct_now"    what token_pool_pct has grown to on this context
+ *   "token_pages_asked"     pages the last token-path launch asked for, and
+ *   "token_blocks_spilled"  blocks of it that found none and were compressed
+ *                           a second time (both wait for the launch)
+ * SNAPMI_E_ARGUMENT for a name that is not in this list. */
+SNAPMI_API int snapmi_ctx_get_info(snapmi_ctx *ctx, const char *name,
+                                   int64_t *value);
 
 /* ------------------------------------------------------------------ */
 /* 2. Scalar mirrors of snap::raw (host buffers; H2D + kernels + D2H).  */

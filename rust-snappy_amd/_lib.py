@@ -57,6 +57,8 @@ SYMBOLS = [
     ("snapmi_version", C.c_char_p, []),
     ("snapmi_ctx_set_option", C.c_int, [_P, C.c_char_p, C.c_int64]),
     ("snapmi_ctx_prepare", C.c_int, [_P, C.c_uint64, C.c_uint32]),
+    ("snapmi_ctx_get_info", C.c_int,
+     [_P, C.c_char_p, C.POINTER(C.c_int64)]),
     ("snapmi_ctx_set_test_option", C.c_int, [_P, C.c_char_p, C.c_int64]),
     ("snapmi_max_compress_len", _SZ, [_SZ]),
     ("snapmi_decompress_len", C.c_int, [C.c_char_p, _SZ, _SZP, _ERRP]),

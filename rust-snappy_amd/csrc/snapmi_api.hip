@@ -98,7 +98,8 @@ int release_batch_scratch(snapmi_ctx *ctx)
 {
     if (!ctx->release_scratch)
         return SNAPMI_OK;
-    for (DevBuf *b : {&ctx->tokens, &ctx->slots}) {
+    for (DevBuf *b : {&ctx->tokens, &ctx->tok_pages, &ctx->tok_stage,
+                      &ctx->slots}) {
         if (b->p) {
             HIP_TRY(ctx, hipFree(b->p));
             b->p = nullptr;
@@ -275,6 +276,8 @@ void snapmi_ctx_destroy(snapmi_ctx *ctx)
         (void)hipHostFree((void *)ctx->h_mail);
     if (ctx->h_ratio)
         (void)hipHostFree((void *)ctx->h_ratio);
+    if (ctx->h_tokstat)
+        (void)hipHostFree((void *)ctx->h_tokstat);
     snapmi::free_lane_tables(ctx);
     for (DevBuf *b : {&ctx->blk_first, &ctx->slot_first, &ctx->blk_size,
                       &ctx->blk_off, &ctx->slots, &ctx->plan_part,
@@ -283,7 +286,8 @@ void snapmi_ctx_destroy(snapmi_ctx *ctx)
                       &ctx->order, &ctx->fr_tables, &ctx->fr_desc,
                       &ctx->fr_meta, &ctx->fr_scan, &ctx->fr_slots,
                       &ctx->fr_chunk_off,
-                      &ctx->tokens, &ctx->ntok, &ctx->sched,
+                      &ctx->tokens, &ctx->tok_pages, &ctx->tok_stage,
+                      &ctx->ntok, &ctx->sched,
                       &ctx->lane_epochs, &ctx->sd_tables, &ctx->sd_desc,
                       &ctx->bl_modes, &ctx->bl_list, &ctx->bl_descs,
                       &ctx->bl_order})
@@ -341,6 +345,13 @@ int snapmi_ctx_set_option(snapmi_ctx *ctx, const char *name, int64_t value)
         ctx->lane_table_budget_pct = (uint32_t)value;
     else if (strcmp(name, "window_tokens") == 0 && value >= 0 && value <= 1)
         ctx->window_tokens = (int)value;
+    else if (strcmp(name, "token_pool_pct") == 0 && value >= 1 &&
+             value <= 100) {
+        ctx->token_pool_pct = (uint32_t)value;
+        ctx->token_pool_now = 0; // (what it had grown to is forgotten)
+    } else if (strcmp(name, "token_pool_min_pages") == 0 && value >= 0 &&
+               value <= 0x7FFFFFFF)
+        ctx->token_pool_min_pages = (uint32_t)value;
     else if (strcmp(name, "span_schedule") == 0 && value >= 0 && value <= 2)
         ctx->span_schedule = (int)value;
     else if (strcmp(name, "lane_coresident") == 0 && value >= 0 && value <= 1)
@@ -729,6 +740,44 @@ int snapmi_ctx_prepare(snapmi_ctx *ctx, uint64_t blocks, uint32_t flags)
         ctx, blocks, (flags & SNAPMI_PREPARE_TOP_OF_MEMORY) != 0);
 }
 
+int snapmi_ctx_get_info(snapmi_ctx *ctx, const char *name, int64_t *value)
+{
+    if (!ctx || !name || !value)
+        return SNAPMI_E_ARGUMENT;
+    if (strcmp(name, "scratch_bytes") == 0) {
+        uint64_t sum = ctx->lane_tables.cap;
+        for (const DevBuf *b :
+             {&ctx->blk_first, &ctx->slot_first, &ctx->blk_size,
+              &ctx->blk_off, &ctx->slots, &ctx->plan_part, &ctx->st_in,
+              &ctx->st_out, &ctx->st_desc, &ctx->st_prof, &ctx->ticket,
+              &ctx->order, &ctx->fr_tables, &ctx->fr_desc, &ctx->fr_meta,
+              &ctx->fr_scan, &ctx->fr_slots, &ctx->fr_chunk_off,
+              &ctx->tokens, &ctx->tok_pages, &ctx->tok_stage, &ctx->ntok,
+              &ctx->sched,
+              &ctx->lane_epochs, &ctx->sd_tables, &ctx->sd_desc,
+              &ctx->bl_modes, &ctx->bl_list, &ctx->bl_descs, &ctx->bl_order})
+            sum += b->cap;
+        *value = (int64_t)sum;
+    } else if (strcmp(name, "token_scratch_bytes") == 0) {
+        *value = (int64_t)(ctx->tokens.cap + ctx->tok_pages.cap +
+                           ctx->tok_stage.cap + ctx->ntok.cap);
+    } else if (strcmp(name, "token_pool_pages") == 0) {
+        *value = ctx->tok_pool_pages_last;
+    } else if (strcmp(name, "token_pool_pct_now") == 0) {
+        *value = ctx->token_pool_now;
+    } else if (strcmp(name, "token_pages_asked") == 0 ||
+               strcmp(name, "token_blocks_spilled") == 0) {
+        // of the last token-path launch: wait for it
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        const volatile uint32_t *t = ctx->h_tokstat;
+        *value = !t ? 0 : name[6] == 'p' ? t[0] : t[1];
+    } else {
+        ctx->last_error = std::string("unknown info: ") + name;
+        return SNAPMI_E_ARGUMENT;
+    }
+    return SNAPMI_OK;
+}
 
 } // extern "C"
 
@@ -1197,8 +1246,11 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     a.host_blocks = (uint32_t)blocks;
     a.host_slots = (uint32_t)slots;
     a.ticket = (uint32_t *)ctx->ticket.p;
-    a.tokens = nullptr;
-    a.tok_exc = nullptr;
+    a.tok_pool = nullptr;
+    a.tok_pages = nullptr;
+    a.tok_ctl = nullptr;
+    a.tok_pool_pages = 0;
+    a.tok_stage = nullptr;
     a.sched = nullptr;
     a.ntok = nullptr;
     a.lane_tables = nullptr;
@@ -1208,7 +1260,6 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     a.lane_per_chunk = 0;
     a.n_lanes = 0;
     a.tok_base = 0;
-    a.tok_stride = kMaxTokens;
     a.small_limit = (uint32_t)small_stream_limit(ctx);
     a.cls_lo = 0;
     a.cls_hi = kMaxBlock;
@@ -1235,8 +1286,7 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     // (k_match_spans): every block at its final position, no slots, no
     // k_compact, the encoder a wide kernel of its own.  What the small-block
     // kernel runs on, and - option window_tokens - a mid-size batch (more
-    // than two blocks per CU, fewer than lane_min_blocks); costs 72 KiB of
-    // tokens per block of the batch.
+    // than two blocks per CU, fewer than lane_min_blocks).
     const bool win_tok =
         blocks > 0 && ctx->lds_order_ok && ctx->compress_mode == 1 && !big &&
         (use_small ||
@@ -1291,27 +1341,81 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     }
     // both match finders on every CU (k_match_both): launches that fill the
     // chip with lanes anyway
-    // tokens per block: 16 416 of 4 bytes and an exception list of a sixteenth
-    // of that in 8-byte tokens (72 KiB together) - or 2 112 when every block
-    // of the batch is of at most 8 KiB: a batch of 4 KiB pages used to reserve
-    // 32 times its input
-    const uint32_t tok_stride =
-        use_small && nb_big == 0 ? kMaxTokensSmall : kMaxTokens;
-    a.tok_stride = tok_stride;
     const bool both_cores = lanes_mode && !waves_mode && !span_match &&
                             ctx->lds_order_ok && ctx->lane_coresident &&
                             nb_big >= ctx->lane_coresident_min_blocks;
+    // The token pool (CompressArgs::tok_pool): pages of 2 KiB for the tokens
+    // of a launch's blocks, token_pool_pct per cent of what the worst case of
+    // every block would take (37 pages; 6 where every block of the batch is
+    // of at most 8 KiB) - never fewer than the worst case of 862 blocks (64
+    // MiB: a small batch does not spill) - and grown by half for the batch
+    // behind one of which more than a hundredth spilled (k_redo_spilled
+    // posts the counts; read without waiting, like the ratio above).
+    if (ctx->h_tokstat) {
+        const volatile uint32_t *t = ctx->h_tokstat;
+        const uint32_t seq = t[3];
+        if (seq != ctx->tokstat_seen) {
+            ctx->tokstat_seen = seq;
+            const uint32_t asked = t[0], spilled = t[1], of = t[2];
+            if (t[3] == seq && of) {
+                ctx->tok_pages_asked = asked;
+                ctx->tok_blocks_spilled = spilled;
+                if ((uint64_t)spilled * 100 > of && ctx->token_pool_now < 100)
+                    ctx->token_pool_now =
+                        ctx->token_pool_now * 3 / 2 + 1 > 100
+                            ? 100
+                            : ctx->token_pool_now * 3 / 2 + 1;
+            }
+        }
+    }
+    if (ctx->token_pool_now < ctx->token_pool_pct)
+        ctx->token_pool_now = ctx->token_pool_pct;
+    const uint64_t worst_pages =
+        seg_blocks * (use_small && nb_big == 0
+                          ? kPagesPerSmallBlock
+                          : kTokPagesPerBlock + kExcPagesPerBlock);
+    // (a page in hand per lane of the launch and a run of 32 per lane
+    // wavefront, tok_page_ask: part of the worst case, so that 100 per cent
+    // still means "never")
+    const uint32_t pool_lanes =
+        lanes_mode && !span_match ? lane_count(ctx, seg_blocks, both_cores)
+                                  : 0;
+    const uint64_t in_hand = pool_lanes + pool_lanes / 2;
+    uint64_t pool_pages = (worst_pages * ctx->token_pool_now + 99) / 100;
+    if (pool_pages < ctx->token_pool_min_pages)
+        pool_pages = ctx->token_pool_min_pages;
+    if (pool_pages > worst_pages + in_hand)
+        pool_pages = worst_pages + in_hand;
+    if (ctx->token_pool_now >= 100)
+        pool_pages = worst_pages + in_hand;
+    // (+ the dump page of the lanes)
+    const size_t pool_bytes = (size_t)(pool_pages + 1) * kTokPage * 4;
+    // the window wavefronts' staging arrays (TokenWriter): one per wavefront
+    // of the largest workgroup this call launches
+    const size_t stage_bytes =
+        (size_t)ctx->num_cus *
+        (use_small ? kSmallTableWaves
+                   : both_cores ? kBothWaves
+                                : span_match ? kCompressWaves : 0) *
+        kTokStageWords * 4;
+    // ... and behind its control words and the list of the spilled blocks,
+    // the blocks' page tables
+    const size_t tab_off =
+        ((size_t)(kTokCtlList + seg_blocks) * 4 + 255) & ~(size_t)255;
+    const size_t tab_bytes =
+        tab_off + (size_t)seg_blocks * kPageTabStride * 4;
     if (lanes_mode && span_match) {
-        if ((rc = reserve(ctx, ctx->tokens, (size_t)seg_blocks * tok_stride * 9 / 2 +
-                                                4096)) ||
+        if ((rc = reserve(ctx, ctx->tokens, pool_bytes, /*slack=*/false)) ||
+            (rc = reserve(ctx, ctx->tok_pages, tab_bytes)) ||
+            (rc = reserve(ctx, ctx->tok_stage, stage_bytes + 256)) ||
             (rc = reserve(ctx, ctx->ntok, (size_t)blocks * sizeof(uint32_t))))
             return rc;
-        a.tokens = (unsigned long long *)ctx->tokens.p;
-        // (the exception lists behind the token arrays, 8-byte aligned)
-        a.tok_exc = (unsigned long long *)((uint8_t *)ctx->tokens.p +
-                                           (((size_t)seg_blocks * tok_stride * 4 +
-                                             255) &
-                                            ~(size_t)255));
+        a.tok_pool = (uint32_t *)ctx->tokens.p;
+        a.tok_ctl = (uint32_t *)ctx->tok_pages.p;
+        a.tok_pages = (uint32_t *)((uint8_t *)ctx->tok_pages.p + tab_off);
+        a.tok_pool_pages = (uint32_t)pool_pages;
+        a.tok_stage = (uint32_t *)ctx->tok_stage.p;
+        ctx->tok_pool_pages_last = (uint32_t)pool_pages;
         a.ntok = (uint32_t *)ctx->ntok.p;
     } else if (lanes_mode) {
         const uint32_t lanes = lane_count(ctx, seg_blocks, both_cores);
@@ -1320,8 +1424,9 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                 return rc;
             ctx->lane_tables_top = false;
         }
-        if ((rc = reserve(ctx, ctx->tokens, (size_t)seg_blocks * tok_stride * 9 / 2 +
-                                                4096)) ||
+        if ((rc = reserve(ctx, ctx->tokens, pool_bytes, /*slack=*/false)) ||
+            (rc = reserve(ctx, ctx->tok_pages, tab_bytes)) ||
+            (rc = reserve(ctx, ctx->tok_stage, stage_bytes + 256)) ||
             (rc = reserve(ctx, ctx->ntok, (size_t)blocks * sizeof(uint32_t))))
             return rc;
         if (ctx->lane_epoch_preset >= 0) { // test knob, see snapmi_ctx.hpp
@@ -1330,12 +1435,12 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                                            ctx->n_lanes, ctx->stream));
             ctx->lane_epoch_preset = -1;
         }
-        a.tokens = (unsigned long long *)ctx->tokens.p;
-        // (the exception lists behind the token arrays, 8-byte aligned)
-        a.tok_exc = (unsigned long long *)((uint8_t *)ctx->tokens.p +
-                                           (((size_t)seg_blocks * tok_stride * 4 +
-                                             255) &
-                                            ~(size_t)255));
+        a.tok_pool = (uint32_t *)ctx->tokens.p;
+        a.tok_ctl = (uint32_t *)ctx->tok_pages.p;
+        a.tok_pages = (uint32_t *)((uint8_t *)ctx->tok_pages.p + tab_off);
+        a.tok_pool_pages = (uint32_t)pool_pages;
+        a.tok_stage = (uint32_t *)ctx->tok_stage.p;
+        ctx->tok_pool_pages_last = (uint32_t)pool_pages;
         a.ntok = (uint32_t *)ctx->ntok.p;
         a.lane_tables = (unsigned long long *)ctx->lane_tables.p;
         a.lane_epochs = (uint32_t *)ctx->lane_epochs.p;
@@ -1480,6 +1585,10 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                 a.tok_base = (uint32_t)lo;
                 a.blk_lo = (uint32_t)lo;
                 a.blk_hi = (uint32_t)mid;
+                // the pool is the segment's: no page handed out, no block
+                // spilled, k_redo_spilled's ticket at 0
+                HIP_TRY(ctx, hipMemsetAsync(ctx->tok_pages.p, 0,
+                                            kTokCtlList * 4, s));
                 if (!waves_mode) // (shared with the wavefront kernel if on)
                     HIP_TRY(ctx, hipMemsetAsync(ctx->ticket.p, 0, 64, s));
                 // A launch of few blocks waits for the latency of its
@@ -1568,6 +1677,29 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                                    0, s, a);
                 if (mid < hi) // the side stream's half is done as well
                     HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+                {
+                    // the blocks whose tokens found no page: once more, by
+                    // the window kernel, to where the encoder would have put
+                    // them (CompressArgs::tok_pool)
+                    if (!ctx->h_tokstat) {
+                        HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_tokstat,
+                                                   64, hipHostMallocDefault));
+                        memset((void *)ctx->h_tokstat, 0, 64);
+                    }
+                    CompressArgs r = a;
+                    r.blk_lo = (uint32_t)lo;
+                    r.blk_hi = (uint32_t)hi;
+                    r.cls_lo = 0;
+                    r.cls_hi = kMaxBlock;
+                    const uint64_t want =
+                        (hi - lo + kCompressWaves - 1) / kCompressWaves;
+                    hipLaunchKernelGGL(
+                        k_redo_spilled,
+                        dim3((uint32_t)(want < (uint64_t)ctx->num_cus
+                                            ? want : ctx->num_cus)),
+                        dim3(kCompressWaves * 64), 0, s, r,
+                        (uint32_t *)ctx->h_tokstat, ++ctx->tokstat_seq);
+                }
             }
             a.blk_lo = 0;
             a.tok_base = 0;

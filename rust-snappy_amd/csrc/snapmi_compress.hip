@@ -981,11 +981,122 @@ namespace {
 // lanes that found them, at their rank among the step's copies - no push into
 // a token register (two ds_permute and their round trip per step), no flush:
 // one predicated 8-byte store and a per-lane sum of sizes.
+// How the match finders come by the pages of the token pool
+// (CompressArgs::tok_pool).  Both are bound by the latency of their own
+// dependent chains, and an atomic on the pool's one counter whose result is
+// waited for where a page starts is one more link - for a whole wavefront,
+// every 512 tokens of any of its lanes (the first form of this: + 6 % on
+// k_match_both at cfg2).
+//  - a window wavefront stages a block's tokens and moves them into pages at
+//    the block's end (tok_commit_wave);
+//  - a LANE has a page in hand; the lanes of a wavefront that have used
+//    theirs get new ones where the round loop is convergent (its top), from a
+//    run of kTokRun pages that the wavefront takes with one atomic, waited
+//    for, every 32 pages (match_blocks).
+// A lane's page in hand passes from block to block; a launch leaves a page or
+// two per lane unused.
+constexpr uint32_t kTokRun = 32, kNoPage = 0xFFFFFFFFu;
+__device__ __forceinline__ uint32_t tok_page_ask(const CompressArgs &a)
+{
+    return atomicAdd(&a.tok_ctl[0], 1u);
+}
+// a lane's page in hand `spare` becomes slot `slot` of block b's page table
+// - or, the pool having run out, the block is put on the spill list and gets
+// the dump page.  `spilled`: it is on the list already.
+__device__ __forceinline__ uint32_t tok_page_take(const CompressArgs &a,
+                                                  uint32_t b, uint32_t slot,
+                                                  uint32_t &spare,
+                                                  bool &spilled)
+{
+    if (!spilled) {
+        uint32_t p = spare;
+        spare = kNoPage;
+        // (the second page of one round - a token page and an exception
+        // page, rare: asked for and waited for here)
+        if (p == kNoPage)
+            p = tok_page_ask(a);
+        if (p < a.tok_pool_pages) {
+            a.tok_pages[(uint64_t)(b - a.tok_base) * kPageTabStride + slot] =
+                p;
+            return p;
+        }
+        spilled = true;
+        a.tok_ctl[kTokCtlList + atomicAdd(&a.tok_ctl[1], 1u)] = b;
+    }
+    return a.tok_pool_pages;
+}
+
+// ... for a window wavefront, whose step is bound by the instructions it
+// issues and has no scalar register to spare (a comparison per step and a
+// rarely taken branch for "this step opens a page" cost k_match_spans 11 %,
+// in seven forms): the wavefront writes a block's tokens into a STAGING array
+// of its own, as it did when every block had one, and at the block's end
+// tok_commit_wave moves them into pages - as many as they need, consecutive,
+// taken with one atomic.  Out of line, its arguments the fields it needs (a
+// reference to the kernel's argument block would make the kernel keep a copy
+// of it in scratch memory).  Returns what goes into CompressArgs::ntok.
+__device__ __noinline__ uint32_t tok_commit_wave(
+    const uint32_t *stage, uint32_t ntok, uint32_t nexc, uint32_t *ctl,
+    uint32_t *tab, uint32_t *pool, uint32_t pool_pages, uint32_t b,
+    uint32_t lane)
+{
+    typedef __attribute__((address_space(1))) unsigned long long g_u64;
+    const uint32_t tp = (ntok + kTokPage - 1) / kTokPage,
+                   ep = (nexc + kExcPage - 1) / kExcPage;
+    uint32_t base = 0;
+    if (lane == 0) {
+        base = atomicAdd(&ctl[0], tp + ep);
+        if (base + tp + ep > pool_pages) {
+            ctl[kTokCtlList + atomicAdd(&ctl[1], 1u)] = b;
+            base = kNoPage;
+        }
+    }
+    base = uni(base);
+    if (base == kNoPage)
+        return kTokSpilled;
+    if (lane < tp)
+        tab[lane] = base + lane;
+    if (lane < ep)
+        tab[kTokPagesPerBlock + lane] = base + tp + lane;
+    // (the wavefront's own stores of this block, read back: loads that see
+    // the L2, where the atomic above has waited for them to arrive)
+    const g_u64 *from = (const g_u64 *)stage;
+    g_u64 *to = (g_u64 *)(pool + (uint64_t)base * kTokPage);
+    const uint32_t words = (ntok + 1) / 2;
+    for (uint32_t i = lane; i < words; i += 4 * kWave) {
+        unsigned long long v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+        v0 = __hip_atomic_load(from + i, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        if (i + kWave < words)
+            v1 = __hip_atomic_load(from + i + kWave, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        if (i + 2 * kWave < words)
+            v2 = __hip_atomic_load(from + i + 2 * kWave, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        if (i + 3 * kWave < words)
+            v3 = __hip_atomic_load(from + i + 3 * kWave, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        to[i] = v0;
+        if (i + kWave < words)
+            to[i + kWave] = v1;
+        if (i + 2 * kWave < words)
+            to[i + 2 * kWave] = v2;
+        if (i + 3 * kWave < words)
+            to[i + 3 * kWave] = v3;
+    }
+    const g_u64 *efrom = (const g_u64 *)(stage + kMaxTokens);
+    g_u64 *eto = (g_u64 *)(pool + (uint64_t)(base + tp) * kTokPage);
+    for (uint32_t i = lane; i < nexc; i += kWave)
+        eto[i] = __hip_atomic_load(efrom + i, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+    return ntok;
+}
+
 struct TokenWriter {
     typedef __attribute__((address_space(1))) uint32_t g_u32;
     typedef __attribute__((address_space(1))) unsigned long long g_u64;
-    g_u32 *tok;    // this block's token array
-    g_u64 *exc;    // ... and its exception list
+    g_u32 *tok;    // the wavefront's staging array: this block's tokens
+    g_u64 *exc;    // ... and its exception list (tok_commit_wave)
     uint32_t ntok; // tokens stored so far (uniform)
     uint32_t nexc; // exceptions stored so far (uniform)
     uint32_t dsum; // encoded bytes of the tokens THIS LANE stored
@@ -993,17 +1104,29 @@ struct TokenWriter {
     uint32_t t;    // always 0 (TokenSink's interface: nothing is pending)
     uint32_t lane;
 
-    __device__ __forceinline__ void init(g_u32 *tokens, g_u64 *exceptions,
-                                         uint32_t l)
+    __device__ __forceinline__ void init(const CompressArgs &a, uint32_t l)
     {
-        tok = tokens;
-        exc = exceptions;
+        tok = (g_u32 *)a.tok_stage +
+              (uint64_t)uni(blockIdx.x * (blockDim.x >> 6) +
+                            (threadIdx.x >> 6)) *
+                  kTokStageWords;
+        exc = (g_u64 *)(tok + kMaxTokens);
         ntok = 0;
         nexc = 0;
         dsum = 0;
         d = 0;
         t = 0;
         lane = l;
+    }
+    // the block's end: its tokens into pages; what goes into
+    // CompressArgs::ntok
+    __device__ __forceinline__ uint32_t commit(const CompressArgs &a,
+                                               uint32_t b) const
+    {
+        return tok_commit_wave(
+            (const uint32_t *)tok, ntok, nexc, a.tok_ctl,
+            a.tok_pages + (uint64_t)(b - a.tok_base) * kPageTabStride,
+            a.tok_pool, a.tok_pool_pages, b, lane);
     }
     // one token, the same in every lane
     __device__ __forceinline__ void record_nf(uint32_t lit_start,
@@ -1158,11 +1281,7 @@ __device__ __forceinline__ void compress_one_block_span(
     if constexpr (kTok) {
         // match finder only: tokens for k_encode_tokens (which also writes
         // the varint of block 0)
-        out.init((TokenWriter::g_u32 *)a.tokens +
-                     (uint64_t)(b - a.tok_base) * a.tok_stride,
-                 (TokenWriter::g_u64 *)a.tok_exc +
-                     (uint64_t)(b - a.tok_base) * (a.tok_stride / 16),
-                 lane);
+        out.init(a, lane);
     } else {
         gptr dst;
         if (k == 0) {
@@ -1177,6 +1296,15 @@ __device__ __forceinline__ void compress_one_block_span(
                 dst[i] = (uint8_t)v;
             }
             dst += varint_len(total);
+        } else if (a.direct) {
+            // (k_redo_spilled behind a lane-kernel batch: the sizes of the
+            // blocks in front are known, as in k_encode_tokens)
+            const uint32_t first = a.blk_first[st_i];
+            const uint64_t nb = (total + kMaxBlock - 1) / kMaxBlock;
+            if (first + nb > a.host_blocks)
+                return; // rejected by k_plan_compress (E_ARGUMENT)
+            dst = (gptr)a.out_ptrs[st_i] + varint_len(total) +
+                  (a.blk_off[b] - a.blk_off[first]);
         } else {
             const uint32_t slot = a.slot_first[st_i] + k - 1;
             if (slot >= a.host_slots)
@@ -1191,10 +1319,13 @@ __device__ __forceinline__ void compress_one_block_span(
             out.finish();
         else
             out.flush();
+        uint32_t count = 0;
+        if constexpr (kTok)
+            count = out.commit(a, b);
         if (lane == 0) {
             a.blk_size[b] = out.d;
             if constexpr (kTok)
-                a.ntok[b] = out.ntok;
+                a.ntok[b] = count;
         }
         return;
     }
@@ -1473,10 +1604,13 @@ __device__ __forceinline__ void compress_one_block_span(
         if (out.t)
             out.flush();
     }
+    uint32_t count = 0;
+    if constexpr (kTok)
+        count = out.commit(a, b);
     if (lane == 0) {
         a.blk_size[b] = out.d;
         if constexpr (kTok)
-            a.ntok[b] = out.ntok;
+            a.ntok[b] = count;
     }
     PROF(
     TICK(8);
@@ -1620,13 +1754,13 @@ struct SpanSched {
         return w + kSchedHead + n_streams + (which ? slots : 0);
     }
     // the stream of pass-2 entry j: slot_first[st] <= j < slot_first[st + 1]
-    __device__ __forceinline__ uint32_t stream_of_slot(const CompressArgs &a,
-                                                       uint32_t j) const
+    __device__ __forceinline__ uint32_t stream_of_slot(
+        const uint32_t *slot_first, uint32_t j) const
     {
         uint32_t lo = 0, hi = n_streams;
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
-            if (a.slot_first[mid] <= j)
+            if (slot_first[mid] <= j)
                 lo = mid;
             else
                 hi = mid;
@@ -1636,21 +1770,22 @@ struct SpanSched {
     // lane 0: the next block to run, or kSchedEmpty when the launch is over
     // (out of line, like next_ticket: an inlined ticket loop under `if (lane
     // == 0)` inside a persistent loop once compiled into a hang)
-    __device__ __forceinline__ uint32_t next(const CompressArgs &a)
+    __device__ __forceinline__ uint32_t next(const uint32_t *blk_first,
+                                             const uint32_t *slot_first)
     {
         for (;;) {
             const uint32_t t = atomicAdd(&w[0], 1u);
             if (t >= n_streams + slots)
                 break;
             if (t < n_streams) { // pass 1: the stream's first block
-                const uint32_t b = a.blk_first[t];
-                if (a.blk_first[t + 1] > b && b < nblocks)
+                const uint32_t b = blk_first[t];
+                if (blk_first[t + 1] > b && b < nblocks)
                     return b;
                 continue; // a stream without blocks
             }
             const uint32_t j = t - n_streams;
-            const uint32_t st = stream_of_slot(a, j);
-            const uint32_t b = a.blk_first[st] + (j - a.slot_first[st]) + 1;
+            const uint32_t st = stream_of_slot(slot_first, j);
+            const uint32_t b = blk_first[st] + (j - slot_first[st]) + 1;
             uint32_t cls = 0; // 0 run now, 1 middle list, 2 light list
             if (b < nblocks) {
                 const uint32_t c = __hip_atomic_load(
@@ -1724,14 +1859,17 @@ struct SpanSched {
 } // namespace
 
 // (the whole wavefront calls, lane 0 draws - the shape of next_ticket, which
-// is known to compile into what it says inside a persistent loop)
+// is known to compile into what it says inside a persistent loop; the two
+// arrays it reads, not the kernel's argument block: a reference to that makes
+// the kernel keep a copy of it in scratch memory)
 __device__ __noinline__ uint32_t span_sched_next(SpanSched sc,
-                                                 const CompressArgs &a,
+                                                 const uint32_t *blk_first,
+                                                 const uint32_t *slot_first,
                                                  uint32_t lane)
 {
     uint32_t b = 0;
     if (lane == 0)
-        b = sc.next(a);
+        b = sc.next(blk_first, slot_first);
     return uni(b);
 }
 
@@ -1756,7 +1894,8 @@ __global__ __launch_bounds__(kCompressWaves * 64) void k_compress_spans(
                        : a.host_slots;
         sc.nblocks = nblocks;
         for (;;) {
-            const uint32_t b = uni(span_sched_next(sc, a, lane));
+            const uint32_t b = uni(
+                span_sched_next(sc, a.blk_first, a.slot_first, lane));
             if (b == kSchedEmpty)
                 break;
             const unsigned long long t0 = __builtin_readcyclecounter();
@@ -1786,6 +1925,42 @@ __global__ __launch_bounds__(kCompressWaves * 64) void k_compress_spans(
             a.ntok[b] = 0xFFFFFFFFu; // encoded here, not by k_encode_tokens
         compress_one_block_span<false>(a, b, lane, table, tbase);
         b = uni(next_ticket(a.ticket, lane, nblocks));
+    }
+}
+
+// The blocks of a token-path launch whose tokens found no page in the pool
+// (CompressArgs::tok_pool), once more: the window kernel compresses them to
+// where k_encode_tokens would have put them (its destination rules, with
+// a.direct the final position - k_scan_sizes has run).  Launched behind every
+// k_encode_tokens; a launch without spilled blocks costs its wavefronts one
+// load.  h_stat (pinned host memory, may be null): what the next batch sizes
+// its pool by - pages asked for, blocks spilled, blocks of the launch, seq.
+__global__ __launch_bounds__(kCompressWaves * 64) void k_redo_spilled(
+    CompressArgs a, uint32_t *h_stat, uint32_t seq)
+{
+    __shared__ __attribute__((aligned(16)))
+    uint16_t tables[kCompressWaves][kMaxTable];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    const lptr16 table = (lptr16)&tables[wave][0];
+    const uint32_t tbase = (uint32_t)(uintptr_t)table;
+    uint32_t count = a.tok_ctl[1];
+    if (count > a.blk_hi - a.blk_lo)
+        count = a.blk_hi - a.blk_lo;
+    if (h_stat && blockIdx.x == 0 && threadIdx.x == 0) {
+        h_stat[0] = a.tok_ctl[0];
+        h_stat[1] = count;
+        h_stat[2] = a.blk_hi - a.blk_lo;
+        __threadfence_system();
+        h_stat[3] = seq;
+    }
+    if (count == 0)
+        return;
+    uint32_t i = uni(next_ticket(a.tok_ctl + 2, lane, count));
+    while (i != 0xFFFFFFFFu) {
+        const uint32_t b = uni(a.tok_ctl[kTokCtlList + i]);
+        compress_one_block_span<false>(a, b, lane, table, tbase);
+        i = uni(next_ticket(a.tok_ctl + 2, lane, count));
     }
 }
 
@@ -2234,11 +2409,55 @@ __device__ __forceinline__ void match_blocks(
     uint32_t mis = 0, hi = 0;
     gcptr src = nullptr, src_al = nullptr;
     typedef __attribute__((address_space(1))) uint32_t g_tok;
-    g_tok *tok = nullptr;
-    g_u64 *exc = nullptr; // the block's exception list (snapmi_kernels.hpp)
+    // the pages the block's tokens and exceptions are going to (the dump
+    // page once the pool has run out: CompressArgs::tok_pool)
+    uint32_t tpage = a.tok_pool_pages, epage = a.tok_pool_pages;
+    bool spilled = false;
     uint32_t nexc = 0;
+    // the lane's page in hand, and what is left of the wavefront's run
+    // (uniform): see tok_page_ask
+    uint32_t spare = kNoPage, run_next = 0, run_end = 0;
+    // where token idx goes; the first token of a page takes the page
+    auto tok_at = [&](uint32_t idx) -> g_tok * {
+        if (idx % kTokPage == 0)
+            tpage = tok_page_take(a, b, idx / kTokPage, spare, spilled);
+        return (g_tok *)a.tok_pool + (uint64_t)tpage * kTokPage +
+               idx % kTokPage;
+    };
+    auto exc_put = [&](unsigned long long v) {
+        if (nexc % kExcPage == 0)
+            epage = tok_page_take(a, b, kTokPagesPerBlock + nexc / kExcPage,
+                                  spare, spilled);
+        if (!spilled)
+            ((g_u64 *)((g_tok *)a.tok_pool + (uint64_t)epage * kTokPage))
+                [nexc % kExcPage] = v;
+        nexc++;
+    };
 
     for (;;) {
+        // token pages for the lanes that used theirs in the last round (the
+        // loop's top is convergent: the run's bounds stay uniform)
+        {
+            const uint64_t M_pg = __ballot(spare == kNoPage);
+            if (M_pg) {
+                const uint32_t cnt = (uint32_t)__builtin_popcountll(M_pg);
+                if (run_end - run_next < cnt) {
+                    const uint32_t leader = (uint32_t)__builtin_ctzll(M_pg);
+                    const uint32_t take = cnt > kTokRun ? cnt : kTokRun;
+                    uint32_t base = 0;
+                    if (lane == leader)
+                        base = atomicAdd(&a.tok_ctl[0], take);
+                    run_next = rdlane(base, leader);
+                    run_end = run_next + take;
+                }
+                if (spare == kNoPage)
+                    spare = run_next + __builtin_amdgcn_mbcnt_hi(
+                                           (uint32_t)(M_pg >> 32),
+                                           __builtin_amdgcn_mbcnt_lo(
+                                               (uint32_t)M_pg, 0));
+                run_next += cnt;
+            }
+        }
         // Tickets are taken for the whole wavefront at once: the lanes that
         // need a block count themselves (ballot) and ONE of them adds the
         // count to the device-wide counter.  (One atomic per lane on one
@@ -2288,10 +2507,7 @@ __device__ __forceinline__ void match_blocks(
                 src = (gcptr)a.in_ptrs[lo] + boff;
                 n = total - boff < kMaxBlock ? (uint32_t)(total - boff)
                                              : kMaxBlock;
-                tok = (g_tok *)a.tokens +
-                      (uint64_t)(b - a.tok_base) * a.tok_stride;
-                exc = (g_u64 *)a.tok_exc +
-                      (uint64_t)(b - a.tok_base) * (a.tok_stride / 16);
+                spilled = false;
                 ntok = 0;
                 nexc = 0;
                 csize = 0;
@@ -2300,8 +2516,10 @@ __device__ __forceinline__ void match_blocks(
                 if (n <= a.cls_lo || n > a.cls_hi) {
                     have = false; // another launch's block
                 } else if (n < kMinNonLiteral) { // src/compress.rs:140-146
-                    tok[0] = tok_pack(n, 0, 0);
-                    a.ntok[b] = 1;
+                    g_tok *const at = tok_at(0);
+                    if (!spilled)
+                        *at = tok_pack(n, 0, 0);
+                    a.ntok[b] = spilled ? kTokSpilled : 1u;
                     a.blk_size[b] = token_bytes(n, 0, 0);
                     have = false;
                 } else {
@@ -2560,7 +2778,7 @@ __device__ __forceinline__ void match_blocks(
                 if (tl > 60 || tc > 64) {
                     csize += token_bytes(tl, tc, to);
                     if (!tok_fits(tl, tc)) // rare: its numbers in full
-                        exc[nexc++] = tok_pack64(tl, tc, to);
+                        exc_put(tok_pack64(tl, tc, to));
                 } else {
                     csize += tl + 3 + (tl != 0) - (tc <= 11 && to <= 2047);
                 }
@@ -2584,22 +2802,35 @@ __device__ __forceinline__ void match_blocks(
         if (finished)
             flush = flush || (ntok & 31) != 0;
         if (flush) { // the token group that holds token ntok-1
-            g_u32x4 *to = (g_u32x4 *)(tok + ((ntok - 1) & ~31u));
+            g_u32x4 *to = (g_u32x4 *)tok_at((ntok - 1) & ~31u);
             const l_u32x4 *from = (const l_u32x4 *)tbuf;
             const u32x4 t0 = from[0], t1 = from[1], t2 = from[2], t3 = from[3],
                         t4 = from[4], t5 = from[5], t6 = from[6], t7 = from[7];
-            to[0] = t0; to[1] = t1; to[2] = t2; to[3] = t3;
-            to[4] = t4; to[5] = t5; to[6] = t6; to[7] = t7;
+            // (a spilled block stores nothing: tens of thousands of lanes
+            // writing one dump page wait for one another in its L2 channel -
+            // 3.9 s for a launch of 64 000 spilled blocks)
+            if (!spilled) {
+                to[0] = t0; to[1] = t1; to[2] = t2; to[3] = t3;
+                to[4] = t4; to[5] = t5; to[6] = t6; to[7] = t7;
+            }
         }
         if (finished) { // done(): src/compress.rs:417-426
             if (next_emit < n) {
                 const uint32_t tl = n - next_emit;
-                tok[ntok++] = tok_pack(tl, 0, 0);
+                // (behind a flushed group in that group's page; the first
+                // token of a group of its own may open a page)
+                g_tok *const at =
+                    ntok % 32 ? (g_tok *)a.tok_pool +
+                                    (uint64_t)tpage * kTokPage + ntok % kTokPage
+                              : tok_at(ntok);
+                if (!spilled)
+                    *at = tok_pack(tl, 0, 0);
+                ntok++;
                 if (!tok_fits(tl, 0))
-                    exc[nexc++] = tok_pack64(tl, 0, 0);
+                    exc_put(tok_pack64(tl, 0, 0));
                 csize += token_bytes(tl, 0, 0);
             }
-            a.ntok[b] = ntok;
+            a.ntok[b] = spilled ? kTokSpilled : ntok;
             a.blk_size[b] = csize;
             have = false;
         }
@@ -2688,8 +2919,8 @@ __global__ __launch_bounds__(64) void k_encode_tokens(CompressArgs a)
         nblocks = a.blk_hi;
     if (b >= nblocks)
         return;
-    if (a.ntok[b] == 0xFFFFFFFFu)
-        return; // this block was encoded by k_compress_blocks
+    if (a.ntok[b] >= kTokSpilled)
+        return; // encoded by k_compress_blocks / left to k_redo_spilled
     uint32_t lo = 0, hi = a.n_streams;
     // (a batch of one-block streams - pages, frame chunks: block b IS
     // stream b, and two loads say so instead of log2(n) dependent ones)
@@ -2743,21 +2974,30 @@ __global__ __launch_bounds__(64) void k_encode_tokens(CompressArgs a)
     out.init(src, n, dst, lane);
     typedef __attribute__((address_space(1))) uint32_t g_tok;
     typedef __attribute__((address_space(1))) unsigned long long g_u64;
-    const g_tok *tok =
-        (const g_tok *)a.tokens + (uint64_t)(b - a.tok_base) * a.tok_stride;
-    const g_u64 *exc = (const g_u64 *)a.tok_exc +
-                       (uint64_t)(b - a.tok_base) * (a.tok_stride / 16);
+    // the block's page table (CompressArgs::tok_pool): a pass of 64 tokens
+    // lies in one page
+    // (lane i holds entry i: no load stands between a pass and its tokens)
+    const uint32_t ptab =
+        lane < kPageTabStride
+            ? a.tok_pages[(uint64_t)(b - a.tok_base) * kPageTabStride + lane]
+            : 0;
+    const g_tok *const pool = (const g_tok *)a.tok_pool;
     const uint32_t count = a.ntok[b];
     uint32_t pos_base = 0, exc_base = 0;
     // (the next pass's tokens are loaded before this pass is encoded: one
     // memory latency less on the chain of every pass)
-    uint32_t tnext = lane < count ? tok[lane] : 0;
+    uint32_t tnext =
+        lane < count ? pool[(uint64_t)rdlane(ptab, 0) * kTokPage + lane] : 0;
     for (uint32_t t0 = 0; t0 < count; t0 += kWave) {
         const uint32_t m = count - t0 < kWave ? count - t0 : kWave;
         uint32_t L = 0, C = 0, O = 0;
         const uint32_t t = tnext;
-        if (t0 + kWave + lane < count)
-            tnext = tok[t0 + kWave + lane];
+        if (t0 + kWave < count) {
+            const uint32_t pg = rdlane(ptab, (t0 + kWave) / kTokPage);
+            if (t0 + kWave + lane < count)
+                tnext = pool[(uint64_t)pg * kTokPage +
+                             (t0 + kWave) % kTokPage + lane];
+        }
         const uint32_t field = (t >> 10) & 63u;
         if (lane < m) {
             L = t & 1023u;
@@ -2770,12 +3010,21 @@ __global__ __launch_bounds__(64) void k_encode_tokens(CompressArgs a)
         const bool ex = lane < m && field == kTokException;
         const uint64_t E = __builtin_amdgcn_ballot_w64(ex);
         if (E) {
+            // (every lane takes part in the exchange: its page table entry
+            // may be the one an exception's lane needs)
+            const uint32_t ei =
+                exc_base + __builtin_amdgcn_mbcnt_hi(
+                               (uint32_t)(E >> 32),
+                               __builtin_amdgcn_mbcnt_lo((uint32_t)E, 0));
+            const uint32_t eslot = ei / kExcPage < kExcPagesPerBlock
+                                       ? ei / kExcPage
+                                       : kExcPagesPerBlock - 1;
+            const uint32_t epg = (uint32_t)__builtin_amdgcn_ds_bpermute(
+                (int)((kTokPagesPerBlock + eslot) << 2), (int)ptab);
             if (ex) {
                 const unsigned long long f =
-                    exc[exc_base +
-                        __builtin_amdgcn_mbcnt_hi(
-                            (uint32_t)(E >> 32),
-                            __builtin_amdgcn_mbcnt_lo((uint32_t)E, 0))];
+                    ((const g_u64 *)(pool + (uint64_t)epg * kTokPage))
+                        [ei % kExcPage];
                 L = (uint32_t)f & 0x1FFFFu;
                 C = (uint32_t)(f >> 17) & 0xFFFFu;
                 O = (uint32_t)(f >> 33) & 0xFFFFu;

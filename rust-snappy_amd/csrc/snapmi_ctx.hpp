@@ -49,7 +49,8 @@ struct snapmi_ctx {
     // grow-only device scratch of the raw codec
     snapmi::DevBuf blk_first, slot_first, blk_size, blk_off, slots, plan_part;
     // lane-per-block match finder: tokens, token counts, HBM hash tables
-    snapmi::DevBuf tokens, ntok, lane_tables, lane_epochs;
+    snapmi::DevBuf tokens, tok_pages, tok_stage, ntok, lane_tables,
+        lane_epochs;
     // lane_tables made of physical chunks (hipMemCreate) mapped into one
     // address range (place_lane_tables, snapmi_api.hip): the chunks and the
     // bytes of the range; empty / 0 when lane_tables.p came from hipMalloc
@@ -128,6 +129,18 @@ struct snapmi_ctx {
     // bytes, input bytes, its number)
     volatile uint32_t *h_ratio = nullptr;
     uint32_t ratio_seq = 0; // batches posted so far
+    // the token pool (CompressArgs::tok_pool): per cent of the worst case it
+    // is sized to (option token_pool_pct), what that has grown to behind
+    // batches that spilled, the floor in pages (64 MiB: small batches never
+    // spill; test option token_pool_min_pages), and what k_redo_spilled
+    // posted of the last launch it has finished: pages asked for | blocks
+    // spilled | blocks | seq
+    uint32_t token_pool_pct = 42, token_pool_now = 0;
+    uint32_t token_pool_min_pages = 32768;
+    volatile uint32_t *h_tokstat = nullptr;
+    uint32_t tokstat_seq = 0, tokstat_seen = 0;
+    uint32_t tok_pages_asked = 0, tok_blocks_spilled = 0;
+    uint32_t tok_pool_pages_last = 0; // pages of the last launch's pool
     // 1 (default): a lane-kernel launch of at most lane_speculate_max_blocks
     // blocks (and no more blocks than lanes) runs k_match_blocks_spec (a
     // probe's round also fetches the entry of the probe that follows a
@@ -255,7 +268,11 @@ inline int fail_ctx(snapmi_ctx *ctx, int kind, const char *fmt, ...)
                                     #expr, hipGetErrorString(_e));            \
     } while (0)
 
-inline int reserve(snapmi_ctx *ctx, DevBuf &b, size_t bytes)
+// (slack: an eighth more than asked for, so that batches that grow a little
+// do not reallocate every time - or none, for the token pool, whose size is a
+// stated share of the input)
+inline int reserve(snapmi_ctx *ctx, DevBuf &b, size_t bytes,
+                   bool slack = true)
 {
     if (bytes <= b.cap)
         return SNAPMI_OK;
@@ -265,7 +282,7 @@ inline int reserve(snapmi_ctx *ctx, DevBuf &b, size_t bytes)
         b.p = nullptr;
         b.cap = 0;
     }
-    size_t want = bytes + bytes / 8 + 256;
+    size_t want = bytes + (slack ? bytes / 8 : 0) + 256;
     HIP_TRY(ctx, hipMalloc(&b.p, want));
     b.cap = want;
     return SNAPMI_OK;

@@ -32,16 +32,30 @@ struct CompressArgs {
     // the order of the blocks is chosen as the launch goes (SpanSched in
     // snapmi_compress.hip); nullptr: blocks in ticket order
     uint32_t *sched;
-    // lane-per-block match finder (k_match_blocks): token stream per block,
-    // per-lane epoch-tagged hash tables in HBM
-    // [(blk_hi - blk_lo) * tok_stride] u32 tokens, then [.. * tok_stride /
-    // 16] u64 exceptions (tok_exc): see kMaxTokens below
-    unsigned long long *tokens;
-    unsigned long long *tok_exc;
-    // tokens per block of the array above: kMaxTokens, or - a batch whose
-    // blocks are all of at most 8 KiB (pages, short frame chunks) -
-    // kMaxTokensSmall: a copy is four bytes or more
-    uint32_t tok_stride;
+    // The token path (k_match_* -> k_encode_tokens): a block's tokens lie in
+    // PAGES of kTokPage tokens that its match finder takes from one pool as
+    // it goes (tok_ctl[0]), its exceptions in pages of kExcPage from the same
+    // pool; tok_pages says which: kPageTabStride entries per block of the
+    // launch, token pages first, exception pages from kTokPagesPerBlock on.
+    // The pool holds tok_pool_pages pages and one more, the DUMP: a block
+    // that asks for a page when none is left is SPILLED - it goes on
+    // (its encoded size is still counted), writes what follows to the dump,
+    // puts itself on the list behind tok_ctl and leaves kTokSpilled in ntok;
+    // k_encode_tokens skips it and k_redo_spilled compresses it once more
+    // with the window kernel, straight to where the encoder would have put
+    // it.  Results cannot depend on who spills: both kernels compute the
+    // reference's bytes (snapmi_api.hip sizes the pool; option
+    // token_pool_pct).
+    uint32_t *tok_pool;
+    uint32_t *tok_pages;
+    // [0] pages asked for, [1] blocks spilled, [2] k_redo_spilled's ticket,
+    // from kTokCtlList on: the spilled blocks
+    uint32_t *tok_ctl;
+    uint32_t tok_pool_pages;
+    // staging arrays of the window wavefronts of a token-path launch
+    // (TokenWriter): kTokStageWords u32 per wavefront - kMaxTokens tokens,
+    // then 1 026 exceptions of 8 bytes
+    uint32_t *tok_stage;
     uint32_t *ntok;             // [blocks]
     uint32_t blk_lo, blk_hi;    // blocks this lane/encode launch covers
     uint32_t tok_base;          // block whose tokens lie at tokens[0]
@@ -93,13 +107,23 @@ constexpr uint32_t kBothWaves = SNAPMI_BOTH_WAVES,
 // round 5's 8-byte form (literal | copy << 17 | offset << 33), in the block's
 // exception list, in the order of their tokens.  Such a token covers 65
 // bytes of input or more, so a block has at most 1 008 of them.
-// Token slots per block: at most 16 385 tokens (every token but the last
-// ends in a copy of >= 4 bytes), rounded up to whole 128-byte groups of 32 so
-// a lane can write its tokens a full line at a time; the exception lists (8
-// bytes x tok_stride / 16 per block) lie behind the token arrays of a launch:
-// 4.5 x tok_stride bytes per block in all, 73.9 KB (round 5: 131.2).
+// A block has at most 16 385 tokens (every token but the last ends in a copy
+// of >= 4 bytes); a lane writes its tokens a 128-byte group of 32 at a time.
+// Pages (round 6): 512 tokens or 256 exceptions = 2 KiB, taken from a pool as
+// a block needs them - the corpus round needs 5 900 tokens a block, 0.4 of
+// its input in bytes, where a slot for the worst case of every block was 1.13
+// (round 5: 2.0).
 constexpr uint32_t kMaxTokens = 16416;
-constexpr uint32_t kMaxTokensSmall = 8192 / 4 + 64; // blocks of <= 8 KiB
+constexpr uint32_t kTokPage = 512, kExcPage = 256;
+constexpr uint32_t kTokPagesPerBlock = (kMaxTokens + kTokPage - 1) / kTokPage;
+constexpr uint32_t kExcPagesPerBlock = 4; // 1 008 exceptions at most
+constexpr uint32_t kPageTabStride = 40;
+static_assert(kTokPagesPerBlock + kExcPagesPerBlock <= kPageTabStride, "");
+// ... of a block of at most 8 KiB: 2 049 tokens, 126 exceptions
+constexpr uint32_t kPagesPerSmallBlock = (8192 / 4 + 64 + kTokPage - 1) / kTokPage + 1;
+constexpr uint32_t kTokCtlList = 16;
+constexpr uint32_t kTokStageWords = kMaxTokens + 2 * (kMaxTokens / 16) + 28; // 128-byte multiple
+constexpr uint32_t kTokSpilled = 0xFFFFFFFEu; // in ntok: see tok_pool
 constexpr uint32_t kTokLiteral = 61, kTokException = 62;
 #if defined(__HIPCC__)
 __device__ __forceinline__ bool tok_fits(uint32_t lit, uint32_t copy)
@@ -170,6 +194,7 @@ __global__ void k_compress_blocks(CompressArgs a);
 __global__ void k_compress_block_lds(CompressArgs a);
 __global__ void k_compress_spans(CompressArgs a);    // window steps, 5 tables/CU
 __global__ void k_match_spans(CompressArgs a); // ... as the token path's match finder
+__global__ void k_redo_spilled(CompressArgs a, uint32_t *h_stat, uint32_t seq);
 __global__ void k_match_spans_8k(CompressArgs a); // ... blocks <= 8 KiB: 10 tables / CU
 __global__ void k_post_ratio(uint32_t *host_mapped, const uint64_t *blk_off,
                              uint32_t blocks, const uint64_t *in_lens,

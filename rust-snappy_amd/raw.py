@@ -98,6 +98,16 @@ class Context:
         if rc:
             _raise(self, rc)
 
+    def info(self, name):
+        """snapmi_ctx_get_info: "scratch_bytes", "token_scratch_bytes",
+        "token_pool_pages", "token_pool_pct_now", "token_pages_asked",
+        "token_blocks_spilled" (include/snapmi.h)."""
+        v = C.c_int64(0)
+        rc = self._L.snapmi_ctx_get_info(self._h, name.encode(), C.byref(v))
+        if rc:
+            _raise(self, rc)
+        return v.value
+
     def table_probe_log(self):
         """snapmi_table_probe_log: what the last placement of the lane tables
         probed, held, kept and took."""

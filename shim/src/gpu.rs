@@ -53,6 +53,7 @@ extern "C" {
         output_cap: usize, written: *mut usize, err: *mut SnapmiError,
     ) -> c_int;
     pub fn snapmi_ctx_prepare(ctx: *mut SnapmiCtx, blocks: u64, flags: u32) -> c_int;
+    pub fn snapmi_ctx_get_info(ctx: *mut SnapmiCtx, name: *const c_char, value: *mut i64) -> c_int;
     pub fn snapmi_host_alloc(bytes: usize) -> *mut c_void;
     pub fn snapmi_host_free(p: *mut c_void);
     pub fn snapmi_frame_scan_host(

@@ -69,6 +69,22 @@ impl Encoder {
         }
     }
 
+    /// Not in the reference: what the context holds and what its last batch
+    /// did, by name (`snapmi_ctx_get_info`: "scratch_bytes",
+    /// "token_blocks_spilled", ... - include/snapmi.h).
+    pub fn info(&mut self, name: &str) -> io::Result<i64> {
+        let c = std::ffi::CString::new(name)
+            .map_err(|e| io::Error::new(io::ErrorKind::InvalidInput, e))?;
+        let mut v = 0i64;
+        match unsafe { gpu::snapmi_ctx_get_info(self.ctx.as_ptr(), c.as_ptr(), &mut v) } {
+            0 => Ok(v),
+            k => Err(io::Error::new(
+                io::ErrorKind::Other,
+                format!("snapmi_ctx_get_info: {} ({})", k, self.ctx.last_error()),
+            )),
+        }
+    }
+
     /// Compresses `input` into `output` (which must hold
     /// `max_compress_len(input.len())` bytes); returns the bytes written.
     pub fn compress(&mut self, input: &[u8], output: &mut [u8]) -> Result<usize> {

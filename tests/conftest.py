@@ -77,10 +77,13 @@ def ctx(request, built):
                 params=["spans", "spans_lds", "waves", "waves_lds", "lanes",
                         "lanes_segmented", "lanes_overlap", "both",
                         "spans_match", "small_tables", "small_tables_lanes",
-                        "coresident", "spans_sched", "product",
+                        "coresident", "spans_sched", "lanes_spill",
+                        "lanes_overlap_spill", "spans_match_spill",
+                        "coresident_spill", "small_tables_spill", "product",
                         "product-lanes",
                         "product-spans_lds", "product-small_tables",
-                        "product-coresident"])
+                        "product-coresident", "product-lanes_spill",
+                        "product-coresident_spill"])
 def cctx(request, built):
     """A context per compressor kernel: the wavefront-per-block kernels (window
     steps and, as the cross-check, one copy per step; five tables per CU and
@@ -95,6 +98,10 @@ def cctx(request, built):
     match finder or to the lane kernel (both skip the other classes' blocks)
     - the configurations above switch those kernels off, so that they keep
     testing the kernels they name on blocks of every size.
+    "<name>_spill": configuration <name> with a token pool of a hundredth of
+    the worst case and no floor - a page or two for a batch of this suite, so
+    nearly every block finds the pool empty and is compressed a second time
+    by k_redo_spilled (and the first blocks of a batch are not).
     "product": the SHIPPED library (libsnapmi.so) with its default options -
     the routing a user gets; "product-<name>": the shipped library forced
     into configuration <name> (those that need no knob of the test build)."""
@@ -113,6 +120,10 @@ def cctx(request, built):
         c = product_context()
     else:
         c = R.raw.Context(0)
+    if request.param.endswith("_spill"):
+        request = type("P", (), {"param": request.param[:-len("_spill")]})
+        c.set_option("token_pool_pct", 1)
+        c.set_option("token_pool_min_pages", 0)
     if request.param == "spans_sched":
         # the window kernel with the order of its blocks chosen as the launch
         # goes (SpanSched), however few blocks there are

@@ -24,6 +24,10 @@ print(f"# bench.py's workload at {gib:g} GiB = {blocks} blocks, compress, a "
 for ns in segs:
     c = raw.Context(0)
     c.set_option("lane_table_budget_pct", 75)
+    import os
+    for kv in filter(None, os.environ.get("AB_OPTS", "").split(",")):
+        k, v = kv.split("=")
+        c.set_option(k, int(v))
     per = -(-blocks // ns)
     c.set_option("lane_segment_blocks", max(64, per))
     torch.cuda.synchronize()
@@ -34,7 +38,8 @@ for ns in segs:
     free1 = torch.cuda.mem_get_info(dev)[0]
     print(f"{ns} segments of {per:6d}: {te*1e3:8.2f} ms {ub/2**30/te:6.1f} "
           f"GiB/s  context {free0-free1:12d} B = {(free0-free1)/ub:.2f} x "
-          f"input  {diag.get('kernel')}  calls {diag.get('call_ms')}",
+          f"input  {diag.get('kernel')}  calls {diag.get('call_ms')}  "
+          f"probe {diag.get('placement', '')[:24]}",
           flush=True)
     c.close()
     torch.cuda.empty_cache()

@@ -234,7 +234,8 @@ def test_frame_scan_host_batches_and_stale_bytes(built):
 
 
 _RUST_SCALARS = {"c_int": "int", "i32": "int", "u32": "uint32_t",
-                 "u64": "uint64_t", "usize": "size_t", "u8": "uint8_t",
+                 "u64": "uint64_t", "i64": "int64_t", "usize": "size_t",
+                 "u8": "uint8_t",
                  "c_char": "char", "c_void": "void",
                  "SnapmiCtx": "snapmi_ctx", "SnapmiError": "snapmi_error"}
 

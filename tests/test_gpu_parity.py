@@ -968,6 +968,45 @@ def test_prepare_places_the_tables_ahead_of_the_first_batch(built):
     c.close()
 
 
+def test_token_pool_spills_are_compressed_again_and_the_pool_grows(built):
+    """The token pool (CompressArgs::tok_pool): a batch whose blocks need
+    more pages than the pool holds loses nothing - the blocks that find no
+    page are compressed a second time by k_redo_spilled, to the oracle's
+    bytes - the counts say how many did, and the context's next batches get a
+    larger pool until none does.  Shipped library, its default routing (1 GiB
+    of one-block streams: the lane kernel beside the window kernel)."""
+    from conftest import product_context
+    from rust_snappy_amd import batch
+    ins, src = _budget_batch()
+    n = len(ins)
+    c = product_context()
+    c.set_option("lane_min_blocks", 1)
+    c.set_option("token_pool_min_pages", 0)
+    c.set_option("token_pool_pct", 20)   # the corpus needs about 33
+    seen = []
+    for _ in range(4):
+        dst, lens, errs = batch.compress(c, src)
+        spilled = c.info("token_blocks_spilled")
+        seen.append((c.info("token_pool_pages"), spilled,
+                     c.info("token_pages_asked")))
+        for i in list(range(0, n, 397)) + [n - 1]:
+            assert errs[i][0] == 0
+            assert dst.stream_bytes(i, lens[i]) == O.compress(ins[i]), i
+    pages = [p for p, _, _ in seen]
+    assert 0 < seen[0][1] < n, seen            # some spilled, some did not
+    assert pages[1] > pages[0], seen           # ... so the pool grew
+    assert seen[-1][1] == 0, seen              # until nothing spilled
+    assert seen[-1][2] <= pages[-1], seen
+    assert c.info("token_pool_pct_now") > 20
+    assert c.info("token_scratch_bytes") <= c.info("scratch_bytes")
+    # 100 %: no block can spill, whatever the data
+    c.set_option("token_pool_pct", 100)
+    dst, lens, errs = batch.compress(c, src)
+    assert c.info("token_blocks_spilled") == 0
+    assert dst.stream_bytes(n - 1, lens[n - 1]) == O.compress(ins[n - 1])
+    c.close()
+
+
 def test_many_small_streams_plan_on_many_workgroups(cctx, ctx):
     """Batches of more than 16 384 streams are planned, scanned and sorted by
     many workgroups (k_plan_compress_a/b/c, k_scan_sizes_a/b/c,
