@@ -490,6 +490,9 @@ def budget(args, ctx, dev):
         rows[f"pct{pct}"] = {"compress_gibs": round(ub / GIB / te, 2),
                              "compress_ms": round(te * 1e3, 2),
                              "context_bytes": int(free0 - free1),
+                             "token_scratch_bytes":
+                                 c.info("token_scratch_bytes"),
+                             "input_bytes": int(ub),
                              "held_at_most_during_placement": held,
                              "first_call_ms": diag["first_call_ms"],
                              "call_ms": diag["call_ms"],
@@ -523,13 +526,16 @@ def budget(args, ctx, dev):
         "placement": diag["placement"]}
     c.close()
     torch.cuda.empty_cache()
-    # ... and the token scratch: the block list matched and encoded in equal
-    # launches of at most lane_segment_blocks blocks - what the context holds
-    # against what the second and third launch's tails cost
-    for seg in (98304, 65536):
+    # ... and the token scratch: the pool at 100 % of the worst case (no
+    # block can spill; round 5's layout in pages), and the block list matched
+    # and encoded in two equal launches (lane_segment_blocks) - what the
+    # context holds against what it costs
+    for seg in (1 << 20, 98304):
         c = raw.Context(ctx.device)
         c.set_option("lane_table_budget_pct", 75)
         c.set_option("lane_segment_blocks", seg)
+        if seg == 1 << 20:
+            c.set_option("token_pool_pct", 100)
         free0 = torch.cuda.mem_get_info(dev)[0]
         diag = {}
         ub, cb, n, te, td = round_tiles(c, dev, args.gib, max(args.steps, 3),
@@ -537,19 +543,21 @@ def budget(args, ctx, dev):
         torch.cuda.empty_cache()
         free1 = torch.cuda.mem_get_info(dev)[0]
         launches = -(-50 * rounds // seg)
-        rows[f"segments_of_at_most_{seg}_blocks"] = {
+        rows["token_pool_100_pct" if seg == 1 << 20 else
+             f"segments_of_at_most_{seg}_blocks"] = {
             "launches": launches,
             "compress_gibs": round(ub / GIB / te, 2),
             "compress_ms": round(te * 1e3, 2),
             "context_bytes": int(free0 - free1),
-            "token_scratch_bytes": -(-50 * rounds // launches) * 73872,
+            "token_scratch_bytes": c.info("token_scratch_bytes"),
+            "blocks_spilled": c.info("token_blocks_spilled"),
             "input_bytes": int(ub), "call_ms": diag["call_ms"]}
         c.close()
         torch.cuda.empty_cache()
     return {"config": f"lane_table_budget_pct 75 / 33 / 15 at {args.gib:g} "
                       "GiB of bench.py's workload, snapmi_ctx_prepare("
-                      "SNAPMI_PREPARE_TOP_OF_MEMORY), and the batch in two "
-                      "and three launches (lane_segment_blocks)",
+                      "SNAPMI_PREPARE_TOP_OF_MEMORY), token_pool_pct 100, "
+                      "and the batch in two launches (lane_segment_blocks)",
             "budgets": rows}
 
 

@@ -207,19 +207,21 @@ SNAPMI_API const char *snapmi_version(void);
  *                          23.3 GB instead of 29.1 and costs 8 % of the
  *                          compress rate, 48 900 21.2 GB (tokens 0.42x the
  *                          input) and 25 % (profiles/r6_token_segments.txt)
- *   "token_pool_pct"       42 (default): the token pool - where the match
+ *   "token_pool_pct"       39 (default): the token pool - where the match
  *                          finders of a large batch leave their tokens for
  *                          the encoder, in pages of 2 KiB taken as a block
  *                          needs them - is this share of what the worst case
- *                          of every block would take (74 KiB a block, 1.16x
- *                          the input; 42 % = 0.49x; the corpus round needs
- *                          0.44x, English text 0.71x).  A block that finds no
- *                          page is compressed a second time by the window
- *                          kernel (same bytes; costs that block twice), and
- *                          the context's next batch gets a pool half as large
- *                          again when more than 1 % of a batch did.  100: no
- *                          block ever spills.  Never under
- *   "token_pool_min_pages" 32768 (default; 64 MiB): batches of up to 885
+ *                          of every block would take (1.16x the input: a
+ *                          token of 4 bytes per 4 bytes of input, rounded to
+ *                          pages), + a page and a half per lane in flight:
+ *                          0.49x the input at cfg2 with everything, of which
+ *                          cfg2 uses 0.46x; English text needs 0.73x.  A block
+ *                          that finds no page is compressed a second time by
+ *                          the window kernel (same bytes; costs that block
+ *                          twice), and the context's next batch gets a pool
+ *                          half as large again when more than 1 % of a batch
+ *                          did.  100: no block ever spills.  Never under
+ *   "token_pool_min_pages" 32768 (default; 64 MiB): batches of up to 750
  *                          blocks never spill
  *   "lane_table_spread"    1 (default): the lane kernel's hash tables are
  *                          spread over up to 4x their size, as far as the

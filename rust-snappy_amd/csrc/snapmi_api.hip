@@ -703,7 +703,7 @@ int snapmi_compress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         h_in_lens = fetched.data();
     }
-    uint64_t blocks = 0, slots = 0, cnt8 = 0;
+    uint64_t blocks = 0, slots = 0, cnt8 = 0, block_bytes = 0;
     // streams under this length are the lane-per-stream kernels': no block
     const uint64_t small = small_stream_limit(ctx);
     uint32_t classes = 0; // which of those kernels have anything to do
@@ -721,6 +721,7 @@ int snapmi_compress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
             continue;
         const uint64_t nb = (len + kMaxBlock - 1) / kMaxBlock;
         blocks += nb;
+        block_bytes += len;
         slots += nb - 1;
         // the stream's last block: a page, a short chunk, a tail?
         const uint64_t last = len - (nb - 1) * kMaxBlock;
@@ -728,7 +729,7 @@ int snapmi_compress_batch(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     }
     return launch_compress(ctx, d_in_ptrs, d_in_lens, d_out_ptrs, d_out_caps,
                            d_out_lens, d_errs, n, blocks, slots, classes,
-                           cnt8);
+                           cnt8, block_bytes);
 }
 
 int snapmi_ctx_prepare(snapmi_ctx *ctx, uint64_t blocks, uint32_t flags)
@@ -1210,7 +1211,8 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                     const uint64_t *d_in_lens, void *const *d_out_ptrs,
                     const uint64_t *d_out_caps, uint64_t *d_out_lens,
                     snapmi_error *d_errs, size_t n, uint64_t blocks,
-                    uint64_t slots, uint32_t small_classes, uint64_t cnt8)
+                    uint64_t slots, uint32_t small_classes, uint64_t cnt8,
+                    uint64_t block_bytes)
 {
     if (blocks > 0x7FFFFFFFu)
         return fail_ctx(ctx, SNAPMI_E_ARGUMENT,
@@ -1251,6 +1253,8 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     a.tok_ctl = nullptr;
     a.tok_pool_pages = 0;
     a.tok_stage = nullptr;
+    a.tok_stage_waves = 0;
+    a.tok_stage_wave0 = 0;
     a.sched = nullptr;
     a.ntok = nullptr;
     a.lane_tables = nullptr;
@@ -1345,12 +1349,12 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                             ctx->lds_order_ok && ctx->lane_coresident &&
                             nb_big >= ctx->lane_coresident_min_blocks;
     // The token pool (CompressArgs::tok_pool): pages of 2 KiB for the tokens
-    // of a launch's blocks, token_pool_pct per cent of what the worst case of
-    // every block would take (37 pages; 6 where every block of the batch is
-    // of at most 8 KiB) - never fewer than the worst case of 862 blocks (64
-    // MiB: a small batch does not spill) - and grown by half for the batch
-    // behind one of which more than a hundredth spilled (k_redo_spilled
-    // posts the counts; read without waiting, like the ratio above).
+    // of a launch's blocks - token_pool_pct per cent of what the worst case
+    // of every block would take, and what the launch keeps in hand on top;
+    // never fewer than 32 768 pages (64 MiB: a small batch does not spill);
+    // grown by half for the batch behind one of which more than a hundredth
+    // spilled (k_redo_spilled posts the counts; read without waiting, like
+    // the ratio above).
     if (ctx->h_tokstat) {
         const volatile uint32_t *t = ctx->h_tokstat;
         const uint32_t seq = t[3];
@@ -1370,34 +1374,47 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     }
     if (ctx->token_pool_now < ctx->token_pool_pct)
         ctx->token_pool_now = ctx->token_pool_pct;
+    // The worst case in pages, from the bytes of the batch's blocks (a caller
+    // that does not say: full blocks): a block of n bytes has at most n / 4 +
+    // 1 tokens and n / 65 exceptions - n / 2 048 + n / 16 640 + 2 pages -
+    // scaled to one launch's share of the blocks.
+    const uint64_t bytes_all =
+        block_bytes ? block_bytes : blocks * (uint64_t)kMaxBlock;
+    const uint64_t bytes_seg =
+        blocks ? (uint64_t)((double)bytes_all * seg_blocks / blocks) + 1 : 0;
     const uint64_t worst_pages =
-        seg_blocks * (use_small && nb_big == 0
-                          ? kPagesPerSmallBlock
-                          : kTokPagesPerBlock + kExcPagesPerBlock);
+        bytes_seg / (kTokPage * 4) + bytes_seg / (65 * kExcPage) +
+        2 * seg_blocks;
     // (a page in hand per lane of the launch and a run of 32 per lane
-    // wavefront, tok_page_ask: part of the worst case, so that 100 per cent
-    // still means "never")
+    // wavefront, tok_page_ask: on top of the share, so that what a launch
+    // keeps in hand does not count against its blocks)
     const uint32_t pool_lanes =
         lanes_mode && !span_match ? lane_count(ctx, seg_blocks, both_cores)
                                   : 0;
     const uint64_t in_hand = pool_lanes + pool_lanes / 2;
-    uint64_t pool_pages = (worst_pages * ctx->token_pool_now + 99) / 100;
+    uint64_t pool_pages =
+        (worst_pages * ctx->token_pool_now + 99) / 100 + in_hand;
     if (pool_pages < ctx->token_pool_min_pages)
         pool_pages = ctx->token_pool_min_pages;
     if (pool_pages > worst_pages + in_hand)
         pool_pages = worst_pages + in_hand;
+    // (100 per cent means "never": the bound of every block, whatever the
+    // launches' shares of the bytes)
     if (ctx->token_pool_now >= 100)
-        pool_pages = worst_pages + in_hand;
+        pool_pages =
+            seg_blocks * (kTokPagesPerBlock + kExcPagesPerBlock) + in_hand;
     // (+ the dump page of the lanes)
     const size_t pool_bytes = (size_t)(pool_pages + 1) * kTokPage * 4;
     // the window wavefronts' staging arrays (TokenWriter): one per wavefront
     // of the largest workgroup this call launches
+    const uint32_t stage_waves =
+        use_small ? kSmallTableWaves
+                  : both_cores ? kBothWaves - kBothLaneWaves
+                               : span_match ? kCompressWaves : 0;
     const size_t stage_bytes =
-        (size_t)ctx->num_cus *
-        (use_small ? kSmallTableWaves
-                   : both_cores ? kBothWaves
-                                : span_match ? kCompressWaves : 0) *
-        kTokStageWords * 4;
+        (size_t)ctx->num_cus * stage_waves * kTokStageWords * 4;
+    a.tok_stage_waves = stage_waves;
+    a.tok_stage_wave0 = 0;
     // ... and behind its control words and the list of the spilled blocks,
     // the blocks' page tables
     const size_t tab_off =
@@ -1616,10 +1633,12 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                         dim3((uint32_t)(want < (uint64_t)ctx->num_cus
                                             ? want : ctx->num_cus)),
                         dim3(kCompressWaves * 64), 0, s, a);
-                } else if (both_cores)
+                } else if (both_cores) {
+                    a.tok_stage_wave0 = kBothLaneWaves;
                     hipLaunchKernelGGL(k_match_both, dim3(ctx->num_cus),
                                        dim3(kBothWaves * 64), 0, s, a);
-                else
+                    a.tok_stage_wave0 = 0;
+                } else
                 hipLaunchKernelGGL(spec ? k_match_blocks_spec : k_match_blocks,
                                    dim3(a.n_lanes / 64), dim3(64), 0, s, a);
                 if (use_small) {
@@ -1656,10 +1675,12 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                             dim3((uint32_t)(want < (uint64_t)ctx->num_cus
                                                 ? want : ctx->num_cus)),
                             dim3(kCompressWaves * 64), 0, s, a);
-                    } else if (both_cores)
+                    } else if (both_cores) {
+                        a.tok_stage_wave0 = kBothLaneWaves;
                         hipLaunchKernelGGL(k_match_both, dim3(ctx->num_cus),
                                            dim3(kBothWaves * 64), 0, s, a);
-                    else
+                        a.tok_stage_wave0 = 0;
+                    } else
                     hipLaunchKernelGGL(
                         spec ? k_match_blocks_spec : k_match_blocks,
                         dim3(a.n_lanes / 64), dim3(64), 0, s, a);

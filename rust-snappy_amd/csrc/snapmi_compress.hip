@@ -1107,8 +1107,8 @@ struct TokenWriter {
     __device__ __forceinline__ void init(const CompressArgs &a, uint32_t l)
     {
         tok = (g_u32 *)a.tok_stage +
-              (uint64_t)uni(blockIdx.x * (blockDim.x >> 6) +
-                            (threadIdx.x >> 6)) *
+              (uint64_t)uni(blockIdx.x * a.tok_stage_waves +
+                            (threadIdx.x >> 6) - a.tok_stage_wave0) *
                   kTokStageWords;
         exc = (g_u64 *)(tok + kMaxTokens);
         ntok = 0;

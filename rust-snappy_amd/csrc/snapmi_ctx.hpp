@@ -135,7 +135,7 @@ struct snapmi_ctx {
     // spill; test option token_pool_min_pages), and what k_redo_spilled
     // posted of the last launch it has finished: pages asked for | blocks
     // spilled | blocks | seq
-    uint32_t token_pool_pct = 42, token_pool_now = 0;
+    uint32_t token_pool_pct = 39, token_pool_now = 0;
     uint32_t token_pool_min_pages = 32768;
     volatile uint32_t *h_tokstat = nullptr;
     uint32_t tokstat_seq = 0, tokstat_seen = 0;
@@ -300,7 +300,7 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                     const uint64_t *d_out_caps, uint64_t *d_out_lens,
                     snapmi_error *d_errs, size_t n, uint64_t blocks,
                     uint64_t slots, uint32_t small_classes = 0xF,
-                    uint64_t cnt8 = 0);
+                    uint64_t cnt8 = 0, uint64_t block_bytes = 0);
 // raw decompress; d_modes optional (1 = stored chunk, plain copy)
 int launch_decompress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
                       const uint64_t *d_in_lens, void *const *d_out_ptrs,

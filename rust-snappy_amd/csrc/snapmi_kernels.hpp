@@ -56,6 +56,10 @@ struct CompressArgs {
     // (TokenWriter): kTokStageWords u32 per wavefront - kMaxTokens tokens,
     // then 1 026 exceptions of 8 bytes
     uint32_t *tok_stage;
+    // ... wavefront w of workgroup g has array g * tok_stage_waves + w -
+    // tok_stage_wave0 (k_match_both: its window wavefronts come behind the
+    // lanes')
+    uint32_t tok_stage_waves, tok_stage_wave0;
     uint32_t *ntok;             // [blocks]
     uint32_t blk_lo, blk_hi;    // blocks this lane/encode launch covers
     uint32_t tok_base;          // block whose tokens lie at tokens[0]

@@ -982,9 +982,9 @@ def test_token_pool_spills_are_compressed_again_and_the_pool_grows(built):
     c = product_context()
     c.set_option("lane_min_blocks", 1)
     c.set_option("token_pool_min_pages", 0)
-    c.set_option("token_pool_pct", 20)   # the corpus needs about 33
+    c.set_option("token_pool_pct", 10)   # the corpus needs about 35
     seen = []
-    for _ in range(4):
+    for _ in range(5):                   # 10, 16, 25, 38, 38 per cent
         dst, lens, errs = batch.compress(c, src)
         spilled = c.info("token_blocks_spilled")
         seen.append((c.info("token_pool_pages"), spilled,
@@ -997,7 +997,7 @@ def test_token_pool_spills_are_compressed_again_and_the_pool_grows(built):
     assert pages[1] > pages[0], seen           # ... so the pool grew
     assert seen[-1][1] == 0, seen              # until nothing spilled
     assert seen[-1][2] <= pages[-1], seen
-    assert c.info("token_pool_pct_now") > 20
+    assert c.info("token_pool_pct_now") > 10
     assert c.info("token_scratch_bytes") <= c.info("scratch_bytes")
     # 100 %: no block can spill, whatever the data
     c.set_option("token_pool_pct", 100)
