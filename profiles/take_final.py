@@ -67,7 +67,7 @@ for k, v in ex["sweep"]["sizes"].items():
 print("sweep wall", ex["sweep"]["wall_s"])
 for k, v in ex["budget"]["budgets"].items():
     print("budget", k, v["compress_gibs"], v["context_bytes"],
-          v["first_call_ms"], v["placement"][:50])
+          v.get("first_call_ms"), v.get("placement", "")[:50])
 c5 = ex["cfg5"]
 print("cfg5", c5["compress_ms"], c5["decompress_ms"], c5["compress_gibs"],
       c5["decompress_gibs"], c5["compress_hbm_frac"],
