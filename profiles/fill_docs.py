@@ -65,7 +65,7 @@ earlier sources: 123.1, 124.3, 125.65 (`r6_v1_*`) - the box decides ±1 %.  This
 | `value` | {g(d['ms_per_step'])} ms per step | **{g(d['value'])}** | round 5's driver box: 125.96 |
 | the first compress call of the context (allocates, places the tables) | {g(d['first_compress_call_ms'])} ms | | round 5: seconds |
 | context after a cfg2 batch (`extras.budget.context_bytes`); its token scratch (`snapmi_ctx_get_info`: pool, page tables, staging) | | {g(B['pct33']['context_bytes']/1e9)} GB; {g(B['pct33']['token_scratch_bytes']/1e9, 2)} GB = {g(B['pct33']['token_scratch_bytes']/B['pct33']['input_bytes'], 3)}× the input | round 5: 38.4 GB, 2.0×; asked: ≤ 24 GB, ≤ 0.5×. `token_pool_pct` 100 (no block can spill): {g(B['token_pool_100_pct']['context_bytes']/1e9)} GB, {g(B['token_pool_100_pct']['compress_gibs'])} GiB/s; two launches of half the blocks: {g(B['segments_of_at_most_98304_blocks']['context_bytes']/1e9)} GB, {g(B['segments_of_at_most_98304_blocks']['compress_gibs'])} GiB/s |
-| `extras.sweep` per call, 64 MiB / 256 MiB / 1 GiB / 4 GiB | compress {sizes('compress_ms', 2)} ms, decompress {sizes('decompress_ms', 2)} ms | compress {sizes('compress_gibs')}, decompress {sizes('decompress_gibs', 0)} | `sweep.wall_s` {ex['sweep']['wall_s']} s (round 5's driver record: 89 s); five fresh boxes, every size within 1.6 % of its median: `r6_sweeps_5_boxes.txt` |
+| `extras.sweep` per call, 64 MiB / 256 MiB / 1 GiB / 4 GiB | compress {sizes('compress_ms', 2)} ms, decompress {sizes('decompress_ms', 2)} ms | compress {sizes('compress_gibs')}, decompress {sizes('decompress_gibs', 0)} | `sweep.wall_s` {ex['sweep']['wall_s']} s (round 5's driver record: 89 s); five fresh boxes, every size within 5.4 % of its median (4 GiB: the tables' region, 62.7-70.6 ms; the sizes without tables within 3.2 %): `r6_sweeps_5_boxes.txt` |
 | per file at 2 GiB, compress / decompress | | html {F['0_html'][0]}/{F['0_html'][1]}, urls {F['1_urls'][0]}/{F['1_urls'][1]}, jpg {F['2_jpg'][0]}/{F['2_jpg'][1]}, jpg_200 {F['3_jpg_200'][0]}/{F['3_jpg_200'][1]}, pdf {F['4_pdf'][0]}/{F['4_pdf'][1]}, html4 {F['5_html4'][0]}/{F['5_html4'][1]}, txt1-4 {' '.join(f'{a}/{b}' for a, b in txt)}, pb {F['0_pb'][0]}/{F['0_pb'][1]}, gaviota {F['1_gaviota'][0]}/{F['1_gaviota'][1]} | |
 | streams of 200 … 4 096 bytes (`extras.tiny`) | | 200 B jpeg {g(T['compress_gibs'],0)}/{g(T['decompress_gibs'],0)}, 200 B text {g(T['text_200']['compress_gibs'],0)}/{g(T['text_200']['decompress_gibs'],0)}, 400 B {g(T['text_400']['compress_gibs'],0)}/{g(T['text_400']['decompress_gibs'],0)}, 1 000 B {g(T['text_1k']['compress_gibs'],0)}/{g(T['text_1k']['decompress_gibs'],0)}, 2 000 B {g(T['text_2k']['compress_gibs'],0)}/{g(T['text_2k']['decompress_gibs'],0)}, 4 096 B {g(T['text_4k']['compress_gibs'],0)}/{g(T['text_4k']['decompress_gibs'],0)} | |
 | one 2 GiB raw stream / a 126 MB stream as a batch of one | {g(ex['stream']['decompress_stream_ms'])} ms | {g(ex['stream']['decompress_stream_gibs'],0)} / {g(ex['stream']['batch_of_one_gibs'],0)} | |
