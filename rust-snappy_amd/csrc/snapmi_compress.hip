@@ -2441,21 +2441,33 @@ __device__ __forceinline__ void match_blocks(
             const uint64_t M_pg = __ballot(spare == kNoPage);
             if (M_pg) {
                 const uint32_t cnt = (uint32_t)__builtin_popcountll(M_pg);
-                if (run_end - run_next < cnt) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi(
+                    (uint32_t)(M_pg >> 32),
+                    __builtin_amdgcn_mbcnt_lo((uint32_t)M_pg, 0));
+                const uint32_t left = run_end - run_next;
+                if (left < cnt) {
+                    // what is left of the run goes to the first of them, a
+                    // new run serves the others (lanes that work on blocks
+                    // of one kind fill their pages in step: a remainder
+                    // dropped here was a tenth of the pages of a batch
+                    // sorted by file)
                     const uint32_t leader = (uint32_t)__builtin_ctzll(M_pg);
-                    const uint32_t take = cnt > kTokRun ? cnt : kTokRun;
+                    const uint32_t more = cnt - left;
+                    const uint32_t take = more > kTokRun ? more : kTokRun;
                     uint32_t base = 0;
                     if (lane == leader)
                         base = atomicAdd(&a.tok_ctl[0], take);
-                    run_next = rdlane(base, leader);
-                    run_end = run_next + take;
+                    base = rdlane(base, leader);
+                    if (spare == kNoPage)
+                        spare = rank < left ? run_next + rank
+                                            : base + (rank - left);
+                    run_next = base + more;
+                    run_end = base + take;
+                } else {
+                    if (spare == kNoPage)
+                        spare = run_next + rank;
+                    run_next += cnt;
                 }
-                if (spare == kNoPage)
-                    spare = run_next + __builtin_amdgcn_mbcnt_hi(
-                                           (uint32_t)(M_pg >> 32),
-                                           __builtin_amdgcn_mbcnt_lo(
-                                               (uint32_t)M_pg, 0));
-                run_next += cnt;
             }
         }
         // Tickets are taken for the whole wavefront at once: the lanes that

@@ -67,12 +67,14 @@ for label, order in list(orders.items()) + [list(orders.items())[0]]:
         raw.compress_batch(c, src.d_ptrs, src.d_lens, comp.d_ptrs, comp.d_lens,
                            clens, None, host_in_lens=src.h_lens)
         c.synchronize()
-        ms.append(round((time.perf_counter() - t0) * 1e3, 2))
+        ms.append((round((time.perf_counter() - t0) * 1e3, 2),
+                   c.info("token_blocks_spilled"),
+                   c.info("token_pages_asked"), c.info("token_pool_pages")))
     cl = clens.cpu().numpy()
     for k in (0, len(lens) - 1):
         assert comp.stream_bytes(k, int(cl[k])) == O.compress(
             files[order[k][1]]), k
-    print(f"{label:22s} calls {ms}  spilled "
-          f"{c.info('token_blocks_spilled')}  {c.last_kernel()}", flush=True)
+    print(f"{label:22s} (ms, spilled, pages asked, pool) {ms}  "
+          f"{c.last_kernel()}", flush=True)
     del src, comp, clens
     torch.cuda.empty_cache()
