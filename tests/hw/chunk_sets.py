@@ -16,7 +16,7 @@ from rust_snappy_amd import raw  # noqa: E402
 
 dev = torch.device("cuda", 0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-tries = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+tries = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 for i in range(n):
     c = raw.Context(0)
     c.set_option("lane_table_budget_pct", 75)
