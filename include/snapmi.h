@@ -220,7 +220,8 @@ SNAPMI_API const char *snapmi_version(void);
  *                          the window kernel (same bytes; costs that block
  *                          twice), and the context's next batch gets a pool
  *                          half as large again when more than 1 % of a batch
- *                          did.  100: no block ever spills.  Never under
+ *                          did (a sixth larger when it was under 10 %).
+ *                          100: no block ever spills.  Never under
  *   "token_pool_min_pages" 32768 (default; 64 MiB): batches of up to 750
  *                          blocks never spill
  *   "lane_table_spread"    1 (default): the lane kernel's hash tables are

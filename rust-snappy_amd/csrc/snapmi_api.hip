@@ -1352,9 +1352,9 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
     // of a launch's blocks - token_pool_pct per cent of what the worst case
     // of every block would take, and what the launch keeps in hand on top;
     // never fewer than 32 768 pages (64 MiB: a small batch does not spill);
-    // grown by half for the batch behind one of which more than a hundredth
-    // spilled (k_redo_spilled posts the counts; read without waiting, like
-    // the ratio above).
+    // grown for the batch behind one of which more than a hundredth spilled
+    // - by half, or by a sixth when it was less than a tenth (k_redo_spilled
+    // posts the counts; read without waiting, like the ratio above).
     if (ctx->h_tokstat) {
         const volatile uint32_t *t = ctx->h_tokstat;
         const uint32_t seq = t[3];
@@ -1364,11 +1364,15 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
             if (t[3] == seq && of) {
                 ctx->tok_pages_asked = asked;
                 ctx->tok_blocks_spilled = spilled;
-                if ((uint64_t)spilled * 100 > of && ctx->token_pool_now < 100)
-                    ctx->token_pool_now =
-                        ctx->token_pool_now * 3 / 2 + 1 > 100
-                            ? 100
-                            : ctx->token_pool_now * 3 / 2 + 1;
+                if ((uint64_t)spilled * 100 > of && ctx->token_pool_now < 100) {
+                    // (half as large again - or, when fewer than a tenth of
+                    // the blocks spilled, a sixth: the pool is nearly there)
+                    const uint32_t next =
+                        (uint64_t)spilled * 10 > of
+                            ? ctx->token_pool_now * 3 / 2 + 1
+                            : ctx->token_pool_now * 7 / 6 + 1;
+                    ctx->token_pool_now = next > 100 ? 100 : next;
+                }
             }
         }
     }

@@ -984,7 +984,7 @@ def test_token_pool_spills_are_compressed_again_and_the_pool_grows(built):
     c.set_option("token_pool_min_pages", 0)
     c.set_option("token_pool_pct", 10)   # the corpus needs about 35
     seen = []
-    for _ in range(5):                   # 10, 16, 25, 38, 38 per cent
+    for _ in range(9):                   # 10, 16, 25, 38 per cent ...
         dst, lens, errs = batch.compress(c, src)
         spilled = c.info("token_blocks_spilled")
         seen.append((c.info("token_pool_pages"), spilled,
@@ -992,10 +992,14 @@ def test_token_pool_spills_are_compressed_again_and_the_pool_grows(built):
         for i in list(range(0, n, 397)) + [n - 1]:
             assert errs[i][0] == 0
             assert dst.stream_bytes(i, lens[i]) == O.compress(ins[i]), i
+        if len(seen) > 1 and seen[-2][1] == 0:
+            break                        # two calls without a spilled block
     pages = [p for p, _, _ in seen]
     assert 0 < seen[0][1] < n, seen            # some spilled, some did not
     assert pages[1] > pages[0], seen           # ... so the pool grew
-    assert seen[-1][1] == 0, seen              # until nothing spilled
+    assert pages == sorted(pages), seen        # (it never shrinks)
+    assert seen[-1][1] == 0 and seen[-2][1] == 0, seen  # until nothing spilled
+    assert pages[-1] == pages[-2], seen        # ... and then it stays
     assert seen[-1][2] <= pages[-1], seen
     assert c.info("token_pool_pct_now") > 10
     assert c.info("token_scratch_bytes") <= c.info("scratch_bytes")
