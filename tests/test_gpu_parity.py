@@ -1003,6 +1003,9 @@ def test_token_pool_spills_are_compressed_again_and_the_pool_grows(built):
     assert seen[-1][2] <= pages[-1], seen
     assert c.info("token_pool_pct_now") > 10
     assert c.info("token_scratch_bytes") <= c.info("scratch_bytes")
+    with pytest.raises(Exception) as e:        # a name that is not in the list
+        c.info("no_such_thing")
+    assert "unknown info" in str(e.value) or "101" in str(e.value), e.value
     # 100 %: no block can spill, whatever the data
     c.set_option("token_pool_pct", 100)
     dst, lens, errs = batch.compress(c, src)
