@@ -719,9 +719,21 @@ def main():
                 assert bool((per[r, o:o + m] == d_round[o:o + m]).all()), \
                     f"after the timed steps: round trip of stream {j}"
         verified_after = True
+    context_holds = None
     if rank == 0:
         placement_log = ctx.table_probe_log()
         log(f"[bench] lane-table placement: {placement_log}")
+        # what the context holds behind the timed steps (snapmi_ctx_get_info:
+        # the library's own count, compress and decompress scratch together)
+        context_holds = {
+            "scratch_bytes": ctx.info("scratch_bytes"),
+            "token_scratch_bytes": ctx.info("token_scratch_bytes"),
+            "token_scratch_over_input": round(
+                ctx.info("token_scratch_bytes") / ubytes, 4),
+            "token_pool_pct_now": ctx.info("token_pool_pct_now"),
+            "token_blocks_spilled_last_launch":
+                ctx.info("token_blocks_spilled")}
+        log(f"[bench] the context holds: {context_holds}")
         log("[bench] compress kernel ms per step: "
             + " ".join(f"{x:.1f}/{y:.1f}" for x, y in zip(k_dom_ms, k_comp_ms))
             + " | decompress: " + " ".join(f"{x:.1f}" for x in k_dec_ms))
@@ -879,6 +891,7 @@ def main():
             "source_sha16": source_sha16(),
             "git_sha": os.environ.get("SNAPMI_GIT_SHA"),
             "placement": placement_log,
+            "context_holds": context_holds,
             "first_compress_call_ms": round(first_call_ms, 1),
             "free_gib_around_first_call": [
                 round(free_before_first / GIB, 1),

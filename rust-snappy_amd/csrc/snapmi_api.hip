@@ -24,6 +24,7 @@
 #include "snapmi.h"
 #include "snapmi_test.h"
 #include "snapmi_ctx.hpp"
+#include "snapmi_pool.hpp"
 #include "snapmi_device.hpp"
 #include "snapmi_kernels.hpp"
 
@@ -823,18 +824,16 @@ constexpr size_t kPlanOneWg = 16384;
 // call, ten times over - 72 s for a context's first 4 GiB batch,
 // profiles/r6_sweep_repro_head.txt).  That is why it is a call of its own.
 // ---------------------------------------------------------------------
-// The lane kernel runs over segments of the block list so that the token
-// scratch stays bounded: at most lane_segment_blocks blocks a launch, and the
-// launches of a batch equal in size - a short last launch has one block per
-// lane or fewer and ends when its heaviest block does, as a full one would.
+// (snapmi_pool.hpp: equal launches of at most lane_segment_blocks blocks)
 static uint64_t segment_blocks(const snapmi_ctx *ctx, uint64_t blocks)
 {
-    if (blocks <= ctx->lane_segment_blocks)
-        return blocks;
-    const uint64_t launches =
-        (blocks + ctx->lane_segment_blocks - 1) / ctx->lane_segment_blocks;
-    return (blocks + launches - 1) / launches;
+    return snapmi::segment_blocks(blocks, ctx->lane_segment_blocks);
 }
+static_assert(snapmi::kPoolTokPage == kTokPage &&
+                  snapmi::kPoolExcPage == kExcPage &&
+                  snapmi::kPoolPagesPerBlock ==
+                      kTokPagesPerBlock + kExcPagesPerBlock,
+              "snapmi_pool.hpp and snapmi_kernels.hpp disagree");
 
 static uint32_t lane_count(const snapmi_ctx *ctx, uint64_t seg_blocks,
                            bool both_cores)
@@ -1364,49 +1363,21 @@ int launch_compress(snapmi_ctx *ctx, const void *const *d_in_ptrs,
             if (t[3] == seq && of) {
                 ctx->tok_pages_asked = asked;
                 ctx->tok_blocks_spilled = spilled;
-                if ((uint64_t)spilled * 100 > of && ctx->token_pool_now < 100) {
-                    // (half as large again - or, when fewer than a tenth of
-                    // the blocks spilled, a sixth: the pool is nearly there)
-                    const uint32_t next =
-                        (uint64_t)spilled * 10 > of
-                            ? ctx->token_pool_now * 3 / 2 + 1
-                            : ctx->token_pool_now * 7 / 6 + 1;
-                    ctx->token_pool_now = next > 100 ? 100 : next;
-                }
+                ctx->token_pool_now =
+                    snapmi::pool_grow(ctx->token_pool_now, spilled, of);
             }
         }
     }
     if (ctx->token_pool_now < ctx->token_pool_pct)
         ctx->token_pool_now = ctx->token_pool_pct;
-    // The worst case in pages, from the bytes of the batch's blocks (a caller
-    // that does not say: full blocks): a block of n bytes has at most n / 4 +
-    // 1 tokens and n / 65 exceptions - n / 2 048 + n / 16 640 + 2 pages -
-    // scaled to one launch's share of the blocks.
-    const uint64_t bytes_all =
-        block_bytes ? block_bytes : blocks * (uint64_t)kMaxBlock;
-    const uint64_t bytes_seg =
-        blocks ? (uint64_t)((double)bytes_all * seg_blocks / blocks) + 1 : 0;
-    const uint64_t worst_pages =
-        bytes_seg / (kTokPage * 4) + bytes_seg / (65 * kExcPage) +
-        2 * seg_blocks;
-    // (a page in hand per lane of the launch and a run of 32 per lane
-    // wavefront, tok_page_ask: on top of the share, so that what a launch
-    // keeps in hand does not count against its blocks)
+    // (snapmi_pool.hpp: the share of the worst case, what the launch keeps in
+    // hand, the floor, and "100 means never")
     const uint32_t pool_lanes =
         lanes_mode && !span_match ? lane_count(ctx, seg_blocks, both_cores)
                                   : 0;
-    const uint64_t in_hand = pool_lanes + pool_lanes / 2;
-    uint64_t pool_pages =
-        (worst_pages * ctx->token_pool_now + 99) / 100 + in_hand;
-    if (pool_pages < ctx->token_pool_min_pages)
-        pool_pages = ctx->token_pool_min_pages;
-    if (pool_pages > worst_pages + in_hand)
-        pool_pages = worst_pages + in_hand;
-    // (100 per cent means "never": the bound of every block, whatever the
-    // launches' shares of the bytes)
-    if (ctx->token_pool_now >= 100)
-        pool_pages =
-            seg_blocks * (kTokPagesPerBlock + kExcPagesPerBlock) + in_hand;
+    const uint64_t pool_pages =
+        snapmi::pool_pages(block_bytes, blocks, seg_blocks, pool_lanes,
+                           ctx->token_pool_now, ctx->token_pool_min_pages);
     // (+ the dump page of the lanes)
     const size_t pool_bytes = (size_t)(pool_pages + 1) * kTokPage * 4;
     // the window wavefronts' staging arrays (TokenWriter): one per wavefront
