@@ -83,7 +83,7 @@ readme = f"""## Results (1× MI355X, device resident; ONE box, one `python bench
 
 | workload | compress | decompress |
 |---|---|---|
-| cfg2: zflat/uflat corpus tiled to 8 GiB, 35 208 raw streams (`bench.py`: value **{g(d['value'])} GiB/s**; on a fresh lease, as the driver runs it: 122.7-124.1 on five leases at the final sources, `r6_headline_fresh_leases.txt`; a process started behind the five minutes of the GPU suite on the same box drew 2.07-2.27 ms in the placement probe of its first tables and 109.8-118.0, DESIGN §4.4) | {g(d['compress_gibs'])} GiB/s (`k_match_both` {g(km['compress_dominant'])} ms: {g(rf['frac']*100)} % of the HBM roofline in algorithmic bytes - the kernel is bound by DRAM transactions; its 17 GB of tables are placed inside the context's memory budget now, `DESIGN.md` §4.4) | {g(d['decompress_gibs'],0)} GiB/s ({g(rd['frac']*100)} %) |
+| cfg2: zflat/uflat corpus tiled to 8 GiB, 35 208 raw streams (`bench.py`: value **{g(d['value'])} GiB/s**; on a fresh lease, as the driver runs it: 122.7-124.1 on six leases of seven at the final sources and 111.9 on one whose tables probed 2.20 ms, `r6_headline_fresh_leases.txt`; a process started behind the five minutes of the GPU suite on the same box drew 2.07-2.27 ms in the placement probe of its first tables and 109.8-118.0, DESIGN §4.4) | {g(d['compress_gibs'])} GiB/s (`k_match_both` {g(km['compress_dominant'])} ms: {g(rf['frac']*100)} % of the HBM roofline in algorithmic bytes - the kernel is bound by DRAM transactions; its 17 GB of tables are placed inside the context's memory budget now, `DESIGN.md` §4.4) | {g(d['decompress_gibs'],0)} GiB/s ({g(rd['frac']*100)} %) |
 | the same workload per call of 64 MiB / 256 MiB / 1 GiB / 4 GiB (`extras.sweep`) | {sizes('compress_gibs')} GiB/s | {sizes('decompress_gibs', 0)} GiB/s |
 | cfg3: 64 GiB framed text (the SURVEY generator, ratio 0.7266), 1 048 576 chunks | {g(c3['frame_encode_gibs'])} GiB/s (44.5-48.8 over the round's boxes) | {g(c3['frame_decode_gibs'],0)} GiB/s ({g(c3['frame_decode_no_index_gibs'],0)} without a chunk index) |
 | cfg5: 32 GiB incompressible | {g(c5['compress_gibs'],0)} GiB/s ({g(c5['compress_hbm_frac']*100,0)} % of the HBM peak) | {g(c5['decompress_gibs'],0)} GiB/s ({g(c5['decompress_hbm_frac']*100,0)} %; 2 290-2 690 by where the caller's buffers lie, `DESIGN.md` §5) |
